@@ -1,0 +1,139 @@
+"""
+TEST INFRASTRUCTURE ONLY -- never imported by the product package.
+
+Loads the *real* TimoStoff/event_utils reference from /root/reference so that
+(i) the numpy restatement in oracle/reference_np.py can be validated against it and
+(ii) golden vectors can be generated (oracle/make_golden.py -> tests/golden/*.npz).
+
+The reference only exists in the build container; on the GPU box this module raises
+ReferenceUnavailable and nothing in tests -m gpu / smoke() / bench.py touches it.
+
+No reference source is copied: absent third-party modules (cv2, h5py, skimage,
+event_utils) are stubbed, and the two files that do not parse as shipped
+(lib/contrast_max/warps.py: class docstring at column 0 :7-10 and a stray token :81;
+lib/contrast_max/objectives.py: class docstring at column 0 :11-13) are read from
+/root/reference at run time, patched IN MEMORY (3 edits) and exec'd as modules.
+"""
+import importlib
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("EVK_REFERENCE_ROOT", "/root/reference")
+
+
+class ReferenceUnavailable(RuntimeError):
+    pass
+
+
+_cache = {}
+
+
+def available():
+    return os.path.isfile(os.path.join(REF_ROOT, "lib", "representations", "image.py"))
+
+
+def _stub(name, **attrs):
+    if name in sys.modules:
+        return sys.modules[name]
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _exec_patched(modname, path, patch):
+    with open(path, "r") as f:
+        src = f.read()
+    src = patch(src)
+    mod = types.ModuleType(modname)
+    mod.__file__ = path
+    mod.__package__ = modname.rsplit(".", 1)[0]
+    sys.modules[modname] = mod
+    exec(compile(src, path, "exec"), mod.__dict__)
+    return mod
+
+
+def _patch_warps(src):
+    lines = src.split("\n")
+    out = []
+    for i, ln in enumerate(lines, start=1):
+        if 7 <= i <= 10:          # class docstring at column 0 -> indent it
+            out.append("    " + ln)
+        elif ln.strip() == "{not:timeslice}":   # stray token
+            continue
+        else:
+            out.append(ln)
+    return "\n".join(out)
+
+
+def _patch_objectives(src):
+    lines = src.split("\n")
+    out = []
+    for i, ln in enumerate(lines, start=1):
+        if 11 <= i <= 13:
+            out.append("    " + ln)
+        else:
+            out.append(ln)
+    return "\n".join(out)
+
+
+def load():
+    """Returns a namespace with the reference's hot-path modules:
+    .image, .voxel_grid, .event_util, .warps, .objectives, .events_cmax"""
+    if "ns" in _cache:
+        return _cache["ns"]
+    if not available():
+        raise ReferenceUnavailable("reference not present at %s" % REF_ROOT)
+    import matplotlib
+    matplotlib.use("Agg")
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    try:
+        import cv2  # noqa: F401
+    except Exception:
+        _stub("cv2", NORM_MINMAX=32)
+    try:
+        import h5py  # noqa: F401
+    except Exception:
+        _stub("h5py")
+    try:
+        import skimage  # noqa: F401
+    except Exception:
+        sk = _stub("skimage")
+        sk.measure = _stub("skimage.measure", block_reduce=None)
+    _stub("event_utils")
+    # scipy.ndimage.filters is a deprecated alias; make sure it resolves silently
+    import warnings
+    warnings.filterwarnings("ignore", category=DeprecationWarning)
+
+    image = importlib.import_module("lib.representations.image")
+    voxel_grid = importlib.import_module("lib.representations.voxel_grid")
+    event_util = importlib.import_module("lib.util.event_util")
+
+    pkg = types.ModuleType("lib.contrast_max")
+    pkg.__path__ = [os.path.join(REF_ROOT, "lib", "contrast_max")]
+    sys.modules["lib.contrast_max"] = pkg
+    warps = _exec_patched("lib.contrast_max.warps",
+                          os.path.join(REF_ROOT, "lib", "contrast_max", "warps.py"), _patch_warps)
+    objectives = _exec_patched("lib.contrast_max.objectives",
+                               os.path.join(REF_ROOT, "lib", "contrast_max", "objectives.py"),
+                               _patch_objectives)
+    pkg.warps, pkg.objectives = warps, objectives
+    try:
+        events_cmax = importlib.import_module("lib.contrast_max.events_cmax")
+    except Exception as e:  # visualization deps may be missing; optimize_contrast is restated anyway
+        events_cmax = None
+        _cache["events_cmax_error"] = repr(e)
+
+    ns = types.SimpleNamespace(image=image, voxel_grid=voxel_grid, event_util=event_util,
+                               warps=warps, objectives=objectives, events_cmax=events_cmax)
+    _cache["ns"] = ns
+    return ns
+
+
+if __name__ == "__main__":
+    ns = load()
+    print("loaded:", [k for k, v in vars(ns).items() if v is not None])
+    print("events_cmax error:", _cache.get("events_cmax_error"))

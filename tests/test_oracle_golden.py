@@ -1,0 +1,170 @@
+"""CPU: the numpy restatement (oracle/reference_np.py) against the golden vectors produced by the real
+reference (oracle/make_golden.py).  Integer and f32-sequential paths must be bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import reference_np as R
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+def test_f1_image_nearest_int_bit_exact(golden):
+    g = golden("f1_image_nearest_int")
+    xs, ys, ps = g["xs"].astype(np.int64), g["ys"].astype(np.int64), g["ps"].astype(np.int64)
+    ss = tuple(g["sensor_size"])
+    assert np.array_equal(R.events_to_image(xs, ys, ps, sensor_size=ss), g["img_pm"])
+    assert np.array_equal(R.events_to_image(xs, ys, np.ones_like(ps), sensor_size=ss), g["img_cnt"])
+    assert np.array_equal(R.events_to_image(xs, ys, ps, sensor_size=ss, meanval=True), g["img_mean"])
+    assert np.array_equal(R.events_to_image(xs, ys, ps, sensor_size=ss, meanval=True, default=7), g["img_mean_default"])
+    assert np.array_equal(R.events_to_image(xs, ys, g["wf"], sensor_size=ss), g["img_wf"])
+    assert R.events_to_image(xs, ys, ps, sensor_size=ss).dtype == np.float64
+
+
+def test_f1_errors():
+    xs = np.array([0, 241]); ys = np.array([0, 0]); ps = np.array([1, 1])
+    with pytest.raises(ValueError):
+        R.events_to_image(xs, ys, ps)
+    with pytest.raises(TypeError):
+        R.events_to_image(xs.astype(float), ys.astype(float), ps)
+
+
+@pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
+def test_f2_voxel_numpy(golden, tag, Bs):
+    g = golden("f2_voxel_numpy")
+    xs, ys = g[tag + "_xs"].astype(np.int64), g[tag + "_ys"].astype(np.int64)
+    ts, ps = g[tag + "_ts"], f64(g[tag + "_ps"])
+    for B in Bs:
+        v = R.events_to_voxel(xs, ys, ts, ps, B, sensor_size=tuple(g[tag + "_sensor_size"]))
+        ref = g["%s_voxel_B%d" % (tag, B)]
+        assert v.dtype == np.float64 and v.shape == ref.shape
+        assert np.array_equal(v, ref)
+
+
+@pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
+def test_f3_voxel_torch(golden, tag, Bs):
+    g = golden("f3_voxel_torch")
+    xs, ys, ts = g[tag + "_xs"], g[tag + "_ys"], g[tag + "_ts"]
+    ps = g[tag + "_ps"].astype(np.float32)
+    ss = tuple(g[tag + "_sensor_size"])
+    for B in Bs:
+        ref = g["%s_voxel_B%d" % (tag, B)]
+        v = R.events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=ss)
+        assert v.dtype == np.float32
+        assert np.array_equal(v, ref)
+        v64 = R.events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=ss, accum="f64")
+        assert np.max(np.abs(f64(v64) - f64(ref))) <= 1e-5 * np.max(np.abs(ref))
+    if tag == "dvs":
+        v = R.events_to_voxel_torch(xs.astype(np.int64), ys.astype(np.int64), ts, ps, 5, sensor_size=ss)
+        assert np.array_equal(v, g["dvs_voxel_B5_long"])
+
+
+def test_f4_image_torch(golden):
+    g = golden("f4_image_torch")
+    xs, ys, ps = g["xs"], g["ys"], g["ps"]
+    ss = tuple(g["sensor_size"])
+    assert np.array_equal(R.events_to_image_torch(xs, ys, ps, sensor_size=ss, interpolation='bilinear', padding=True), g["bil_pad"])
+    assert np.array_equal(R.events_to_image_torch(xs, ys, ps, sensor_size=ss, interpolation='bilinear', padding=False), g["bil_nopad"])
+    assert np.array_equal(R.events_to_image_torch(xs, ys, ps, sensor_size=ss, interpolation=None, padding=True), g["near_pad"])
+    assert np.array_equal(R.events_to_image_torch(xs, ys, ps, sensor_size=ss, interpolation=None, padding=False), g["near_nopad"])
+    assert np.array_equal(R.events_to_image_torch(xs, ys, ps, sensor_size=ss, interpolation=None, padding=False, default=3), g["near_default3"])
+    assert np.array_equal(R.events_to_image(f64(xs), f64(ys), f64(ps), sensor_size=ss, interpolation='bilinear', padding=False), g["np_bil"])
+    assert np.array_equal(R.events_to_image(f64(xs), f64(ys), f64(ps), sensor_size=ss, interpolation='bilinear', padding=True), g["np_bil_pad"])
+
+
+def test_f5_warp(golden):
+    g = golden("f5_warp")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w = R.linvel_warp()
+    assert (w.name, w.dims) == ("linvel_warp", 2)
+    for i, prm in enumerate(g["params"]):
+        xp, yp, jx, jy = w.warp(x, y, t, p, t[-1], prm, compute_grad=True)
+        for a, k in ((xp, "xp"), (yp, "yp"), (jx, "jx"), (jy, "jy")):
+            assert np.array_equal(a, g["%s%d" % (k, i)])
+        assert np.array_equal(R.events_bounds_mask(xp, yp, 0, 240, 0, 180), g["mask%d" % i])
+    xp, yp, jx, jy = w.warp(x, y, t, p, t[-1], g["params"][1])
+    assert jx is None and jy is None
+
+
+def test_f6_get_iwe_verbatim(golden):
+    g = golden("f6_get_iwe")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w = R.linvel_warp()
+    img_size = tuple(g["img_size"])
+    for i, prm in enumerate(g["params"]):
+        iwe, diwe = R.get_iwe(prm, x, y, t, p, w, img_size, compute_gradient=True)
+        assert iwe.shape == (181, 241) and diwe.shape == (2, 181, 241) and iwe.dtype == np.float32
+        assert np.array_equal(iwe, g["iwe%d" % i])
+        assert np.array_equal(diwe, g["diwe%d" % i])
+    iwe, d = R.get_iwe(g["params"][0], x, y, t, p, w, img_size, compute_gradient=False, use_polarity=False)
+    assert d is None and np.array_equal(iwe, g["iwe_nopol0"])
+    # Q1: img_size only sets the bounds mask, the canvas stays (181, 241)
+    x, y, t, p = f64(g["q1_xs"]), f64(g["q1_ys"]), f64(g["q1_ts"]), f64(g["q1_ps"])
+    iwe, diwe = R.get_iwe(np.array([30., -20.]), x, y, t, p, w, tuple(g["q1_img_size"]), compute_gradient=True)
+    assert np.array_equal(iwe, g["q1_iwe"]) and np.array_equal(diwe, g["q1_diwe"])
+
+
+@pytest.mark.parametrize("tag", ["s48", "vga"])
+def test_f7_iwe_sized(golden, tag):
+    g = golden("f7_iwe_sized")
+    x, y, t, p = f64(g[tag + "_xs"]), f64(g[tag + "_ys"]), f64(g[tag + "_ts"]), f64(g[tag + "_ps"])
+    ss = tuple(g[tag + "_sensor_size"])
+    iwe, diwe = R.get_iwe(g["params"], x, y, t, p, R.linvel_warp(), ss, compute_gradient=True, sensor_size=ss)
+    assert np.array_equal(iwe, g[tag + "_iwe"]) and np.array_equal(diwe, g[tag + "_diwe"])
+    iwe64, diwe64 = R.get_iwe(g["params"], x, y, t, p, R.linvel_warp(), ss, compute_gradient=True, sensor_size=ss, accum="f64")
+    assert np.max(np.abs(f64(iwe64) - f64(iwe))) <= 1e-5 * np.max(np.abs(iwe))
+    assert np.max(np.abs(f64(diwe64) - f64(diwe))) <= 1e-5 * np.max(np.abs(diwe))
+
+
+def test_f10_blur(golden):
+    from scipy.ndimage import gaussian_filter
+    g = golden("f10_blur")
+    a3 = g["a3"]
+    for s in (1.0, 2.0, 0.5):
+        assert np.array_equal(R.gaussian_filter_reflect(a3, s), g["blur3_s%g" % s])
+        assert np.array_equal(R.gaussian_filter_reflect(a3[0], s), g["blur2_s%g" % s])
+        assert np.array_equal(R.gaussian_filter_reflect(a3, s), gaussian_filter(a3, s))   # scipy on this box
+    assert np.array_equal(R.gaussian_filter_reflect(g["small"], 1.0), g["small_blur_s1"])
+    # Q4: channel mixing of the 2-channel axis at sigma=1
+    z = np.zeros((2, 21, 21), dtype=np.float32); z[0, 10, 10] = 1
+    b = R.gaussian_filter_reflect(z, 1.0)
+    assert abs(b[0].sum() - 0.64561) < 1e-4 and abs(b[1].sum() - 0.35439) < 1e-4
+
+
+def test_f8_objective(golden):
+    g = golden("f8_objective")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w, obj = R.linvel_warp(), R.variance_objective()
+    img_size = tuple(g["img_size"])
+    for i, prm in enumerate(g["params"]):
+        for j, s in enumerate(g["sigmas"]):
+            f = obj.evaluate_function(prm, x, y, t, p, w, img_size, blur_sigma=s)
+            gr = obj.evaluate_gradient(prm, x, y, t, p, w, img_size, blur_sigma=s)
+            assert np.float64(f) == g["f"][i, j]
+            assert np.array_equal(f64(gr), g["grad"][i, j])
+    al = R.variance_objective(adaptive_lifespan=True, minimum_events=5000)
+    al.iter_update(np.array([400., -250.]))
+    f = al.evaluate_function(np.array([40., -25.]), x, y, t, p, w, img_size, blur_sigma=1.0)
+    assert al.s_idx == g["al_s_idx"] and np.float64(f) == g["al_f"]
+    al.iter_update(np.array([400., -250.]))
+    assert np.array_equal(f64(al.evaluate_gradient(np.array([40., -25.]), x, y, t, p, w, img_size, blur_sigma=1.0)), g["al_grad"])
+
+
+@pytest.mark.parametrize("mode", ["numeric", "analytic"])
+def test_f9_optimize_trace(golden, mode):
+    g8, g = golden("f8_objective"), golden("f9_optimize_trace")
+    x, y, t, p = f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"])
+    obj = R.variance_objective()
+    trace = []
+    f0, g0 = obj.evaluate_function, obj.evaluate_gradient
+    obj.evaluate_function = lambda prm, *a, **k: (trace.append(("f", np.array(prm, float))), f0(prm, *a, **k))[1]
+    obj.evaluate_gradient = lambda prm, *a, **k: (trace.append(("g", np.array(prm, float))), g0(prm, *a, **k))[1]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        argmax = R.optimize_contrast(x, y, t, p, R.linvel_warp(), obj, numeric_grads=(mode == "numeric"),
+                                     blur_sigma=1.0, img_size=tuple(g8["img_size"]))
+    assert np.allclose(argmax, g[mode + "_argmax"], rtol=0, atol=1e-9)
+    assert [k for k, _ in trace] == list(g[mode + "_kind"])
+    assert np.allclose(np.array([q for _, q in trace]), g[mode + "_params"], rtol=0, atol=1e-9)
