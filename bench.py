@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark (BASELINE.json): Mevents/s of events_to_voxel_torch, 5 temporal bins, 640x480, 10 M
+synthetic events per GPU resident in HBM (configs[1]); plus contrast-maximisation evaluations/s (configs[2] shape) in
+the `cmax` object.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank voxelises ITS shard of the stream
+(weak scaling: 10 M events per rank, disjoint time-sorted slices of one N*10 M stream) and the (B, H, W) grids are
+all-reduced (the path's only exchange step).  value = events of all ranks / max-over-ranks time.
+
+A "step" = one full voxelisation of the resident events (everything the product does for one call, including any
+bucketing pre-pass and the output memset; excluding only the host<->device copies of the events).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, B = 480, 640, 5
+N_PER_GPU = 10_000_000
+HBM_PEAK_GBS = 8000.0
+
+
+def synth(seed, n, t_lo, t_hi, real_xy=False):
+    rng = np.random.default_rng(seed)
+    if real_xy:
+        x = rng.uniform(1, W - 1, n).astype(np.float32)
+        y = rng.uniform(1, H - 1, n).astype(np.float32)
+    else:
+        x = rng.integers(0, W, n).astype(np.float32)
+        y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(t_lo, t_hi, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    return x, y, t, p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--events", type=int, default=N_PER_GPU)
+    ap.add_argument("--impl", default=None, help="kernel variant: direct | tiled | auto")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cmax", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import event_utils_amd as E
+    from event_utils_amd import tiled
+    from event_utils_amd.events import DeviceEvents
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+
+    n = args.events
+    # rank r holds the r-th time slice of one stream spanning [0, 0.1 s)
+    span = 0.1 / world
+    x, y, t, p = synth(1 + rank, n, rank * span, (rank + 1) * span)
+    xd, yd, td, pd = (torch.from_numpy(a).to(dev) for a in (x, y, t, p))
+    t_first, t_last = 0.0, 0.1
+    if world > 1:   # global ts[0] / ts[-1]: two scalars, agreed once outside the timed region
+        lo = torch.tensor([float(t[0])], device=dev)
+        hi = torch.tensor([float(t[-1])], device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        t_first, t_last = float(lo.item()), float(hi.item())
+    else:
+        t_first, t_last = float(t[0]), float(t[-1])
+
+    out = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+    impl = args.impl or tiled.default_impl()
+
+    def step():
+        out.zero_()
+        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=out, check=False, impl=impl)
+        if world > 1:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        step()
+        ev1[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * world / (elapsed / args.steps) / 1e6
+    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    # ---- roofline of the dominant kernel(s): HIP-event timing of the voxel call alone (no memset, no collective) ----
+    kinfo = tiled.time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=impl, reps=max(5, args.steps))
+    alg_bytes = 16.0 * n + out.numel() * 4.0
+    dom_ms = kinfo["dominant_ms"]
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kinfo["dominant"],
+                "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": alg_bytes,
+                "whole_call_ms": round(kinfo["total_ms"], 4),
+                "whole_call_frac": round(alg_bytes / (kinfo["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels_ms": kinfo["kernels_ms"]}
+
+    result = {
+        "metric": "Mevents/s (voxel 5-bin 640x480)", "value": round(value, 1), "unit": "Mevents/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 10M events/GPU, 640x480, events_to_voxel_torch 5 temporal bins "
+                               "(temporal-bilinear, nearest pixel), uniform-random events, columns resident in HBM",
+                   "events_per_gpu": n, "sensor": [H, W], "bins": B, "impl": kinfo["impl"],
+                   "parallelism": "event-sharded x%d, all-reduce of the (B,H,W) grid" % world if world > 1 else "single GPU"},
+        "device_ms_per_step": round(dev_ms, 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cmax:
+        result["cmax"] = bench_cmax(E, DeviceEvents, dev, impl)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(x, y, t, p)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_cmax(E, DeviceEvents, dev, impl):
+    """configs[2] shape: 10 M events, 640x480, linear-flow warp + IWE + variance (and + analytic gradient)."""
+    n = N_PER_GPU
+    x, y, t, p = synth(2, n, 0.0, 0.1, real_xy=True)
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.sensor_size = (H, W)
+    obj.impl = impl
+    prm = np.array([30.0, -20.0])
+    res = {"workload": "configs[2]: 10M events, 640x480, get_iwe(linvel)+blur+variance; params (30,-20) px/s"}
+    for name, fn in (("f", obj.evaluate_function), ("grad", obj.evaluate_gradient)):
+        for _ in range(2):
+            fn(prm, ev, None, None, None, w, (H, W), 1.0)
+        torch.cuda.synchronize()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(prm, ev, None, None, None, w, (H, W), 1.0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name + "_evals_per_s"] = round(1.0 / dt, 2)
+        res[name + "_ms"] = round(dt * 1e3, 4)
+        res[name + "_Mevents_per_s"] = round(n / dt / 1e6, 1)
+        res[name + "_hbm_frac"] = round((16.0 * n) / dt / 1e9 / HBM_PEAK_GBS, 4)
+    return res
+
+
+def cpu_baseline(x, y, t, p):
+    """The reference's numpy CPU path (events_to_voxel, voxel_grid.py:184-217) as restated in oracle/reference_np.py,
+    timed on this box's host, one thread, on the same 10 M-event workload (bounded: 1 warm-up on 1 M, 2 timed reps)."""
+    from oracle import reference_np as R
+    xi, yi = x.astype(np.int64), y.astype(np.int64)
+    t64, p64 = t.astype(np.float64), p.astype(np.float64)
+    m = 1_000_000
+    R.events_to_voxel(xi[:m], yi[:m], t64[:m], p64[:m], B, sensor_size=(H, W))
+    reps, best = 2, []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        R.events_to_voxel(xi, yi, t64, p64, B, sensor_size=(H, W))
+        best.append(time.perf_counter() - t0)
+    dt = float(np.median(best))
+    return {"value": round(len(x) / dt / 1e6, 2), "unit": "Mevents/s", "cores": 1, "kind": "port",
+            "sample": "oracle numpy events_to_voxel (reference numpy path), %d events, 640x480x5, median of %d runs, "
+                      "%.2f s each; host has %d logical cores" % (len(x), reps, dt, os.cpu_count())}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Device plumbing: PyTorch-ROCm is used ONLY for device memory, streams and torch.distributed.  All arithmetic on
+event data happens in libevk.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.EvkError("event_utils_amd needs an AMD GPU (MI355X / gfx950): torch.cuda.is_available() is False "
+                            "and there is no CPU fallback")
+    _lib.lib()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+_NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+
+
+def to_device(a, dtype, device=None):
+    """numpy array / torch tensor (any device) -> contiguous 1-D+ torch tensor of `dtype` on the GPU.
+    No copy when `a` already is such a tensor."""
+    device = device or require_gpu()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+    a = np.asarray(a)
+    want = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}[dtype]
+    if a.dtype != want:
+        a = a.astype(want)
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a).to(device, non_blocking=False)
+
+
+def zeros(shape, dtype=torch.float32, device=None):
+    return torch.zeros(shape, dtype=dtype, device=device or require_gpu())
+
+
+class OobCounter:
+    """Lazily-checked device counter of events the reference would have rejected with an exception."""
+
+    def __init__(self, device=None):
+        self.t = torch.zeros(1, dtype=torch.int32, device=device or require_gpu())
+
+    @property
+    def ptr(self):
+        return ptr(self.t)
+
+    def raise_if_set(self, exc_type, msg):
+        n = int(self.t.item())  # synchronises; the reference is synchronous too
+        if n:
+            raise exc_type("%s (%d offending events)" % (msg, n))
+
+
+_scratch = {}
+
+
+def reduce_scratch(device):
+    key = (device.index, "reduce")
+    if key not in _scratch:
+        nbytes = int(_lib.lib().evk_reduce_scratch_bytes())
+        _scratch[key] = (torch.empty(nbytes // 8, dtype=torch.float64, device=device), nbytes)
+    return _scratch[key]

@@ -1,0 +1,80 @@
+"""ctypes binding of libevk.so (include/evk.h).  There is NO fallback: if the HIP library is missing or cannot be
+loaded the product fails loudly -- build it with `python -m event_utils_amd.csrc.build` (or __graft_entry__.build())."""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libevk.so")
+
+EVK_IWE_ABS_POLARITY = 1
+EVK_IWE_GRADIENT = 2
+
+P = c_void_p  # every device / host pointer crosses as void*
+
+# name -> argtypes (restype is int unless noted); mirrors include/evk.h one-to-one
+SIGNATURES = {
+    "evk_image_nearest_i32": [P, P, P, c_int64, c_int, c_int, P, P, P],
+    "evk_image_nearest_f64": [P, P, P, c_int64, c_int, c_int, P, P, P],
+    "evk_image_nearest_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P],
+    "evk_image_bilinear_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P],
+    "evk_splat_indexed_f32": [P, P, P, P, P, c_int64, c_int, c_int, P, P, P],
+    "evk_splat_drv_indexed_f32": [P, P, P, P, P, P, c_int, c_int64, c_int, c_int, P, P, P],
+    "evk_image_drv_f64": [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, P],
+    "evk_voxel_f32": [P, P, P, P, c_int64, c_float, c_float, c_int, c_int, c_int, P, P, P],
+    "evk_voxel_f64": [P, P, P, P, c_int64, c_double, c_double, c_int, c_int, c_int, P, P, P],
+    "evk_warp_linvel_f64": [P, P, P, c_int64, c_double, c_double, c_double, P, P, P, P, P],
+    "evk_bounds_mask_f64": [P, P, c_int64, c_double, c_double, c_double, c_double, P, P],
+    "evk_iwe_linvel_f32": [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, c_int,
+                           c_uint32, c_double, P, P, P],
+    "evk_iwe_linvel_f64": [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, c_int,
+                           c_uint32, c_double, P, P, P],
+    "evk_gaussian_filter_f32": [P, P, P, c_int, P, P, c_int, P],
+    "evk_variance_f32": [P, c_int64, P, P, c_int64, P],
+    "evk_variance_grad_f32": [P, P, c_int64, P, P, c_int64, P],
+}
+_SPECIAL = {
+    "evk_version": ([], c_int),
+    "evk_error_string": ([c_int], c_char_p),
+    "evk_reduce_scratch_bytes": ([], c_int64),
+}
+
+
+class EvkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built -- never falls back to a CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise EvkError("libevk.so is not built (%s missing): run `python -m event_utils_amd.csrc.build`; "
+                           "event_utils_amd has no CPU fallback" % LIB_PATH)
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise EvkError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        for name, (argtypes, restype) in _SPECIAL.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().evk_error_string(rc)
+        raise EvkError("%s failed: %s (code %d)" % (what or "evk call", msg.decode() if msg else "?", rc))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

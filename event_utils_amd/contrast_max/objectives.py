@@ -1,0 +1,248 @@
+"""
+Contrast-maximisation objectives on MI355X.  Mirrors the reference's lib/contrast_max/objectives.py plugin API
+(objective_function ABC :10-140, get_iwe :165-199, variance_objective :202-264).  Events live on the device
+(events.DeviceEvents); one evaluation = one streaming pass of the fused warp -> mask -> bilinear-splat kernel over the
+events + a few image-sized kernels; only the motion parameters and 4 doubles cross PCIe.
+
+Extensions (all default to the reference's behaviour):
+  objective.sensor_size   None = quirk Q1 (the IWE canvas is always (181, 241), objectives.py:191-192);
+                          (H, W) = use that sensor size for the canvas (configs with img_size != (180, 240)).
+  objective.reference_exact  True = quirks Q4/Q5 (channel-mixing 3-D blur of dIWE, un-blurred IWE in the gradient);
+                          False = per-channel blur and blurred IWE: the true gradient of evaluate_function.
+  objective.process_group / objective.distributed  event-sharded data parallelism: each rank accumulates its shard,
+                          IWE (+dIWE) are all-reduced over RCCL before blur / reductions.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from .. import _device as D
+from .. import _lib
+from .. import tiled
+from ..events import DeviceEvents
+from ..representations.image import _events_to_image_drv_device
+from ..util.event_util import events_bounds_mask
+
+
+def gaussian_kernel1d(sigma, truncate=4.0):
+    """The kernel scipy.ndimage.gaussian_filter builds (order 0): radius int(truncate*sigma+0.5), normalised
+    exp(-x^2/(2 sigma^2)) in float64 (the reference calls scipy at objectives.py:233,253)."""
+    sigma = float(sigma)
+    radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def gaussian_filter_device(src, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(src, sigma) (mode='reflect') for a 2-D or 3-D float32 device tensor."""
+    w, radius = gaussian_kernel1d(sigma, truncate)
+    src = src.contiguous()
+    dst, tmp = torch.empty_like(src), torch.empty_like(src)
+    dims = np.array(src.shape, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    _lib.call("evk_gaussian_filter_f32", D.ptr(src), D.ptr(dst), D.ptr(tmp), src.dim(), D.host_ptr(dims),
+              D.host_ptr(w), radius, D.stream())
+    return dst
+
+
+def _as_device_events(xs, ys, ts, ps):
+    if isinstance(xs, DeviceEvents):
+        return xs
+    return DeviceEvents.from_arrays(xs, ys, ts, ps)
+
+
+def iwe_device(params, ev, img_size, compute_gradient=False, use_polarity=True, sensor_size=None, impl=None,
+               process_group=None, distributed=False, t_ref=None):
+    """Fused linear-flow get_iwe on device-resident events -> (iwe, d_iwe | None) float32 device tensors of shape
+    (H+1, W+1) / (2, H+1, W+1).  t_ref defaults to ts[-1] of `ev` (objectives.py:186); an event-sharded caller passes
+    the GLOBAL ts[-1]."""
+    dev = ev.x.device
+    ss = (180, 240) if sensor_size is None else sensor_size       # Q1
+    ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
+    buf = torch.zeros((3 if compute_gradient else 1, ch, cw), dtype=torch.float32, device=dev)
+    iwe, diwe = buf[0], (buf[1:3] if compute_gradient else None)
+    flags = (0 if use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if compute_gradient else 0)
+    if t_ref is None:
+        t_ref = ev.t_at(-1)
+    if len(ev):
+        tiled.iwe_linvel(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
+                         float(img_size[0]), ch, cw, flags, iwe, diwe, impl=impl)
+    if distributed or process_group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+    return iwe, diwe
+
+
+def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, use_polarity=True,
+            return_events=False, return_per_event_contrast=False, sensor_size=None):
+    """
+    Image of warped events and its derivative w.r.t. the motion parameters (reference: objectives.py:165-199):
+    warp at t0 = ts[-1] (:186) -> events_bounds_mask(0, img_size[1], 0, img_size[0]) (:187) -> multiply everything by
+    the mask (:188-190) -> events_to_image_drv with its DEFAULT sensor_size (:191-192, quirk Q1; pass sensor_size to
+    override).  Returns numpy float32 (iwe, d_iwe | None [, (xs, ys)]).
+    linvel_warp uses the fused kernel; any other warp_function plugin is called as upstream and its output goes
+    through the generic mask + splat kernels.
+    """
+    if return_per_event_contrast:
+        raise NotImplementedError("return_per_event_contrast (image_to_event_weights gather, image.py:138-160) is a "
+                                  "'next' row of the hot-path table")
+    fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
+    if fused and not return_events:
+        ev = _as_device_events(xs, ys, ts, ps)
+        iwe, diwe = iwe_device(params, ev, img_size, compute_gradient, use_polarity, sensor_size)
+        return iwe.cpu().numpy(), (diwe.cpu().numpy() if diwe is not None else None)
+    # generic plugin path (and return_events): materialise the warp as the reference does
+    if isinstance(xs, DeviceEvents):
+        ev = xs
+        xs, ys, ts, ps = (c.double() for c in (ev.x, ev.y, ev.t, ev.p * ev.p_scale))
+    if not use_polarity:
+        ps = np.abs(ps) if not isinstance(ps, torch.Tensor) else ps.abs()
+    t0 = ts[-1] if not isinstance(ts, torch.Tensor) else float(ts[-1].item())
+    xw, yw, jx, jy = warpfunc.warp(xs, ys, ts, ps, t0, params, compute_grad=compute_gradient)
+    mask = events_bounds_mask(xw, yw, 0, img_size[1], 0, img_size[0])
+    xw, yw, pm = xw * mask, yw * mask, ps * mask
+    if compute_gradient:
+        jx, jy = jx * mask, jy * mask
+    kw = {} if sensor_size is None else {"sensor_size": tuple(sensor_size)}
+    iwe, diwe = _events_to_image_drv_device(xw, yw, pm, jx, jy, kw.get("sensor_size", (180, 240)), True, 'bilinear',
+                                            True, compute_gradient)
+    returnval = [iwe.cpu().numpy(), diwe.cpu().numpy() if diwe is not None else None]
+    if return_events:
+        to_np = (lambda a: a.cpu().numpy()) if isinstance(xw, torch.Tensor) else (lambda a: a)
+        returnval.append((to_np(xw), to_np(yw)))
+    return tuple(returnval)
+
+
+class objective_function(ABC):
+    """Parent class of contrast-maximisation objectives (reference: objectives.py:10-140): constructor attributes,
+    abstract evaluate_function / evaluate_gradient, iter_update (:113-127), update_lifespan (:129-140)."""
+
+    def __init__(self, name="template", use_polarity=True, has_derivative=True, default_blur=1.0,
+                 adaptive_lifespan=False, pixel_crossings=5, minimum_events=10000):
+        self.name = name
+        self.use_polarity = use_polarity
+        self.has_derivative = has_derivative
+        self.default_blur = default_blur
+        self.adaptive_lifespan = adaptive_lifespan
+        self.pixel_crossings = pixel_crossings
+        self.minimum_events = minimum_events
+
+        self.recompute_lifespan = True
+        self.lifespan = 0.5
+        self.s_idx = 0
+        self.num_events = None
+        # extensions, see module docstring
+        self.sensor_size = None
+        self.reference_exact = True
+        self.process_group = None
+        self.distributed = False
+        self.impl = None
+        self.t_ref = None
+        super().__init__()
+
+    @abstractmethod
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        pass
+
+    @abstractmethod
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        pass
+
+    def iter_update(self, params, pixel_crossings=None):
+        """Callback at each optimisation step: lifespan = pixel_crossings / |params| (5 if 0) (objectives.py:113-127)."""
+        pixel_crossings = self.pixel_crossings if pixel_crossings is None else pixel_crossings
+        magnitude = np.linalg.norm(params)
+        if magnitude == 0:
+            dt = 5
+        else:
+            dt = pixel_crossings / magnitude
+        self.lifespan = dt
+        self.recompute_lifespan = True
+
+    def update_lifespan(self, ts):
+        """New start index of the events used in optimisation (objectives.py:129-140; no prints on the hot path)."""
+        if self.adaptive_lifespan:
+            self.s_idx = np.searchsorted(ts, ts[-1] - self.lifespan)
+            self.s_idx = len(ts) - self.minimum_events if len(ts) - self.s_idx < self.minimum_events else self.s_idx
+        if self.num_events is None:
+            self.num_events = len(ts) - self.s_idx
+
+    # -- shared device plumbing ------------------------------------------------------------------------------
+    def _lifespan_cut(self, ev):
+        """xs[s_idx:-1] ... and ps*100 (objectives.py:217-225, quirk Q10: the last event is dropped)."""
+        if not self.adaptive_lifespan:
+            return ev
+        if self.recompute_lifespan:
+            self.update_lifespan(ev.t_host())
+            self.recompute_lifespan = False
+        return ev.slice(int(self.s_idx), -1).scaled(100.0)
+
+    def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):
+        fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
+        if fused:
+            ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
+            return iwe_device(params, ev, img_size, compute_gradient, self.use_polarity, self.sensor_size, self.impl,
+                              self.process_group, self.distributed, self.t_ref)
+        if self.adaptive_lifespan:
+            if self.recompute_lifespan:
+                self.update_lifespan(ts)
+                self.recompute_lifespan = False
+            xs, ys, ts, ps = xs[self.s_idx:-1], ys[self.s_idx:-1], ts[self.s_idx:-1], ps[self.s_idx:-1]
+            ps = ps * 100
+        dev = D.require_gpu()
+        iwe, diwe = get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=compute_gradient,
+                            use_polarity=self.use_polarity, sensor_size=self.sensor_size)
+        return D.to_device(iwe, torch.float32, dev), (D.to_device(diwe, torch.float32, dev) if diwe is not None else None)
+
+
+class variance_objective(objective_function):
+    """Variance objective (Gallego et al.; reference: objectives.py:202-264)."""
+
+    def __init__(self, adaptive_lifespan=False, minimum_events=10000):
+        super().__init__(name="variance", use_polarity=True, has_derivative=True, default_blur=1.0,
+                         adaptive_lifespan=adaptive_lifespan, pixel_crossings=5, minimum_events=minimum_events)
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        """-var(blur(iwe) - mean) over the whole padded image (objectives.py:211-236, Q6)."""
+        dev = D.require_gpu()
+        if iwe is None:
+            iwe, _ = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, False)
+        else:
+            iwe = D.to_device(iwe, torch.float32, dev)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        if blur_sigma > 0:
+            iwe = gaussian_filter_device(iwe, blur_sigma)
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        scratch, nbytes = D.reduce_scratch(dev)
+        _lib.call("evk_variance_f32", D.ptr(iwe.contiguous()), iwe.numel(), D.ptr(out), D.ptr(scratch), nbytes,
+                  D.stream())
+        loss = out[1].item()
+        return np.float32(-loss)
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        """-mean(2 (iwe-mean(iwe)) * blur(d_iwe)[i]) (objectives.py:238-264).  reference_exact keeps Q4 (3-D blur mixes
+        the two channels) and Q5 (IWE is NOT blurred here)."""
+        dev = D.require_gpu()
+        if iwe is None or d_iwe is None:
+            iwe, d_iwe = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, True)
+        else:
+            iwe, d_iwe = D.to_device(iwe, torch.float32, dev), D.to_device(d_iwe, torch.float32, dev)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        if blur_sigma > 0:
+            if self.reference_exact:
+                d_iwe = gaussian_filter_device(d_iwe, blur_sigma)
+            else:
+                d_iwe = torch.stack([gaussian_filter_device(d_iwe[i], blur_sigma) for i in range(d_iwe.shape[0])])
+                iwe = gaussian_filter_device(iwe, blur_sigma)
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        scratch, nbytes = D.reduce_scratch(dev)
+        _lib.call("evk_variance_grad_f32", D.ptr(iwe.contiguous()), D.ptr(d_iwe.contiguous()), iwe.numel(), D.ptr(out),
+                  D.ptr(scratch), nbytes, D.stream())
+        g = out[:2].cpu().numpy()
+        return -(g.astype(np.float32))

@@ -1,0 +1,172 @@
+"""
+Event -> image accumulation on MI355X.  Same names, positional order, defaults, return dtypes and exception types as
+the reference's lib/representations/image.py; the per-event work runs in libevk.so (HIP), there is no CPU path.
+
+Reference citations are file:line in the reference checkout (lib/representations/image.py unless stated).
+"""
+import numpy as np
+import torch
+
+from .. import _device as D
+from .. import _lib
+
+_INF = float("inf")
+
+
+def _is_int_tensor(t):
+    return t.dtype in (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8)
+
+
+def _clip_thresholds(img_size, clip_out_of_range, interpolation, padding):
+    """image.py:73-74 / :193-194."""
+    if not clip_out_of_range:
+        return _INF, _INF
+    clipx = img_size[1] if interpolation is None and padding == False else img_size[1] - 1  # noqa: E712
+    clipy = img_size[0] if interpolation is None and padding == False else img_size[0] - 1  # noqa: E712
+    return float(clipx), float(clipy)
+
+
+def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padding=False, meanval=False, default=0):
+    """
+    Place events into an image (reference: image.py:5-44).  numpy in, float64 numpy out.
+    Nearest branch (:28-41): accumulate on the (H+1, W+1) canvas, crop to (H, W) (:44); integer weights are
+    accumulated in int32 on the device, so the result is bit-exact with np.bincount.  Integer coordinates are
+    required (TypeError otherwise), coordinates outside the canvas raise ValueError (:30-36).
+    Bilinear branch (:18-27): defers to events_to_image_torch WITHOUT sensor_size (always (180, 240)), as upstream.
+    """
+    img_size = (sensor_size[0] + 1, sensor_size[1] + 1)
+    if interpolation == 'bilinear':
+        xt, yt, pt = (torch.from_numpy(np.ascontiguousarray(a)).float() for a in (xs, ys, ps))
+        img = events_to_image_torch(xt, yt, pt, clip_out_of_range=True, interpolation='bilinear', padding=padding)
+        img[img == 0] = default
+        img = img.numpy()
+        if meanval:
+            event_count_image = events_to_image_torch(xt, yt, torch.ones_like(xt), clip_out_of_range=True,
+                                                      padding=padding).numpy()
+    else:
+        xs, ys, ps = np.asarray(xs), np.asarray(ys), np.asarray(ps)
+        if not (np.issubdtype(xs.dtype, np.integer) and np.issubdtype(ys.dtype, np.integer)):
+            raise TypeError("only int indices permitted")      # np.ravel_multi_index, image.py:31
+        dev = D.require_gpu()
+        n = xs.shape[0]
+        xd, yd = D.to_device(xs, torch.int32), D.to_device(ys, torch.int32)
+        oob = D.OobCounter(dev)
+        int_w = np.issubdtype(ps.dtype, np.integer) or ps.dtype == np.bool_
+        if int_w and (n == 0 or float(np.abs(ps.astype(np.int64)).max()) * n < 2 ** 31):
+            canvas = torch.zeros(img_size, dtype=torch.int32, device=dev)
+            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(D.to_device(ps, torch.int32)), n,
+                      img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
+        else:
+            canvas = torch.zeros(img_size, dtype=torch.float64, device=dev)
+            _lib.call("evk_image_nearest_f64", D.ptr(xd), D.ptr(yd), D.ptr(D.to_device(ps, torch.float64)), n,
+                      img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
+        if meanval:
+            cnt = torch.zeros(img_size, dtype=torch.int32, device=dev)
+            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), None, n, img_size[0], img_size[1], D.ptr(cnt),
+                      None, D.stream())
+            event_count_image = cnt.cpu().numpy().astype(np.float64)
+        oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas %s" % (img_size,))
+        img = canvas.cpu().numpy().astype(np.float64)
+    if meanval:
+        img = np.divide(img, event_count_image, out=np.ones_like(img) * default, where=event_count_image != 0)
+    return img[0:sensor_size[0], 0:sensor_size[1]]
+
+
+def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_out_of_range=True,
+                          interpolation=None, padding=True, default=0):
+    """
+    Event tensors -> float32 image tensor on `device` (reference: image.py:46-100), nearest or bilinear.
+    Quirks kept: nearest-branch clipping moves rejected events to pixel (0,0) with their weight intact (Q8, :93-95);
+    with the default padding=True, interpolation=None the thresholds are W-1 / H-1 (:73-74); float coordinates are
+    truncated toward zero (.long(), :88-91); out-of-range indices raise IndexError (:96-99).
+    """
+    if device is None:
+        device = xs.device
+    if interpolation == 'bilinear' and padding:
+        img_size = (sensor_size[0] + 1, sensor_size[1] + 1)
+    else:
+        img_size = list(sensor_size)
+    dev = D.require_gpu()
+    clipx, clipy = _clip_thresholds(img_size, clip_out_of_range, interpolation, padding)
+    if ps.dtype == torch.float64:
+        raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
+                           "destination and Double for the source.")
+    n = xs.shape[0]
+    img = torch.full(tuple(img_size), float(default), dtype=torch.float32, device=dev)
+    oob = D.OobCounter(dev)
+    xd, yd = D.to_device(xs, torch.float32), D.to_device(ys, torch.float32)   # ints < 2^24 are exact in f32
+    pd = D.to_device(ps.squeeze() if ps.dim() > 1 else ps, torch.float32)
+    if interpolation == 'bilinear' and not _is_int_tensor(xs):
+        _lib.call("evk_image_bilinear_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, img_size[0], img_size[1], clipx, clipy,
+                  D.ptr(img), oob.ptr, D.stream())
+    else:
+        if ps.dtype != torch.float32:
+            raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
+                               "destination and %s for the source." % str(ps.dtype))
+        _lib.call("evk_image_nearest_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, img_size[0], img_size[1], clipx, clipy,
+                  D.ptr(img), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),))
+    return img.to(device)
+
+
+def interpolate_to_image(pxs, pys, dxs, dys, weights, img):
+    """Accumulate with bilinear weights into `img` IN PLACE (reference: image.py:102-115).  Tensors in, `img` is
+    returned; a CPU `img` is round-tripped through the GPU."""
+    dev = D.require_gpu()
+    work = img if img.is_cuda else img.to(dev)
+    work = work if work.is_contiguous() else work.contiguous()
+    oob = D.OobCounter(dev)
+    _lib.call("evk_splat_indexed_f32", D.ptr(D.to_device(pxs, torch.int64)), D.ptr(D.to_device(pys, torch.int64)),
+              D.ptr(D.to_device(dxs, torch.float32)), D.ptr(D.to_device(dys, torch.float32)),
+              D.ptr(D.to_device(weights, torch.float32)), pxs.shape[0], work.shape[0], work.shape[1], D.ptr(work),
+              oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img.shape),))
+    if work is not img:
+        img.copy_(work)
+    return img
+
+
+def interpolate_to_derivative_img(pxs, pys, dxs, dys, d_img, w1, w2):
+    """Derivative-of-bilinear accumulate into `d_img` (C, H, W) IN PLACE (reference: image.py:117-136)."""
+    dev = D.require_gpu()
+    work = d_img if d_img.is_cuda else d_img.to(dev)
+    work = work if work.is_contiguous() else work.contiguous()
+    oob = D.OobCounter(dev)
+    _lib.call("evk_splat_drv_indexed_f32", D.ptr(D.to_device(pxs, torch.int64)), D.ptr(D.to_device(pys, torch.int64)),
+              D.ptr(D.to_device(dxs, torch.float32)), D.ptr(D.to_device(dys, torch.float32)),
+              D.ptr(D.to_device(w1, torch.float32)), D.ptr(D.to_device(w2, torch.float32)), work.shape[0],
+              pxs.shape[0], work.shape[1], work.shape[2], D.ptr(work), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(d_img.shape),))
+    if work is not d_img:
+        d_img.copy_(work)
+    return d_img
+
+
+def _events_to_image_drv_device(xn, yn, pn, jacobian_xn, jacobian_yn, sensor_size, clip_out_of_range, interpolation,
+                                padding, compute_gradient):
+    dev = D.require_gpu()
+    img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
+    clipx, clipy = _clip_thresholds(img_size, clip_out_of_range, interpolation, padding)
+    n = len(xn)
+    img = torch.zeros(img_size, dtype=torch.float32, device=dev)
+    d_img = torch.zeros((2,) + tuple(img_size), dtype=torch.float32, device=dev) if compute_gradient else None
+    jx = D.to_device(jacobian_xn, torch.float64) if compute_gradient else None
+    jy = D.to_device(jacobian_yn, torch.float64) if compute_gradient else None
+    oob = D.OobCounter(dev)
+    _lib.call("evk_image_drv_f64", D.ptr(D.to_device(xn, torch.float64)), D.ptr(D.to_device(yn, torch.float64)),
+              D.ptr(D.to_device(pn, torch.float64)), D.ptr(jx), D.ptr(jy), n, img_size[0], img_size[1], clipx, clipy,
+              D.ptr(img), D.ptr(d_img), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (img_size,))
+    return img, d_img
+
+
+def events_to_image_drv(xn, yn, pn, jacobian_xn, jacobian_yn, device=None, sensor_size=(180, 240),
+                        clip_out_of_range=True, interpolation='bilinear', padding=True, compute_gradient=False):
+    """
+    Events (+ per-event Jacobians) -> IWE and dIWE (reference: image.py:162-217).  float64 numpy in; float32 numpy
+    out, padded and un-cropped: (H+1, W+1) and (2, H+1, W+1) (or None).  Coordinates are cast to float32 before
+    floor/frac (Q7, :179-183).
+    """
+    img, d_img = _events_to_image_drv_device(xn, yn, pn, jacobian_xn, jacobian_yn, sensor_size, clip_out_of_range,
+                                             interpolation, padding, compute_gradient)
+    return img.cpu().numpy(), (d_img.cpu().numpy() if d_img is not None else None)

@@ -1,0 +1,128 @@
+"""
+Event -> voxel grid on MI355X.  Mirrors the reference's lib/representations/voxel_grid.py (same names, argument
+order, defaults, dtypes); the B per-bin passes of the reference are ONE pass over the events in libevk.so.
+Citations: voxel_grid.py in the reference checkout unless stated.
+"""
+import numpy as np
+import torch
+
+from .. import _device as D
+from .. import _lib
+
+
+def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None):
+    """Device-resident core of events_to_voxel_torch: accumulates into `out` (B, H, W) float32 (allocated if None)."""
+    dev = xd.device
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    if out is None:
+        out = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+    oob = D.OobCounter(dev) if check else None
+    from .. import tiled
+    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl)
+    if check:
+        oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+    return out
+
+
+def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """
+    Events -> (B, H, W) float32 voxel grid with temporal bilinear weights (reference: voxel_grid.py:114-153).
+    t_norm = (ts-ts[0])/(ts[-1]-ts[0])*(B-1) in float32 (:133-134, unguarded: dt == 0 gives NaN, Q9), weights
+    ps*max(0, 1-|t_norm-b|) (:138-139), nearest-pixel accumulate with float coordinates truncated toward zero and
+    out-of-range coordinates raising IndexError (:140-142 -> image.py:87-99, clip_out_of_range=False).
+    Like the reference the float path needs float32 ts / ps (float64 raises RuntimeError).
+    """
+    if device is None:
+        device = xs.device
+    assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
+    if not temporal_bilinear:
+        raise NotImplementedError("temporal_bilinear=False is dead code upstream (undefined names, "
+                                  "voxel_grid.py:144-147)")
+    if ts.dtype == torch.float64 or ps.dtype == torch.float64:
+        raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
+                           "destination and Double for the source.")
+    dev = D.require_gpu()
+    xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
+    td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
+    t_first, t_last = float(td[0].item()), float(td[-1].item())
+    out = _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last)
+    return out.to(device)
+
+
+def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True):
+    """
+    numpy events -> (B, H, W) float64 voxel grid (reference: voxel_grid.py:184-217): float64 t_norm and weights,
+    integer coordinates on the (H+1, W+1) canvas of events_to_image (image.py:17,28-44): non-integer coordinates
+    raise TypeError, coordinates outside the canvas ValueError, x == W / y == H fall in the cropped pad.
+    """
+    assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
+    if not temporal_bilinear:
+        raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:213-214)")
+    xs, ys = np.asarray(xs).squeeze(), np.asarray(ys).squeeze()
+    ts, ps = np.asarray(ts, dtype=np.float64), np.asarray(ps)
+    if not (np.issubdtype(xs.dtype, np.integer) and np.issubdtype(ys.dtype, np.integer)):
+        raise TypeError("only int indices permitted")
+    dev = D.require_gpu()
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    out = torch.zeros((B, H, W), dtype=torch.float64, device=dev)
+    oob = D.OobCounter(dev)
+    _lib.call("evk_voxel_f64", D.ptr(D.to_device(xs, torch.int32)), D.ptr(D.to_device(ys, torch.int32)),
+              D.ptr(D.to_device(ts, torch.float64)), D.ptr(D.to_device(ps.squeeze(), torch.float64)), len(xs),
+              float(ts[0]), float(ts[-1]), B, H, W, D.ptr(out), oob.ptr, D.stream())
+    oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas")
+    return out.cpu().numpy()
+
+
+def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
+    """Separate voxel grids of positive / non-positive events (reference: voxel_grid.py:155-182)."""
+    pos_weights = torch.where(ps > 0, 1.0, 0.0).to(torch.float32)
+    neg_weights = torch.where(ps <= 0, 1.0, 0.0).to(torch.float32)
+    voxel_pos = events_to_voxel_torch(xs, ys, ts, pos_weights, B, device=device, sensor_size=sensor_size,
+                                      temporal_bilinear=temporal_bilinear)
+    voxel_neg = events_to_voxel_torch(xs, ys, ts, neg_weights, B, device=device, sensor_size=sensor_size,
+                                      temporal_bilinear=temporal_bilinear)
+    return voxel_pos, voxel_neg
+
+
+def events_to_neg_pos_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True):
+    """numpy twin (reference: voxel_grid.py:219-243): np.where(ps, 1, 0) / np.where(ps, 0, 1) weights."""
+    pos_weights = np.where(ps, 1, 0)
+    neg_weights = np.where(ps, 0, 1)
+    voxel_pos = events_to_voxel(xs, ys, ts, pos_weights, B, sensor_size=sensor_size, temporal_bilinear=temporal_bilinear)
+    voxel_neg = events_to_voxel(xs, ys, ts, neg_weights, B, sensor_size=sensor_size, temporal_bilinear=temporal_bilinear)
+    return voxel_pos, voxel_neg
+
+
+def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temporal_bilinear=True):
+    """One voxel grid per n consecutive events (reference: voxel_grid.py:37-57)."""
+    voxels = []
+    for idx in range(0, len(xs) - n, n):
+        voxels.append(events_to_voxel_torch(xs[idx:idx + n], ys[idx:idx + n], ts[idx:idx + n], ps[idx:idx + n], B,
+                                            sensor_size=sensor_size, temporal_bilinear=temporal_bilinear))
+    return voxels
+
+
+def events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t0, t1, device=None, np_ts=None, sensor_size=(180, 240),
+                                   temporal_bilinear=True):
+    """Voxel grid of the events with t0 <= t < t1 (reference: voxel_grid.py:82-112)."""
+    assert (t1 > t0)
+    if np_ts is None:
+        np_ts = ts.cpu().numpy()
+    if device is None:
+        device = xs.device
+    start_idx = np.searchsorted(np_ts, t0)
+    end_idx = np.searchsorted(np_ts, t1)
+    assert (start_idx < end_idx)
+    return events_to_voxel_torch(xs[start_idx:end_idx], ys[start_idx:end_idx], ts[start_idx:end_idx],
+                                 ps[start_idx:end_idx], B, device, sensor_size=sensor_size,
+                                 temporal_bilinear=temporal_bilinear)
+
+
+def voxel_grids_fixed_t_torch(xs, ys, ts, ps, B, t, sensor_size=(180, 240), temporal_bilinear=True):
+    """One voxel grid per time window of width t (reference: voxel_grid.py:59-80)."""
+    voxels = []
+    np_ts = ts.cpu().numpy()
+    for t_start in np.arange(ts[0].item(), ts[-1].item() - t, t):
+        voxels.append(events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t_start, t_start + t, np_ts=np_ts,
+                                                     sensor_size=sensor_size, temporal_bilinear=temporal_bilinear))
+    return voxels

@@ -1,0 +1,158 @@
+/*
+ * evk.h -- C ABI of libevk.so: MI355X (gfx950 / CDNA4) kernels for the data-parallel core of
+ * TimoStoff/event_utils (event -> image / voxel scatter-add binning, linear-flow contrast maximisation).
+ *
+ * Boundary rules:
+ *   - plain C: pointers, sizes, scalars.  No torch / C++ types.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Every entry point only ENQUEUES work on `stream` and returns.
+ *   - every pointer is a DEVICE pointer unless the parameter is named host_*.
+ *   - the library never allocates or frees caller-visible memory; outputs are ACCUMULATED INTO (the caller zero-
+ *     or default-initialises them, as the reference does with its `default` image, image.py:77).
+ *   - return value: 0 = ok, <0 = EVK_E* argument error, >0 = hipError_t from the launch.  Never throws / exits.
+ *   - data-dependent errors the reference raises as Python exceptions (index out of range: image.py:30-36,96-99) are
+ *     counted on the device in `oob` (uint32, caller-zeroed, may be NULL = unchecked); offending events are
+ *     dropped; the host wrapper raises the reference's exception type when the counter is non-zero.
+ *
+ * Reference citations are file:line relative to the reference checkout.
+ */
+#ifndef EVK_H
+#define EVK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVK_VERSION 100
+
+#define EVK_OK 0
+#define EVK_EINVAL (-1)   /* bad size / null pointer / unsupported parameter            */
+#define EVK_ESCRATCH (-2) /* caller-provided scratch too small                           */
+#define EVK_EALIGN (-3)   /* pointer not aligned as documented                            */
+
+/* flags for evk_iwe_* */
+#define EVK_IWE_ABS_POLARITY 1u /* get_iwe(use_polarity=False): ps = |ps|  (objectives.py:184-185)   */
+#define EVK_IWE_GRADIENT 2u     /* also accumulate dIWE/dparams (2 planes) (objectives.py:189-192)    */
+
+int evk_version(void);
+const char *evk_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Event image, nearest pixel
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* events_to_image(..., interpolation=None), numpy path: np.ravel_multi_index + np.bincount on the (H+1, W+1)
+ * canvas (image.py:28-38).  canvas[y, x] += w (w == NULL -> 1).  Integer accumulate => bit-exact.
+ * Events outside [0,canvas_w) x [0,canvas_h) are counted in *oob (reference: ValueError, image.py:30-36). */
+int evk_image_nearest_i32(const int32_t *x, const int32_t *y, const int32_t *w, int64_t n, int canvas_h,
+                          int canvas_w, int32_t *canvas, uint32_t *oob, void *stream);
+
+/* Same call site with floating-point weights (np.bincount(weights=ps) accumulates in float64, image.py:37). */
+int evk_image_nearest_f64(const int32_t *x, const int32_t *y, const double *w, int64_t n, int canvas_h,
+                          int canvas_w, double *canvas, uint32_t *oob, void *stream);
+
+/* events_to_image_torch(..., interpolation=None) (image.py:87-99): coordinates truncated toward zero (.long()),
+ * events with x >= clipx or y >= clipy are sent to pixel (0,0) WITH their weight (quirk Q8; pass +inf to disable
+ * clipping = clip_out_of_range=False), negative indices wrap as torch's index_put_ does, anything still outside
+ * the image is counted in *oob (reference: IndexError). img is (h, w) float32. */
+int evk_image_nearest_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                          float clipy, float *img, uint32_t *oob, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Event image, bilinear 4-neighbour splat
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* events_to_image_torch(..., interpolation='bilinear') (image.py:79-86) + interpolate_to_image (image.py:102-115):
+ * px=floor(x), dx=x-px, events with x >= clipx or y >= clipy get index (0,0) and weight 0;
+ * img[py,px]+=w(1-dx)(1-dy), img[py,px+1]+=w dx(1-dy), img[py+1,px]+=w(1-dx)dy, img[py+1,px+1]+=w dx dy (f32). */
+int evk_image_bilinear_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                           float clipy, float *img, uint32_t *oob, void *stream);
+
+/* interpolate_to_image (image.py:102-115) on caller-computed integer pixels px, py (int64, torch .long()) and
+ * fractions dx, dy: the four accumulates into img (h, wd).  Negative indices wrap, out-of-range counts in *oob. */
+int evk_splat_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy, const float *w,
+                          int64_t n, int h, int wd, float *img, uint32_t *oob, void *stream);
+
+/* interpolate_to_derivative_img (image.py:117-136): d_img is (C, h, wd), w1 and w2 are (C, n) row-major float32. */
+int evk_splat_drv_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy,
+                              const float *w1, const float *w2, int C, int64_t n, int h, int wd, float *d_img,
+                              uint32_t *oob, void *stream);
+
+/* events_to_image_drv (image.py:162-217) for arbitrary per-event Jacobians: float64 inputs are cast to float32
+ * BEFORE floor/frac (image.py:179-183), IWE splat as above, and if jx/jy != NULL the derivative splat of
+ * interpolate_to_derivative_img (image.py:117-136) into d_img (2, h, wd) with w1 = jx*p*mask, w2 = jy*p*mask
+ * (image.py:211-212).  jx, jy are (2, n) row-major float64. */
+int evk_image_drv_f64(const double *x, const double *y, const double *p, const double *jx, const double *jy,
+                      int64_t n, int h, int wd, float clipx, float clipy, float *img, float *d_img, uint32_t *oob,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Voxel grid (temporal-bilinear, spatially nearest)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* events_to_voxel_torch (voxel_grid.py:114-153): t_norm = (t - t_first)/(t_last - t_first)*(B-1) in float32,
+ * bin weights p*max(0, 1-|t_norm-b|), one nearest-pixel accumulate per touched bin (image.py:87-95 with
+ * clip_out_of_range=False).  ONE pass over the events (each event touches <= 2 bins) instead of the reference's B.
+ * vox is (B, h, wd) float32.  t_first / t_last are ts[0] / ts[-1] (the caller reads them; they are also what every
+ * rank of an event-sharded run must agree on). */
+int evk_voxel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first,
+                  float t_last, int B, int h, int wd, float *vox, uint32_t *oob, void *stream);
+
+/* events_to_voxel (voxel_grid.py:184-217), numpy path: integer coordinates on the (h+1, wd+1) canvas of
+ * events_to_image (x == wd / y == h are legal and cropped away, image.py:17,44), float64 arithmetic and output. */
+int evk_voxel_f64(const int32_t *x, const int32_t *y, const double *t, const double *p, int64_t n, double t_first,
+                  double t_last, int B, int h, int wd, double *vox, uint32_t *oob, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Contrast maximisation: warp, mask, IWE, blur, objective
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* linvel_warp.warp (warps.py:51-61): dt=t-t0; xo=x-dt*vx; yo=y-dt*vy; if jx/jy != NULL they are (2, n) float64:
+ * jx=[-dt; 0], jy=[0; -dt]. */
+int evk_warp_linvel_f64(const double *x, const double *y, const double *t, int64_t n, double t0, double vx,
+                        double vy, double *xo, double *yo, double *jx, double *jy, void *stream);
+
+/* events_bounds_mask (event_util.py:15-28): mask = !(x<=xmin || x>xmax) * !(y<=ymin || y>ymax) as 0.0/1.0. */
+int evk_bounds_mask_f64(const double *x, const double *y, int64_t n, double xmin, double xmax, double ymin,
+                        double ymax, double *mask, void *stream);
+
+/* get_iwe (objectives.py:165-199) fused for the linear-flow model: warp at t_ref (= ts[-1], :186) in float64 ->
+ * events_bounds_mask(0, bounds_w, 0, bounds_h) (:187) -> multiply by mask (:188-190) -> cast to float32, inner mask
+ * x >= canvas_w-1 / y >= canvas_h-1, floor/frac (image.py:179-205) -> IWE splat (image.py:102-115) and, with
+ * EVK_IWE_GRADIENT, dIWE splat (image.py:117-136; for this model only w1[0] = w2[1] = -dt*p are non-zero).
+ * iwe is (canvas_h, canvas_w) f32, diwe is (2, canvas_h, canvas_w) f32.  Per-event values are bit-identical to the
+ * reference's; only the summation order differs.  p_scale multiplies the polarity in float64 before everything
+ * else (1.0 normally; 100.0 on the adaptive-lifespan path, objectives.py:225).  Columns are float32 (evk_iwe_linvel_f32, 16 B/event) or float64
+ * (evk_iwe_linvel_f64, 32 B/event, exact for arbitrary float64 inputs). */
+int evk_iwe_linvel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, double t_ref,
+                       double vx, double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                       uint32_t flags, double p_scale, float *iwe, float *diwe, void *stream);
+int evk_iwe_linvel_f64(const double *x, const double *y, const double *t, const double *p, int64_t n, double t_ref,
+                       double vx, double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                       uint32_t flags, double p_scale, float *iwe, float *diwe, void *stream);
+
+/* scipy.ndimage.gaussian_filter(a, sigma) (objectives.py:233,253), mode='reflect': separable correlation with the
+ * symmetric kernel host_weights[0..2*radius] (float64, HOST pointer; computed by the caller exactly as scipy does),
+ * filtering axes 0..ndim-1 in order, each pass evaluated in float64 and stored as float32.  ndim is 2 or 3; a 3-D
+ * (2, H, W) input is also filtered across its first axis (quirk Q4).  src is not modified; tmp is a scratch array of
+ * the same size; the result lands in dst.  src, dst, tmp must be distinct. */
+int evk_gaussian_filter_f32(const float *src, float *dst, float *tmp, int ndim, const int *host_dims,
+                            const double *host_weights, int radius, void *stream);
+
+/* variance_objective.evaluate_function (objectives.py:234-236): out[0] = mean(img), out[1] = var(img - mean(img))
+ * (population variance over all n pixels, float64 accumulation), out[2] = sum(img).
+ * scratch: >= evk_reduce_scratch_bytes() bytes. out: 4 doubles on the device. */
+int evk_variance_f32(const float *img, int64_t n, double *out, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* variance_objective.evaluate_gradient (objectives.py:256-264): for i in {0,1}
+ * out[i] = mean( 2*(iwe - mean(iwe)) * diwe[i] ), out[2] = mean(iwe); the caller negates. diwe is (2, n). */
+int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_t n, double *out, void *scratch,
+                          int64_t scratch_bytes, void *stream);
+
+int64_t evk_reduce_scratch_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVK_H */

@@ -1,0 +1,123 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/evk.h declares; host-side logic; the
+product fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "evk.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(evk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from event_utils_amd.csrc import build
+    build.build(verbose=False)
+    from event_utils_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), "libevk.so does not export %s" % n
+    bound = set(_lib.SIGNATURES) | set(_lib._SPECIAL)
+    assert bound == set(names), "ctypes binding and header disagree: %s" % (bound ^ set(names))
+    assert _lib.lib().evk_version() == 100
+    assert _lib.lib().evk_error_string(-1) == b"invalid argument"
+
+
+def test_argument_errors_need_no_gpu():
+    from event_utils_amd import _lib
+    L = _lib.lib()
+    # n < 0 and null output are rejected before anything touches the device
+    assert L.evk_voxel_f32(None, None, None, None, -1, 0.0, 1.0, 5, 4, 4, None, None, None) == -1
+    assert L.evk_image_nearest_i32(None, None, None, 0, 4, 4, None, None, None) == -1
+    assert L.evk_variance_f32(None, 10, None, None, 0, None) == -1
+    with pytest.raises(_lib.EvkError):
+        _lib.check(-2, "x")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_product_fails_loudly_without_gpu():
+    import event_utils_amd as E
+    from event_utils_amd._lib import EvkError
+    x = np.array([1, 2]); p = np.array([1, 1])
+    with pytest.raises(EvkError):
+        E.events_to_image(x, x, p)
+    with pytest.raises(EvkError):
+        E.events_to_voxel_torch(torch.ones(3), torch.ones(3), torch.arange(3.), torch.ones(3), 2)
+    with pytest.raises(EvkError):
+        E.get_iwe((0., 0.), x * 1.0, x * 1.0, x * 1.0, p * 1.0, E.linvel_warp(), (180, 240))
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+    code = "import sys, event_utils_amd, event_utils_amd.lib; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "event_utils_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                s = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in s and "from oracle" not in s, f
+
+
+def test_reference_api_surface():
+    """Names, positional order and defaults of the reference's public functions."""
+    import inspect
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max import events_cmax
+
+    def sig(f):
+        return [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+    E_ = inspect.Parameter.empty
+    assert sig(E.events_to_image) == [("xs", E_), ("ys", E_), ("ps", E_), ("sensor_size", (180, 240)),
+                                      ("interpolation", None), ("padding", False), ("meanval", False), ("default", 0)]
+    assert sig(E.events_to_image_torch) == [("xs", E_), ("ys", E_), ("ps", E_), ("device", None),
+                                            ("sensor_size", (180, 240)), ("clip_out_of_range", True),
+                                            ("interpolation", None), ("padding", True), ("default", 0)]
+    assert sig(E.events_to_voxel) == [("xs", E_), ("ys", E_), ("ts", E_), ("ps", E_), ("B", E_),
+                                      ("sensor_size", (180, 240)), ("temporal_bilinear", True)]
+    assert sig(E.events_to_voxel_torch) == [("xs", E_), ("ys", E_), ("ts", E_), ("ps", E_), ("B", E_), ("device", None),
+                                            ("sensor_size", (180, 240)), ("temporal_bilinear", True)]
+    assert sig(E.get_iwe)[:11] == [("params", E_), ("xs", E_), ("ys", E_), ("ts", E_), ("ps", E_), ("warpfunc", E_),
+                                   ("img_size", E_), ("compute_gradient", False), ("use_polarity", True),
+                                   ("return_events", False), ("return_per_event_contrast", False)]
+    assert sig(E.optimize) == [("xs", E_), ("ys", E_), ("ts", E_), ("ps", E_), ("warp", E_), ("obj", E_),
+                               ("numeric_grads", True), ("img_size", (180, 240))]
+    s = sig(events_cmax.optimize_contrast)
+    assert [n for n, _ in s] == ["xs", "ys", "ts", "ps", "warp_function", "objective", "optimizer", "x0",
+                                 "numeric_grads", "blur_sigma", "img_size", "grid_search_init", "minimum_events"]
+    assert sig(E.linvel_warp.warp)[1:] == [("xs", E_), ("ys", E_), ("ts", E_), ("ps", E_), ("t0", E_), ("params", E_),
+                                           ("compute_grad", False)]
+    w, o = E.linvel_warp(), E.variance_objective()
+    assert (w.name, w.dims) == ("linvel_warp", 2)
+    assert (o.name, o.use_polarity, o.has_derivative, o.default_blur, o.adaptive_lifespan, o.pixel_crossings,
+            o.minimum_events) == ("variance", True, True, 1.0, False, 5, 10000)
+    o.iter_update(np.array([3.0, 4.0]))
+    assert o.lifespan == 1.0 and o.recompute_lifespan
+    o.iter_update(np.array([0, 0]))
+    assert o.lifespan == 5
+
+
+def test_gaussian_kernel_matches_oracle_and_scipy():
+    from event_utils_amd.contrast_max.objectives import gaussian_kernel1d
+    from oracle.reference_np import gaussian_kernel1d as ok
+    for s in (0.5, 1.0, 2.0, 3.3):
+        w, r = gaussian_kernel1d(s)
+        w2, r2 = ok(s)
+        assert r == r2 and np.array_equal(w, w2)
+
+
+def test_f32_lossless_policy():
+    from event_utils_amd.events import _f32_lossless
+    assert _f32_lossless(np.arange(10))
+    assert _f32_lossless(np.array([0.5, 0.25, 3.0]))
+    assert not _f32_lossless(np.array([0.1]))
+    assert _f32_lossless(np.array([0.1], dtype=np.float32))

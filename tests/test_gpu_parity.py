@@ -1,0 +1,402 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI, via the reference-signature Python API) against
+(i) the golden vectors produced by the real reference and (ii) the numpy oracle on seeded inputs.
+Bars: bit-exact for integer event images; float paths |a-b| <= 1e-5 * max|ref| (BASELINE.json north_star) -- float
+atomics sum in arbitrary order, so bit-equality is only demanded where the arithmetic is order-free."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+def close(a, ref, tol=TOL):
+    a, ref = f64(a), f64(ref)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    scale = max(np.max(np.abs(ref)), 1e-30)
+    err = np.max(np.abs(a - ref))
+    assert err <= tol * scale, "max err %.3e vs tol %.3e (scale %.3e)" % (err, tol * scale, scale)
+
+
+@pytest.fixture(scope="module")
+def E():
+    import event_utils_amd as E
+    from event_utils_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return E
+
+
+# ------------------------------------------------------------------------------------------------ F1 / C1
+def test_f1_image_nearest_int_bit_exact(E, golden):
+    g = golden("f1_image_nearest_int")
+    xs, ys, ps = g["xs"].astype(np.int64), g["ys"].astype(np.int64), g["ps"].astype(np.int64)
+    ss = tuple(g["sensor_size"])
+    out = E.events_to_image(xs, ys, ps, sensor_size=ss)
+    assert out.dtype == np.float64 and np.array_equal(out, g["img_pm"])
+    assert np.array_equal(E.events_to_image(xs, ys, np.ones_like(ps), sensor_size=ss), g["img_cnt"])
+    assert np.array_equal(E.events_to_image(xs, ys, ps, sensor_size=ss, meanval=True), g["img_mean"])
+    assert np.array_equal(E.events_to_image(xs, ys, ps, sensor_size=ss, meanval=True, default=7), g["img_mean_default"])
+    close(E.events_to_image(xs, ys, g["wf"], sensor_size=ss), g["img_wf"], 1e-12)
+
+
+def test_image_nearest_errors(E):
+    xs = np.array([0, 241]); ys = np.array([0, 0]); ps = np.array([1, 1])
+    with pytest.raises(ValueError):
+        E.events_to_image(xs, ys, ps)
+    with pytest.raises(ValueError):
+        E.events_to_image(np.array([-1, 3]), ys, ps)
+    with pytest.raises(TypeError):
+        E.events_to_image(xs.astype(float), ys.astype(float), ps)
+
+
+def test_c1_image_1m_events_bit_exact(E):
+    """BASELINE.json configs[0]: 1M events, 240x180, nearest, integer counts."""
+    rng = np.random.default_rng(0)
+    n, H, W = 1_000_000, 180, 240
+    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
+    ps = rng.integers(0, 2, n) * 2 - 1
+    assert np.array_equal(E.events_to_image(xs, ys, ps, sensor_size=(H, W)), R.events_to_image(xs, ys, ps, sensor_size=(H, W)))
+    cnt = E.events_to_image(xs, ys, np.ones_like(ps), sensor_size=(H, W))
+    assert np.array_equal(cnt, R.events_to_image(xs, ys, np.ones_like(ps), sensor_size=(H, W)))
+    assert cnt.sum() == n
+
+
+def test_image_empty_and_ragged(E):
+    e = np.array([], dtype=np.int64)
+    assert np.array_equal(E.events_to_image(e, e, e), np.zeros((180, 240)))
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 5, 63, 64, 65, 1023):
+        xs, ys, ps = rng.integers(0, 240, n), rng.integers(0, 180, n), rng.integers(-3, 4, n)
+        assert np.array_equal(E.events_to_image(xs, ys, ps), R.events_to_image(xs, ys, ps))
+
+
+# ------------------------------------------------------------------------------------------------ F2 / F3 voxel
+@pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
+def test_f2_voxel_numpy(E, golden, tag, Bs):
+    g = golden("f2_voxel_numpy")
+    xs, ys = g[tag + "_xs"].astype(np.int64), g[tag + "_ys"].astype(np.int64)
+    ts, ps = g[tag + "_ts"], f64(g[tag + "_ps"])
+    for B in Bs:
+        v = E.events_to_voxel(xs, ys, ts, ps, B, sensor_size=tuple(g[tag + "_sensor_size"]))
+        assert v.dtype == np.float64
+        close(v, g["%s_voxel_B%d" % (tag, B)], 1e-12)
+
+
+@pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
+def test_f3_voxel_torch(E, golden, tag, Bs):
+    g = golden("f3_voxel_torch")
+    xs, ys, ts = (torch.from_numpy(g[tag + k]) for k in ("_xs", "_ys", "_ts"))
+    ps = torch.from_numpy(g[tag + "_ps"].astype(np.float32))
+    ss = tuple(g[tag + "_sensor_size"])
+    for B in Bs:
+        v = E.events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=ss)
+        assert v.dtype == torch.float32 and v.device.type == "cpu"       # device=None -> xs.device
+        close(v.numpy(), g["%s_voxel_B%d" % (tag, B)])
+        vd = E.events_to_voxel_torch(xs.cuda(), ys.cuda(), ts.cuda(), ps.cuda(), B, sensor_size=ss)
+        assert vd.is_cuda
+        close(vd.cpu().numpy(), g["%s_voxel_B%d" % (tag, B)])
+    if tag == "dvs":
+        v = E.events_to_voxel_torch(xs.long(), ys.long(), ts, ps, 5, sensor_size=ss)
+        close(v.numpy(), g["dvs_voxel_B5_long"])
+
+
+def test_voxel_errors_and_edges(E):
+    x = torch.tensor([1., 2., 300.]); y = torch.tensor([1., 2., 3.]); t = torch.tensor([0., .5, 1.]); p = torch.ones(3)
+    with pytest.raises(IndexError):
+        E.events_to_voxel_torch(x, y, t, p, 3)
+    with pytest.raises(RuntimeError):
+        E.events_to_voxel_torch(y, y, t.double(), p, 3)
+    with pytest.raises(AssertionError):
+        E.events_to_voxel_torch(y, y, t[:2], p, 3)
+    # negative indices wrap like torch's index_put_
+    v = E.events_to_voxel_torch(torch.tensor([-1., 2.]), torch.tensor([-1., 0.]), torch.tensor([0., 1.]), torch.ones(2), 2,
+                                sensor_size=(4, 5))
+    ref = R.events_to_voxel_torch(np.array([-1., 2.], np.float32), np.array([-1., 0.], np.float32),
+                                  np.array([0., 1.], np.float32), np.ones(2, np.float32), 2, sensor_size=(4, 5))
+    assert np.array_equal(v.numpy(), ref)
+    # dt == 0 -> NaN everywhere the events land (Q9)
+    v = E.events_to_voxel_torch(y, y, torch.ones(3), p, 3, sensor_size=(8, 8)).numpy()
+    ref = R.events_to_voxel_torch(y.numpy(), y.numpy(), np.ones(3, np.float32), p.numpy(), 3, sensor_size=(8, 8))
+    assert np.array_equal(np.isnan(v), np.isnan(ref)) and np.isnan(v).sum() == 9
+    with pytest.raises(ValueError):
+        E.events_to_voxel(np.array([1, 500]), np.array([1, 1]), np.array([0., 1.]), np.array([1., 1.]), 2)
+    with pytest.raises(TypeError):
+        E.events_to_voxel(np.array([1., 5.]), np.array([1., 1.]), np.array([0., 1.]), np.array([1., 1.]), 2)
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1001, 200_003])
+def test_voxel_vs_oracle_ragged(E, n):
+    rng = np.random.default_rng(n)
+    H, W, B = 48, 64, 5
+    x = rng.uniform(0, W, n).astype(np.float32); y = rng.uniform(0, H, n).astype(np.float32)
+    x[x >= W] = W - 1; y[y >= H] = H - 1
+    t = np.sort(rng.uniform(0, 1, n)).astype(np.float32) if n > 1 else np.array([0.5], np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    if n == 1:
+        return   # dt == 0: covered above
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    v = E.events_to_voxel_torch(*(torch.from_numpy(a) for a in (x, y, t, p)), B, sensor_size=(H, W)).numpy()
+    close(v, ref)
+    # unaligned views (slices start at odd offsets): the scalar-load kernel variant
+    xs, ys, ts_, ps = (torch.from_numpy(a).cuda()[1:] for a in (x, y, t, p))
+    if n > 2:
+        ref = R.events_to_voxel_torch(x[1:], y[1:], t[1:], p[1:], B, sensor_size=(H, W), accum="f64")
+        close(E.events_to_voxel_torch(xs, ys, ts_, ps, B, sensor_size=(H, W)).cpu().numpy(), ref)
+
+
+def test_c2_voxel_vga_mass_and_oracle(E):
+    """BASELINE.json configs[1] shape (640x480, 5 bins): 2M events vs the oracle, and at the full 10M events the
+    size-independent properties: mass conservation (sum(voxel) == sum(ps)) and shard additivity f(A u B) = f(A)+f(B)."""
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    rng = np.random.default_rng(1)
+    H, W, B, n = 480, 640, 5, 10_000_000
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    m = 2_000_000
+    ref = R.events_to_voxel_torch(x[:m], y[:m], t[:m], p[:m], B, sensor_size=(H, W), accum="f64")
+    xd, yd, td, pd = (torch.from_numpy(a).cuda() for a in (x, y, t, p))
+    close(E.events_to_voxel_torch(xd[:m], yd[:m], td[:m], pd[:m], B, sensor_size=(H, W)).cpu().numpy(), ref)
+    full = E.events_to_voxel_torch(xd, yd, td, pd, B, sensor_size=(H, W))
+    assert abs(full.double().sum().item() - float(p.astype(np.float64).sum())) <= 1e-3 * np.sqrt(n)
+    t0, t1 = float(t[0]), float(t[-1])
+    half = n // 2
+    a = _voxel_f32_device(xd[:half], yd[:half], td[:half], pd[:half], B, (H, W), t0, t1)
+    b = _voxel_f32_device(xd[half:], yd[half:], td[half:], pd[half:], B, (H, W), t0, t1)
+    close((a + b).cpu().numpy(), full.cpu().numpy())
+    # all-positive weights: every bin plane is non-negative and the count is conserved
+    cnt = E.events_to_voxel_torch(xd, yd, td, torch.ones_like(pd), B, sensor_size=(H, W))
+    assert cnt.min().item() >= 0 and abs(cnt.double().sum().item() - n) <= 1e-6 * n
+
+
+# ------------------------------------------------------------------------------------------------ F4 image torch
+def test_f4_image_torch(E, golden):
+    g = golden("f4_image_torch")
+    xs, ys, ps = (torch.from_numpy(g[k]) for k in ("xs", "ys", "ps"))
+    ss = tuple(g["sensor_size"])
+    for key, kw in (("bil_pad", dict(interpolation='bilinear', padding=True)),
+                    ("bil_nopad", dict(interpolation='bilinear', padding=False)),
+                    ("near_pad", dict(interpolation=None, padding=True)),
+                    ("near_nopad", dict(interpolation=None, padding=False)),
+                    ("near_default3", dict(interpolation=None, padding=False, default=3))):
+        out = E.events_to_image_torch(xs, ys, ps, sensor_size=ss, **kw)
+        assert out.dtype == torch.float32
+        close(out.numpy(), g[key])
+    close(E.events_to_image(f64(g["xs"]), f64(g["ys"]), f64(g["ps"]), sensor_size=ss, interpolation='bilinear', padding=False), g["np_bil"])
+    close(E.events_to_image(f64(g["xs"]), f64(g["ys"]), f64(g["ps"]), sensor_size=ss, interpolation='bilinear', padding=True), g["np_bil_pad"])
+    with pytest.raises(IndexError):
+        E.events_to_image_torch(xs, ys, ps, sensor_size=ss, clip_out_of_range=False, padding=False)
+    with pytest.raises(RuntimeError):
+        E.events_to_image_torch(xs, ys, ps.double(), sensor_size=ss)
+
+
+def test_interpolate_primitives(E):
+    rng = np.random.default_rng(7)
+    n, H, W = 5000, 33, 47
+    px = rng.integers(0, W - 1, n); py = rng.integers(0, H - 1, n)
+    dx = rng.random(n).astype(np.float32); dy = rng.random(n).astype(np.float32)
+    w = rng.normal(size=n).astype(np.float32)
+    w1 = rng.normal(size=(2, n)).astype(np.float32); w2 = rng.normal(size=(2, n)).astype(np.float32)
+    ref = R.interpolate_to_image(px, py, dx, dy, w, np.zeros((H, W), np.float32), accum="f64")
+    img = torch.zeros(H, W)
+    out = E.interpolate_to_image(*(torch.from_numpy(a) for a in (px, py, dx, dy, w)), img)
+    assert out is img
+    close(img.numpy(), ref)
+    refd = R.interpolate_to_derivative_img(px, py, dx, dy, np.zeros((2, H, W), np.float32), w1, w2, accum="f64")
+    dimg = torch.zeros(2, H, W, device="cuda")
+    E.interpolate_to_derivative_img(*(torch.from_numpy(a).cuda() for a in (px, py, dx, dy)), dimg,
+                                    torch.from_numpy(w1).cuda(), torch.from_numpy(w2).cuda())
+    close(dimg.cpu().numpy(), refd)
+    with pytest.raises(IndexError):
+        E.interpolate_to_image(torch.tensor([W - 1]), torch.tensor([0]), torch.tensor([.5]), torch.tensor([.5]),
+                               torch.tensor([1.]), torch.zeros(H, W))
+
+
+# ------------------------------------------------------------------------------------------------ F5 warp
+def test_f5_warp_bit_exact(E, golden):
+    g = golden("f5_warp")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w = E.linvel_warp()
+    for i, prm in enumerate(g["params"]):
+        xp, yp, jx, jy = w.warp(x, y, t, p, t[-1], prm, compute_grad=True)
+        for a, k in ((xp, "xp"), (yp, "yp"), (jx, "jx"), (jy, "jy")):
+            assert a.dtype == np.float64 and np.array_equal(a, g["%s%d" % (k, i)])
+        assert np.array_equal(E.events_bounds_mask(xp, yp, 0, 240, 0, 180), g["mask%d" % i])
+    xp, yp, jx, jy = E.warp_events(x, y, t, p, t[-1], g["params"][1])
+    assert jx is None and jy is None and np.array_equal(xp, g["xp1"])
+
+
+# ------------------------------------------------------------------------------------------------ F6 / F7 IWE
+def test_f6_get_iwe_verbatim(E, golden):
+    g = golden("f6_get_iwe")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w = E.linvel_warp()
+    img_size = tuple(g["img_size"])
+    for i, prm in enumerate(g["params"]):
+        iwe, diwe = E.get_iwe(prm, x, y, t, p, w, img_size, compute_gradient=True)
+        assert iwe.shape == (181, 241) and diwe.shape == (2, 181, 241) and iwe.dtype == np.float32
+        close(iwe, g["iwe%d" % i]); close(diwe, g["diwe%d" % i])
+    iwe, d = E.get_iwe(g["params"][0], x, y, t, p, w, img_size, compute_gradient=False, use_polarity=False)
+    assert d is None
+    close(iwe, g["iwe_nopol0"])
+    x, y, t, p = f64(g["q1_xs"]), f64(g["q1_ys"]), f64(g["q1_ts"]), f64(g["q1_ps"])
+    iwe, diwe = E.get_iwe(np.array([30., -20.]), x, y, t, p, w, tuple(g["q1_img_size"]), compute_gradient=True)
+    close(iwe, g["q1_iwe"]); close(diwe, g["q1_diwe"])
+
+
+@pytest.mark.parametrize("tag", ["s48", "vga"])
+def test_f7_iwe_sized_and_generic_plugin_path(E, golden, tag):
+    g = golden("f7_iwe_sized")
+    x, y, t, p = f64(g[tag + "_xs"]), f64(g[tag + "_ys"]), f64(g[tag + "_ts"]), f64(g[tag + "_ps"])
+    ss = tuple(g[tag + "_sensor_size"])
+    iwe, diwe = E.get_iwe(g["params"], x, y, t, p, E.linvel_warp(), ss, compute_gradient=True, sensor_size=ss)
+    close(iwe, g[tag + "_iwe"]); close(diwe, g[tag + "_diwe"])
+
+    class host_warp(E.warp_function):        # a user plugin: numpy in, numpy out -> generic mask + splat kernels
+        def __init__(self):
+            super().__init__("host_linvel", 2)
+
+        def warp(self, xs, ys, ts, ps, t0, params, compute_grad=False):
+            return R.linvel_warp().warp(xs, ys, ts, ps, t0, params, compute_grad)
+    iwe2, diwe2 = E.get_iwe(g["params"], x, y, t, p, host_warp(), ss, compute_gradient=True, sensor_size=ss)
+    close(iwe2, g[tag + "_iwe"]); close(diwe2, g[tag + "_diwe"])
+    # f64 columns (exact for arbitrary float64 input)
+    from event_utils_amd.events import DeviceEvents
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f64")
+    iwe3, diwe3 = E.get_iwe(g["params"], ev, None, None, None, E.linvel_warp(), ss, compute_gradient=True, sensor_size=ss)
+    close(iwe3, g[tag + "_iwe"]); close(diwe3, g[tag + "_diwe"])
+    out = E.get_iwe(g["params"], x, y, t, p, E.linvel_warp(), ss, return_events=True, sensor_size=ss)
+    xw, yw, _, _ = R.linvel_warp().warp(x, y, t, p, t[-1], g["params"])
+    m = R.events_bounds_mask(xw, yw, 0, ss[1], 0, ss[0])
+    assert np.array_equal(out[2][0], xw * m) and np.array_equal(out[2][1], yw * m)
+
+
+def test_c3_iwe_vga_vs_oracle(E):
+    """BASELINE.json configs[2] shape: 640x480 warp + IWE (+dIWE), 1M events vs the oracle's f64 sum."""
+    rng = np.random.default_rng(2)
+    H, W, n = 480, 640, 1_000_000
+    x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    prm = np.array([30., -20.])
+    ref_iwe, ref_d = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), compute_gradient=True,
+                               sensor_size=(H, W), accum="f64")
+    iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W))
+    close(iwe, ref_iwe); close(diwe, ref_d)
+    # large flow: many events leave the sensor
+    prm = np.array([-3000., 2500.])
+    ref_iwe, ref_d = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), compute_gradient=True,
+                               sensor_size=(H, W), accum="f64")
+    iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W))
+    close(iwe, ref_iwe); close(diwe, ref_d)
+
+
+# ------------------------------------------------------------------------------------------------ F10 blur
+def test_f10_blur(E, golden):
+    from event_utils_amd.contrast_max.objectives import gaussian_filter_device
+    g = golden("f10_blur")
+    a3 = torch.from_numpy(g["a3"]).cuda()
+    for s in (1.0, 2.0, 0.5):
+        assert np.array_equal(gaussian_filter_device(a3, s).cpu().numpy(), g["blur3_s%g" % s])
+        assert np.array_equal(gaussian_filter_device(a3[0], s).cpu().numpy(), g["blur2_s%g" % s])
+    assert np.array_equal(gaussian_filter_device(torch.from_numpy(g["small"]).cuda(), 1.0).cpu().numpy(), g["small_blur_s1"])
+
+
+# ------------------------------------------------------------------------------------------------ F8 / F9 objective
+def test_f8_objective(E, golden):
+    g = golden("f8_objective")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    w, obj = E.linvel_warp(), E.variance_objective()
+    img_size = tuple(g["img_size"])
+    from event_utils_amd.events import DeviceEvents
+    ev = DeviceEvents.from_arrays(x, y, t, p)
+    assert ev.dtype == torch.float32            # fixture columns are float32-lossless
+    for i, prm in enumerate(g["params"]):
+        for j, s in enumerate(g["sigmas"]):
+            f = obj.evaluate_function(prm, ev, None, None, None, w, img_size, blur_sigma=s)
+            gr = obj.evaluate_gradient(prm, ev, None, None, None, w, img_size, blur_sigma=s)
+            assert isinstance(f, np.float32) and gr.shape == (2,) and gr.dtype == np.float32
+            assert abs(f - g["f"][i, j]) <= TOL * abs(g["f"][i, j])
+            assert np.max(np.abs(f64(gr) - g["grad"][i, j])) <= TOL * np.max(np.abs(g["grad"][i, j])) + 1e-9
+    # numpy front door, precomputed iwe / d_iwe front door
+    f = obj.evaluate_function(g["params"][1], x, y, t, p, w, img_size, blur_sigma=1.0)
+    assert abs(f - g["f"][1, 1]) <= TOL * abs(g["f"][1, 1])
+    iwe, diwe = E.get_iwe(g["params"][1], x, y, t, p, w, img_size, compute_gradient=True)
+    assert abs(obj.evaluate_function(iwe=iwe, blur_sigma=1.0) - g["f"][1, 1]) <= TOL * abs(g["f"][1, 1])
+    gr = obj.evaluate_gradient(iwe=iwe, d_iwe=diwe, blur_sigma=1.0)
+    assert np.max(np.abs(f64(gr) - g["grad"][1, 1])) <= TOL * np.max(np.abs(g["grad"][1, 1])) + 1e-9
+    # adaptive lifespan (Q10)
+    al = E.variance_objective(adaptive_lifespan=True, minimum_events=5000)
+    al.iter_update(np.array([400., -250.]))
+    f = al.evaluate_function(np.array([40., -25.]), ev, None, None, None, w, img_size, blur_sigma=1.0)
+    assert al.s_idx == g["al_s_idx"] and abs(f - g["al_f"]) <= TOL * abs(g["al_f"])
+    al.iter_update(np.array([400., -250.]))
+    gr = al.evaluate_gradient(np.array([40., -25.]), ev, None, None, None, w, img_size, blur_sigma=1.0)
+    assert np.max(np.abs(f64(gr) - g["al_grad"])) <= TOL * np.max(np.abs(g["al_grad"]))
+
+
+def test_consistent_gradient_mode(E, golden):
+    """reference_exact=False: the analytic gradient equals the finite-difference gradient of evaluate_function."""
+    g = golden("f8_objective")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    from event_utils_amd.events import DeviceEvents
+    ev = DeviceEvents.from_arrays(x, y, t, p)
+    w, obj = E.linvel_warp(), E.variance_objective()
+    obj.reference_exact = False
+    prm = np.array([35., -22.])
+    gr = f64(obj.evaluate_gradient(prm, ev, None, None, None, w, (180, 240), blur_sigma=1.0))
+    h = 0.05
+    fd = np.zeros(2)
+    for k in range(2):
+        e = np.zeros(2); e[k] = h
+        fd[k] = (f64(obj.evaluate_function(prm + e, ev, None, None, None, w, (180, 240), blur_sigma=1.0)) -
+                 f64(obj.evaluate_function(prm - e, ev, None, None, None, w, (180, 240), blur_sigma=1.0))) / (2 * h)
+    assert np.max(np.abs(gr - fd)) <= 0.05 * np.max(np.abs(fd)) + 1e-4
+
+
+@pytest.mark.parametrize("mode", ["numeric", "analytic"])
+def test_f9_optimize(E, golden, mode):
+    g8, g = golden("f8_objective"), golden("f9_optimize_trace")
+    x, y, t, p = f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"])
+    obj = E.variance_objective()
+    trace = []
+    f0, g0 = obj.evaluate_function, obj.evaluate_gradient
+
+    def frec(prm, *a, **k):
+        v = f0(prm, *a, **k)
+        trace.append(("f", np.array(prm, float), float(v), None))
+        return v
+
+    def grec(prm, *a, **k):
+        v = g0(prm, *a, **k)
+        trace.append(("g", np.array(prm, float), None, f64(v)))
+        return v
+    obj.evaluate_function, obj.evaluate_gradient = frec, grec
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        argmax = E.optimize(x, y, t, p, E.linvel_warp(), obj, numeric_grads=(mode == "numeric"), img_size=tuple(g8["img_size"]))
+    # first evaluations are pinned tightly (same params in, same values out); the rest of the BFGS trajectory
+    # amplifies 1e-7-level summation-order noise, so the end point is compared loosely
+    k = 0
+    for kind, prm, fv, gv in trace[:4]:
+        assert kind == str(g[mode + "_kind"][k]) and np.allclose(prm, g[mode + "_params"][k], atol=1e-6)
+        if kind == "f":
+            assert abs(fv - g[mode + "_f"][k]) <= TOL * abs(g[mode + "_f"][k])
+        else:
+            assert np.max(np.abs(gv - g[mode + "_g"][k])) <= TOL * np.max(np.abs(g[mode + "_g"][k])) + 1e-9
+        k += 1
+    if mode == "analytic":
+        assert np.linalg.norm(np.asarray(argmax, float) - g[mode + "_argmax"]) < 1.5
+        assert np.linalg.norm(np.asarray(argmax, float) - np.array([40., -25.])) < 2.0
+    fa = f64(f0(np.asarray(argmax, float), x, y, t, p, E.linvel_warp(), tuple(g8["img_size"]), 1.0))
+    fr = f64(f0(g[mode + "_argmax"], x, y, t, p, E.linvel_warp(), tuple(g8["img_size"]), 1.0))
+    assert fa <= fr + 0.02 * abs(fr)        # at least as good an optimum as the reference found
