@@ -32,11 +32,18 @@ SIGNATURES = {
     "evk_gaussian_filter_f32": [P, P, P, c_int, P, P, c_int, P],
     "evk_variance_f32": [P, c_int64, P, P, c_int64, P],
     "evk_variance_grad_f32": [P, P, c_int64, P, P, c_int64, P],
+    "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
+    "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P],
+    "evk_voxel_tiled_f32": [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P, P],
+    "evk_iwe_linvel_tiled_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
+                                 c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, P, c_int64, P, P, P],
 }
 _SPECIAL = {
     "evk_version": ([], c_int),
     "evk_error_string": ([c_int], c_char_p),
     "evk_reduce_scratch_bytes": ([], c_int64),
+    "evk_bucket_scratch_bytes": ([c_int], c_int64),
+    "evk_iwe_tiled_staging_bytes": ([c_int, c_int, c_int, c_int, c_int], c_int64),
 }
 
 

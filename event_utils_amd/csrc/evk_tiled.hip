@@ -1,0 +1,509 @@
+// Tile-bucketed event kernels (the MI355X design): global float atomics top out at ~21 G/s on this chip (memory-side
+// atomics, measured: tools/probe.py), i.e. 2-12 atomics per 16-byte event cap the direct kernels at 1-10 Gev/s while
+// the HBM stream alone sustains ~300 Gev/s.  So:
+//   1. events are bucketed ONCE by output tile (counting sort: per-block tile histogram -> scan -> scatter into
+//      16-byte (x, y, t, p) records, contiguous per tile);
+//   2. one workgroup per tile streams its records with 16 B/lane coalesced loads and accumulates in an LDS tile
+//      (ds_add_f32, ~TB/s-class);
+//   3. the tile is flushed with plain, coalesced stores: voxel tiles are owned exclusively; IWE windows (tile + halo,
+//      shifted by the flow) go to a staging area and a gather kernel sums the (<= a few) windows covering each pixel.
+// No global atomics remain on the hot path (only the rare event that lands outside its block's window uses one).
+#include "evk_common.h"
+
+namespace evk {
+
+struct TileGrid {
+    int tw_log2, th_log2;  // tile size (pixels), powers of two
+    int tiles_x, tiles_y;  // tiles covering the key domain
+    int dom_w, dom_h;      // key domain in pixels
+};
+
+#define EVK_KEY_NEAREST 0  // voxel / nearest image: trunc toward zero, negative wrap, out-of-domain -> dropped + counted
+#define EVK_KEY_FLOOR_CLAMP 1  // IWE: floor, clamped into the domain (the tile only seeds the window; any event is legal)
+
+__device__ __forceinline__ int tile_key(float x, float y, const TileGrid &g, int mode) {
+    int xi, yi;
+    if (mode == EVK_KEY_NEAREST) {
+        long long xl = (long long)x, yl = (long long)y;
+        if (xl < 0) xl += g.dom_w;
+        if (yl < 0) yl += g.dom_h;
+        if (xl < 0 || xl >= g.dom_w || yl < 0 || yl >= g.dom_h) return -1;
+        xi = (int)xl;
+        yi = (int)yl;
+    } else {
+        const float fx = floorf(x), fy = floorf(y);
+        xi = fx > 0.0f ? (fx < (float)(g.dom_w - 1) ? (int)fx : g.dom_w - 1) : 0;  // NaN -> 0
+        yi = fy > 0.0f ? (fy < (float)(g.dom_h - 1) ? (int)fy : g.dom_h - 1) : 0;
+    }
+    return (yi >> g.th_log2) * g.tiles_x + (xi >> g.tw_log2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bucketing: histogram -> scan -> scatter
+// ---------------------------------------------------------------------------------------------------------
+#define EVK_BUCKET_THREADS 1024
+#define EVK_BUCKET_BLOCKS 256  // one 1024-thread workgroup per CU; table is [tile][EVK_BUCKET_BLOCKS]
+
+// Block b owns the contiguous event range [b*chunk, (b+1)*chunk) (chunk % 4 == 0); table[b][tile] = its count.
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *__restrict__ x,
+                                                                  const float *__restrict__ y, int64_t n,
+                                                                  int64_t chunk, TileGrid g, int mode, int ntiles,
+                                                                  uint32_t *__restrict__ table, uint32_t *oob) {
+    extern __shared__ uint32_t hist[];
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    uint32_t dropped = 0;
+    const int64_t nq = (hi > lo) ? ((hi - lo) >> 2) : 0;
+    for (int64_t q = threadIdx.x; q < nq; q += blockDim.x) {
+        const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int key = tile_key(xv.v[k], yv.v[k], g, mode);
+            if (key >= 0)
+                atomicAdd(&hist[key], 1u);
+            else
+                ++dropped;
+        }
+    }
+    for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {  // ragged tail of the last block
+        const int key = tile_key(x[i], y[i], g, mode);
+        if (key >= 0)
+            atomicAdd(&hist[key], 1u);
+        else
+            ++dropped;
+    }
+    if (dropped && oob) atomicAdd(oob, dropped);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x] = hist[i];
+}
+
+// Per tile: exclusive prefix of table[tile][.] over the EVK_BUCKET_BLOCKS blocks (in place) and the tile total.
+// One wavefront per tile: lane l owns blocks 4l..4l+3 (one 16-byte load), wave-wide scan by shuffles.
+__global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__ table, int ntiles,
+                                                          uint32_t *__restrict__ totals) {
+    static_assert(EVK_BUCKET_BLOCKS == 256, "lane l owns 4 blocks");
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    uint4 *row = reinterpret_cast<uint4 *>(table + (int64_t)tile * EVK_BUCKET_BLOCKS);
+    const uint4 c = row[lane];
+    const uint32_t sum = c.x + c.y + c.z + c.w;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t base = incl - sum;
+    row[lane] = make_uint4(base, base + c.x, base + c.x + c.y, base + c.x + c.y + c.z);
+    if (lane == 63) totals[tile] = incl;
+}
+
+// bucket_start[0..ntiles] = exclusive scan of totals (single block).
+__global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__restrict__ totals, int ntiles,
+                                                           uint32_t *__restrict__ bucket_start) {
+    __shared__ uint32_t part[1024];
+    const int per = (ntiles + 1023) / 1024;
+    const int i0 = threadIdx.x * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
+    uint32_t s = 0;
+    for (int i = i0; i < i1; ++i) s += totals[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (int i = i0; i < i1; ++i) {
+        bucket_start[i] = run;
+        run += totals[i];
+    }
+    if (threadIdx.x == 1023) bucket_start[ntiles] = part[1023];
+}
+
+// Scatter: LDS cursors start at bucket_start[tile] + (this block's exclusive prefix); an LDS returning atomic hands
+// every event its final slot; the 16-byte record is written there.  Events keep their time order across blocks and
+// (up to the interleaving of one block's waves) within a block.
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float *__restrict__ x,
+                                                                     const float *__restrict__ y,
+                                                                     const float *__restrict__ t,
+                                                                     const float *__restrict__ p, int64_t n,
+                                                                     int64_t chunk, TileGrid g, int mode, int ntiles,
+                                                                     const uint32_t *__restrict__ table,
+                                                                     const uint32_t *__restrict__ bucket_start,
+                                                                     float4 *__restrict__ rec) {
+    extern __shared__ uint32_t cursor[];
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x)
+        cursor[i] = bucket_start[i] + table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x];
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    const int64_t nq = (hi > lo) ? ((hi - lo) >> 2) : 0;
+    for (int64_t q = threadIdx.x; q < nq; q += blockDim.x) {
+        const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q), tv = load4(t + lo, q), pv = load4(p + lo, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int key = tile_key(xv.v[k], yv.v[k], g, mode);
+            if (key >= 0) {
+                const uint32_t pos = atomicAdd(&cursor[key], 1u);
+                rec[pos] = make_float4(xv.v[k], yv.v[k], tv.v[k], pv.v[k]);
+            }
+        }
+    }
+    for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {
+        const int key = tile_key(x[i], y[i], g, mode);
+        if (key >= 0) {
+            const uint32_t pos = atomicAdd(&cursor[key], 1u);
+            rec[pos] = make_float4(x[i], y[i], t[i], p[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// voxel grid: one workgroup per tile, LDS accumulators (B x th x tw), exclusive plain-store flush
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_add(float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void voxel_bins_lds(float *acc, int tpix, int local, int B, float tn, float p) {
+    if (tn != tn) {  // dt == 0 (Q9): NaN in every bin of the pixel
+        for (int b = 0; b < B; ++b) lds_add(acc + b * tpix + local, tn * p);
+        return;
+    }
+    const float fl = floorf(tn);
+    const int b0 = (int)fmaxf(fminf(fl, (float)(B + 1)), -2.0f);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = b0 + k;
+        if (b < 0 || b >= B) continue;
+        const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - (float)b));
+        if (val != 0.0f) lds_add(acc + b * tpix + local, val);
+    }
+}
+
+__global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec,
+                                                           const uint32_t *__restrict__ bucket_start, TileGrid g,
+                                                           float t_first, float dt, float bm1, int B,
+                                                           float *__restrict__ vox) {
+    extern __shared__ float acc[];
+    const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
+    const int tile = blockIdx.x;
+    const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+    for (int i = threadIdx.x; i < B * tpix; i += EVK_BLOCK) acc[i] = 0.0f;
+    __syncthreads();
+    const uint32_t lo = bucket_start[tile], hi = bucket_start[tile + 1];
+    auto one = [&](const float4 &r) {
+        long long xl = (long long)r.x, yl = (long long)r.y;
+        if (xl < 0) xl += g.dom_w;
+        if (yl < 0) yl += g.dom_h;
+        const int local = (((int)yl - ty0) << g.tw_log2) + ((int)xl - tx0);
+        const float tn = (r.z - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+        voxel_bins_lds(acc, tpix, local, B, tn, r.w);
+    };
+    uint32_t i = lo + threadIdx.x;
+    for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {  // 4 independent 16-byte loads in flight per lane
+        const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
+        one(r0), one(r1), one(r2), one(r3);
+    }
+    for (; i < hi; i += EVK_BLOCK) one(rec[i]);
+    __syncthreads();
+    const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    for (int c = threadIdx.x; c < B * tpix; c += EVK_BLOCK) {
+        const int b = c / tpix, l = c - b * tpix;
+        const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
+        if (X < g.dom_w && Y < g.dom_h) {
+            float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
+            *o += acc[c];  // the tile is owned by this workgroup: plain read-modify-write, coalesced per row
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused linear-flow IWE: one workgroup per (tile, time slice); LDS window = tile + flow halo
+// ---------------------------------------------------------------------------------------------------------
+struct IweParams {
+    double t_ref, vx, vy, bw, bh, p_scale;
+    float clipx, clipy;
+    int ch, cw;        // canvas
+    int slices;        // time slices per tile (runtime, from the flow magnitude)
+    int win_w, win_h;  // LDS / staging window capacity (cells)
+    int abs_p, grad;
+    int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
+};
+
+// Same per-event arithmetic as evk_scatter.hip's iwe_event (kept textually identical: parity depends on it).
+__device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &q, int &px, int &py, float &dx,
+                                              float &dy, float &mp, float &jf) {
+    const double dt = (double)r.z - q.t_ref;
+    const double xw = (double)r.x - dt * q.vx;
+    const double yw = (double)r.y - dt * q.vy;
+    if (xw <= 0.0 || xw > q.bw || yw <= 0.0 || yw > q.bh) return false;
+    const double ps = (double)r.w * q.p_scale;
+    const double pd = q.abs_p ? fabs(ps) : ps;
+    const float xf = (float)xw, yf = (float)yw;
+    if (xf >= q.clipx || yf >= q.clipy) return false;
+    const float fx = floorf(xf), fy = floorf(yf);
+    dx = xf - fx;
+    dy = yf - fy;
+    px = (int)fx;
+    py = (int)fy;
+    mp = (float)pd;
+    jf = (float)(-dt);
+    return true;
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
+                                                         const uint32_t *__restrict__ bucket_start, TileGrid g,
+                                                         IweParams q, float *__restrict__ staging,
+                                                         int4 *__restrict__ origins, float *__restrict__ iwe,
+                                                         float *__restrict__ diwe) {
+    extern __shared__ float win[];
+    const int wcells = q.win_w * q.win_h;
+    constexpr int PLANES = GRAD ? 3 : 1;
+    const int tile = blockIdx.x / q.slices, s = blockIdx.x - tile * q.slices;
+    const uint32_t blo = bucket_start[tile], bhi = bucket_start[tile + 1];
+    const uint32_t cnt = bhi - blo;
+    const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * s) / q.slices);
+    const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (s + 1)) / q.slices);
+    for (int i = threadIdx.x; i < PLANES * wcells; i += EVK_BLOCK) win[i] = 0.0f;
+    // Window origin from the time span of this slice (records are time-ordered up to intra-block interleaving; an
+    // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
+    int wx0 = 0, wy0 = 0;
+    if (hi > lo) {
+        const double ta = (double)rec[lo].z - q.t_ref, tb = (double)rec[hi - 1].z - q.t_ref;
+        const double dxa = -ta * q.vx, dxb = -tb * q.vx, dya = -ta * q.vy, dyb = -tb * q.vy;
+        const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+        int sx = (int)floor(fmin(dxa, dxb)) - 1, sy = (int)floor(fmin(dya, dyb)) - 1;
+        sx = sx < q.sx_lo ? q.sx_lo : (sx > q.sx_hi ? q.sx_hi : sx);  // the gather kernel relies on these bounds
+        sy = sy < q.sy_lo ? q.sy_lo : (sy > q.sy_hi ? q.sy_hi : sy);
+        wx0 = tx0 + sx;
+        wy0 = ty0 + sy;
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)q.ch * q.cw;
+    auto one = [&](const float4 &r) {
+        int px, py;
+        float dx, dy, mp, jf;
+        if (!iwe_event_f32(r, q, px, py, dx, dy, mp, jf)) return;
+        const float ax = 1.0f - dx, ay = 1.0f - dy;
+        const int lx = px - wx0, ly = py - wy0;
+        const float a = jf * mp;
+        if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
+            float *c = win + ly * q.win_w + lx;
+            lds_add(c, mp * ax * ay);
+            lds_add(c + 1, mp * dx * ay);
+            lds_add(c + q.win_w, mp * ax * dy);
+            lds_add(c + q.win_w + 1, mp * dx * dy);
+            if constexpr (GRAD) {
+                float *d0 = c + wcells, *d1 = d0 + wcells;
+                lds_add(d0, a * (-ay));
+                lds_add(d0 + 1, a * ay);
+                lds_add(d0 + q.win_w, a * (-dy));
+                lds_add(d0 + q.win_w + 1, a * dy);
+                lds_add(d1, a * (-ax));
+                lds_add(d1 + 1, a * (-dx));
+                lds_add(d1 + q.win_w, a * ax);
+                lds_add(d1 + q.win_w + 1, a * dx);
+            }
+        } else {  // outside the window (flow larger than the halo, clamped outlier): straight to the image
+            float *c = iwe + (int64_t)py * q.cw + px;
+            atomic_add(c, mp * ax * ay);
+            atomic_add(c + 1, mp * dx * ay);
+            atomic_add(c + q.cw, mp * ax * dy);
+            atomic_add(c + q.cw + 1, mp * dx * dy);
+            if constexpr (GRAD) {
+                float *d0 = diwe + (int64_t)py * q.cw + px, *d1 = d0 + plane;
+                atomic_add(d0, a * (-ay));
+                atomic_add(d0 + 1, a * ay);
+                atomic_add(d0 + q.cw, a * (-dy));
+                atomic_add(d0 + q.cw + 1, a * dy);
+                atomic_add(d1, a * (-ax));
+                atomic_add(d1 + 1, a * (-dx));
+                atomic_add(d1 + q.cw, a * ax);
+                atomic_add(d1 + q.cw + 1, a * dx);
+            }
+        }
+    };
+    uint32_t i = lo + threadIdx.x;
+    for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {
+        const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
+        one(r0), one(r1), one(r2), one(r3);
+    }
+    for (; i < hi; i += EVK_BLOCK) one(rec[i]);
+    __syncthreads();
+    float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
+    for (int c = threadIdx.x; c < PLANES * wcells; c += EVK_BLOCK) st[c] = win[c];
+    if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
+}
+
+// Gather: every canvas pixel sums the staged windows that cover it (candidates: tiles whose window, shifted by at
+// most max_shift, can reach the pixel) and ADDS the sum to the image (which already holds the rare direct atomics).
+template <bool GRAD>
+__global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restrict__ staging,
+                                                          const int4 *__restrict__ origins, TileGrid g, int slices,
+                                                          int win_w, int win_h, int ch, int cw, int sx_lo, int sx_hi,
+                                                          int sy_lo, int sy_hi, float *__restrict__ iwe,
+                                                          float *__restrict__ diwe) {
+    constexpr int PLANES = GRAD ? 3 : 1;
+    const int wcells = win_w * win_h;
+    const int64_t plane = (int64_t)ch * cw;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < plane;
+         pix += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(pix % cw), Y = (int)(pix / cw);
+        // a window starts at tile_origin + shift, shift in [s_lo, s_hi] (clamped by k_iwe_tiled): tile tx can cover X
+        // iff tx*tw + s_lo <= X < tx*tw + s_hi + win_w
+        const int tx_a = (X - sx_hi - win_w + 1) >> g.tw_log2, tx_b = (X - sx_lo) >> g.tw_log2;
+        const int ty_a = (Y - sy_hi - win_h + 1) >> g.th_log2, ty_b = (Y - sy_lo) >> g.th_log2;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        for (int ty = ty_a; ty <= ty_b; ++ty) {
+            if (ty < 0 || ty >= g.tiles_y) continue;
+            for (int tx = tx_a; tx <= tx_b; ++tx) {
+                if (tx < 0 || tx >= g.tiles_x) continue;
+                const int tile = ty * g.tiles_x + tx;
+                for (int s = 0; s < slices; ++s) {
+                    const int w = tile * slices + s;
+                    const int4 o = origins[w];
+                    if (!o.z) continue;
+                    const int lx = X - o.x, ly = Y - o.y;
+                    if (lx < 0 || ly < 0 || lx >= win_w || ly >= win_h) continue;
+                    const float *st = staging + (int64_t)w * PLANES * wcells + ly * win_w + lx;
+                    s0 += st[0];
+                    if constexpr (GRAD) {
+                        s1 += st[wcells];
+                        s2 += st[2 * wcells];
+                    }
+                }
+            }
+        }
+        iwe[pix] += s0;
+        if constexpr (GRAD) {
+            diwe[pix] += s1;
+            diwe[plane + pix] += s2;
+        }
+    }
+}
+
+static inline int make_grid(TileGrid &g, int dom_h, int dom_w, int tw_log2, int th_log2) {
+    if (dom_h <= 0 || dom_w <= 0 || tw_log2 < 2 || tw_log2 > 8 || th_log2 < 2 || th_log2 > 8) return EVK_EINVAL;
+    g.tw_log2 = tw_log2;
+    g.th_log2 = th_log2;
+    g.dom_w = dom_w;
+    g.dom_h = dom_h;
+    g.tiles_x = (dom_w + (1 << tw_log2) - 1) >> tw_log2;
+    g.tiles_y = (dom_h + (1 << th_log2) - 1) >> th_log2;
+    return EVK_OK;
+}
+
+#define EVK_MAX_TILES 8192
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_log2) {
+    TileGrid g;
+    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK) return EVK_EINVAL;
+    const int nt = g.tiles_x * g.tiles_y;
+    return nt <= EVK_MAX_TILES ? nt : EVK_EINVAL;
+}
+
+extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
+    if (ntiles <= 0) return 0;
+    return ((int64_t)EVK_BUCKET_BLOCKS * ntiles + ntiles) * (int64_t)sizeof(uint32_t);
+}
+
+extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n,
+                                     int key_mode, int dom_h, int dom_w, int tw_log2, int th_log2, float *records,
+                                     uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                     void *stream) {
+    TileGrid g;
+    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK) return EVK_EINVAL;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    if (ntiles > EVK_MAX_TILES || n < 0 || n >= (int64_t)1 << 32 || (key_mode != 0 && key_mode != 1)) return EVK_EINVAL;
+    if (!bucket_start || !scratch || (n > 0 && (!x || !y || !t || !p || !records))) return EVK_EINVAL;
+    if (scratch_bytes < evk_bucket_scratch_bytes(ntiles)) return EVK_ESCRATCH;
+    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p) && aligned16(records))) return EVK_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *table = (uint32_t *)scratch;
+    uint32_t *totals = table + (int64_t)EVK_BUCKET_BLOCKS * ntiles;
+    int64_t chunk = (n + EVK_BUCKET_BLOCKS - 1) / EVK_BUCKET_BLOCKS;
+    chunk = (chunk + 3) & ~(int64_t)3;
+    if (chunk == 0) chunk = 4;
+    const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+    k_tile_hist<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, n, chunk, g, key_mode, ntiles, table, oob);
+    k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
+    k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, bucket_start);
+    k_tile_scatter<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, t, p, n, chunk, g, key_mode, ntiles, table,
+                                                                   bucket_start, (float4 *)records);
+    return launch_status();
+}
+
+extern "C" int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_start, int h, int wd, int tw_log2,
+                                   int th_log2, float t_first, float t_last, int B, float *vox, void *stream) {
+    TileGrid g;
+    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_start || !vox)
+        return EVK_EINVAL;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const size_t lds = (size_t)B * sizeof(float) << (tw_log2 + th_log2);
+    if (lds > 64 * 1024) return EVK_EINVAL;
+    const float dt = t_last - t_first, bm1 = (float)(B - 1);
+    k_voxel_tiled<<<ntiles, EVK_BLOCK, lds, (hipStream_t)stream>>>((const float4 *)records, bucket_start, g, t_first, dt,
+                                                                 bm1, B, vox);
+    return launch_status();
+}
+
+extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int slices, int planes, int win_w, int win_h) {
+    return (int64_t)ntiles * slices * ((int64_t)planes * win_w * win_h * sizeof(float) + sizeof(int4));
+}
+
+extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w,
+                                        int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
+                                        double t_ref, double vx, double vy, double bounds_w, double bounds_h, int canvas_h,
+                                        int canvas_w, uint32_t flags, double p_scale, void *staging,
+                                        int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
+    TileGrid g;
+    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_start || !iwe || !staging)
+        return EVK_EINVAL;
+    const bool grad = flags & EVK_IWE_GRADIENT;
+    if ((grad && !diwe) || slices < 1 || slices > 256 || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
+    const int tw = 1 << tw_log2, th = 1 << th_log2;
+    if (win_w < tw + 3 || win_h < th + 3) return EVK_EINVAL;
+    const int planes = grad ? 3 : 1;
+    const size_t lds = (size_t)planes * win_w * win_h * sizeof(float);
+    if (lds > 64 * 1024) return EVK_EINVAL;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    if (staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, slices, planes, win_w, win_h)) return EVK_ESCRATCH;
+    IweParams q;
+    q.t_ref = t_ref, q.vx = vx, q.vy = vy, q.bw = bounds_w, q.bh = bounds_h, q.p_scale = p_scale;
+    q.clipx = (float)(canvas_w - 1), q.clipy = (float)(canvas_h - 1);
+    q.ch = canvas_h, q.cw = canvas_w, q.slices = slices, q.win_w = win_w, q.win_h = win_h;
+    q.abs_p = (flags & EVK_IWE_ABS_POLARITY) ? 1 : 0, q.grad = grad;
+    // displacement of an event at time t is -(t - t_ref) * v; over [t_first, t_ref] it spans [min(0, D), max(0, D)]
+    const double Dx = -(t_first - t_ref) * vx, Dy = -(t_first - t_ref) * vy;
+    if (!(fabs(Dx) < 1e6 && fabs(Dy) < 1e6)) return EVK_EINVAL;
+    q.sx_lo = (int)floor(fmin(0.0, Dx)) - 1, q.sx_hi = (int)floor(fmax(0.0, Dx)) - 1;
+    q.sy_lo = (int)floor(fmin(0.0, Dy)) - 1, q.sy_hi = (int)floor(fmax(0.0, Dy)) - 1;
+    const int nwin = ntiles * slices;
+    int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
+    float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
+    hipStream_t s = (hipStream_t)stream;
+    const int ggrid = stream_grid((int64_t)canvas_h * canvas_w);
+    if (grad) {
+        k_iwe_tiled<true><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
+        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
+                                                       q.sy_lo, q.sy_hi, iwe, diwe);
+    } else {
+        k_iwe_tiled<false><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
+        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
+                                                       q.sy_lo, q.sy_hi, iwe, diwe);
+    }
+    return launch_status();
+}

@@ -54,11 +54,13 @@ def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padd
         int_w = np.issubdtype(ps.dtype, np.integer) or ps.dtype == np.bool_
         if int_w and (n == 0 or float(np.abs(ps.astype(np.int64)).max()) * n < 2 ** 31):
             canvas = torch.zeros(img_size, dtype=torch.int32, device=dev)
-            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(D.to_device(ps, torch.int32)), n,
+            wd_ = D.to_device(ps, torch.int32)      # keep every device temporary alive until the launch
+            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
                       img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
         else:
             canvas = torch.zeros(img_size, dtype=torch.float64, device=dev)
-            _lib.call("evk_image_nearest_f64", D.ptr(xd), D.ptr(yd), D.ptr(D.to_device(ps, torch.float64)), n,
+            wd_ = D.to_device(ps, torch.float64)
+            _lib.call("evk_image_nearest_f64", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
                       img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
         if meanval:
             cnt = torch.zeros(img_size, dtype=torch.int32, device=dev)
@@ -116,9 +118,9 @@ def interpolate_to_image(pxs, pys, dxs, dys, weights, img):
     work = img if img.is_cuda else img.to(dev)
     work = work if work.is_contiguous() else work.contiguous()
     oob = D.OobCounter(dev)
-    _lib.call("evk_splat_indexed_f32", D.ptr(D.to_device(pxs, torch.int64)), D.ptr(D.to_device(pys, torch.int64)),
-              D.ptr(D.to_device(dxs, torch.float32)), D.ptr(D.to_device(dys, torch.float32)),
-              D.ptr(D.to_device(weights, torch.float32)), pxs.shape[0], work.shape[0], work.shape[1], D.ptr(work),
+    a = [D.to_device(pxs, torch.int64), D.to_device(pys, torch.int64), D.to_device(dxs, torch.float32),
+         D.to_device(dys, torch.float32), D.to_device(weights, torch.float32)]
+    _lib.call("evk_splat_indexed_f32", D.ptr(a[0]), D.ptr(a[1]), D.ptr(a[2]), D.ptr(a[3]), D.ptr(a[4]), pxs.shape[0], work.shape[0], work.shape[1], D.ptr(work),
               oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img.shape),))
     if work is not img:
@@ -132,9 +134,10 @@ def interpolate_to_derivative_img(pxs, pys, dxs, dys, d_img, w1, w2):
     work = d_img if d_img.is_cuda else d_img.to(dev)
     work = work if work.is_contiguous() else work.contiguous()
     oob = D.OobCounter(dev)
-    _lib.call("evk_splat_drv_indexed_f32", D.ptr(D.to_device(pxs, torch.int64)), D.ptr(D.to_device(pys, torch.int64)),
-              D.ptr(D.to_device(dxs, torch.float32)), D.ptr(D.to_device(dys, torch.float32)),
-              D.ptr(D.to_device(w1, torch.float32)), D.ptr(D.to_device(w2, torch.float32)), work.shape[0],
+    a = [D.to_device(pxs, torch.int64), D.to_device(pys, torch.int64), D.to_device(dxs, torch.float32),
+         D.to_device(dys, torch.float32), D.to_device(w1, torch.float32), D.to_device(w2, torch.float32)]
+    _lib.call("evk_splat_drv_indexed_f32", D.ptr(a[0]), D.ptr(a[1]), D.ptr(a[2]), D.ptr(a[3]), D.ptr(a[4]), D.ptr(a[5]),
+              work.shape[0],
               pxs.shape[0], work.shape[1], work.shape[2], D.ptr(work), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(d_img.shape),))
     if work is not d_img:
@@ -153,8 +156,8 @@ def _events_to_image_drv_device(xn, yn, pn, jacobian_xn, jacobian_yn, sensor_siz
     jx = D.to_device(jacobian_xn, torch.float64) if compute_gradient else None
     jy = D.to_device(jacobian_yn, torch.float64) if compute_gradient else None
     oob = D.OobCounter(dev)
-    _lib.call("evk_image_drv_f64", D.ptr(D.to_device(xn, torch.float64)), D.ptr(D.to_device(yn, torch.float64)),
-              D.ptr(D.to_device(pn, torch.float64)), D.ptr(jx), D.ptr(jy), n, img_size[0], img_size[1], clipx, clipy,
+    xd, yd, pd = D.to_device(xn, torch.float64), D.to_device(yn, torch.float64), D.to_device(pn, torch.float64)
+    _lib.call("evk_image_drv_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), D.ptr(jx), D.ptr(jy), n, img_size[0], img_size[1], clipx, clipy,
               D.ptr(img), D.ptr(d_img), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (img_size,))
     return img, d_img

@@ -66,8 +66,9 @@ def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear
     H, W = int(sensor_size[0]), int(sensor_size[1])
     out = torch.zeros((B, H, W), dtype=torch.float64, device=dev)
     oob = D.OobCounter(dev)
-    _lib.call("evk_voxel_f64", D.ptr(D.to_device(xs, torch.int32)), D.ptr(D.to_device(ys, torch.int32)),
-              D.ptr(D.to_device(ts, torch.float64)), D.ptr(D.to_device(ps.squeeze(), torch.float64)), len(xs),
+    xd, yd = D.to_device(xs, torch.int32), D.to_device(ys, torch.int32)
+    td, pd = D.to_device(ts, torch.float64), D.to_device(ps.squeeze(), torch.float64)
+    _lib.call("evk_voxel_f64", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), len(xs),
               float(ts[0]), float(ts[-1]), B, H, W, D.ptr(out), oob.ptr, D.stream())
     oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas")
     return out.cpu().numpy()

@@ -12,17 +12,122 @@ def default_impl():
     return os.environ.get("EVK_IMPL", "auto")
 
 
+TILED_MIN_EVENTS = 100_000      # below this the bucketing pre-pass costs more than the atomics it saves
+_WIN_MAX = 64                   # LDS window edge cap: 3 planes x 64 x 64 x 4 B = 48 KB
+_persist = {}
+
+
+def _buf(key, nbytes, device):
+    """Grow-only persistent device scratch (avoids re-allocating tens of MB per objective evaluation)."""
+    import torch
+    b = _persist.get((key, device.index))
+    if b is None or b.numel() < nbytes:
+        b = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _persist[(key, device.index)] = b
+    return b
+
+
+class Buckets:
+    """Events partitioned by tile: `records` (n_kept, 4) float32 (x, y, t, p), `bucket_start` (ntiles+1) offsets."""
+
+    def __init__(self, records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles):
+        self.records, self.bucket_start = records, bucket_start
+        self.key_mode, self.dom_h, self.dom_w = key_mode, dom_h, dom_w
+        self.tw_log2, self.th_log2, self.ntiles = tw_log2, th_log2, ntiles
+
+
+def can_tile(cols, impl):
+    """Tiled path preconditions: float32, contiguous, 16-byte aligned columns, n < 2^32; under 'auto' also enough
+    events to amortise the bucketing pre-pass."""
+    import torch
+    n = cols[0].shape[0]
+    if impl not in ("tiled", "auto") or n == 0 or n >= 2 ** 32:
+        return False
+    if not all(c.dtype == torch.float32 and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in cols):
+        return False
+    return impl == "tiled" or n >= TILED_MIN_EVENTS
+
+
+def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None):
+    """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass)."""
+    import torch
+    L = _lib.lib()
+    ntiles = L.evk_bucket_num_tiles(dom_h, dom_w, tw_log2, th_log2)
+    if ntiles <= 0:
+        raise _lib.EvkError("unsupported tiling %s of domain %s" % ((tw_log2, th_log2), (dom_h, dom_w)))
+    n = xd.shape[0]
+    dev = xd.device
+    records = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    bucket_start = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
+    nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
+    scratch = _buf("bucket", nbytes, dev)
+    _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, key_mode, dom_h, dom_w, tw_log2,
+              th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
+              oob.ptr if oob is not None else None, D.stream())
+    return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles)
+
+
+def voxel_tile_shape(H, W, B):
+    """Tile (log2 w, log2 h) for the voxel kernel: >= ~4 tiles per CU for load balance, B*tile*4 B of LDS <= 32 KB."""
+    env = os.environ.get("EVK_VOXEL_TILE")
+    if env:
+        a, b = env.split("x")
+        return int(a), int(b)
+    for tw, th in ((5, 5), (5, 4), (4, 4), (4, 3), (3, 3)):
+        ntiles = -(-W // (1 << tw)) * -(-H // (1 << th))
+        if ntiles >= 1000 and B * 4 << (tw + th) <= 32768:
+            return tw, th
+    return 3, 3
+
+
 def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None):
+    """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W)."""
     impl = impl or default_impl()
+    if can_tile((xd, yd, td, pd), impl) and B * 4 * 64 <= 32768:
+        tw, th = voxel_tile_shape(H, W, B)
+        bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
+        _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th, t_first, t_last, B,
+                  D.ptr(out), D.stream())
+        return out
     _lib.call("evk_voxel_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], t_first, t_last, B, H, W,
               D.ptr(out), oob.ptr if oob is not None else None, D.stream())
     return out
 
 
+def _iwe_window(t_first, t_ref, vx, vy, tw):
+    """Time slices and LDS window for the tiled IWE kernel from the flow displacement over the stream."""
+    import math
+    Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
+    room = _WIN_MAX - tw - 4
+    S = max(1, int(math.ceil(max(Dx, Dy) / room)))
+    rnd = lambda v: min(_WIN_MAX, (int(v) + 7) // 8 * 8)
+    return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(tw + math.ceil(Dy / S) + 4)
+
+
 def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, impl=None):
     """Fused get_iwe for the linear-flow model on DeviceEvents `ev`, accumulating into iwe (ch, cw) / diwe (2, ch, cw)."""
+    import math
     import torch
     impl = impl or default_impl()
+    if can_tile((ev.x, ev.y, ev.t, ev.p), impl) and math.isfinite(vx) and math.isfinite(vy):
+        tw = th = 5
+        dom_h = max(int(bounds_h) + 1, ch)
+        dom_w = max(int(bounds_w) + 1, cw)
+        t_first = ev.t_at(0)
+        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw)
+        if S <= 64:
+            key = (1, dom_h, dom_w, tw, th)
+            bk = ev._buckets.get(key)
+            if bk is None:
+                bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
+                ev._buckets[key] = bk
+            planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
+            nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, S, planes, win_w, win_h))
+            staging = _buf("iwe_staging", nbytes, ev.x.device)
+            _lib.call("evk_iwe_linvel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), dom_h, dom_w, tw, th, S,
+                      win_w, win_h, t_first, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale),
+                      D.ptr(staging), nbytes, D.ptr(iwe), D.ptr(diwe), D.stream())
+            return
     fn = "evk_iwe_linvel_f32" if ev.dtype == torch.float32 else "evk_iwe_linvel_f64"
     _lib.call(fn, D.ptr(ev.x), D.ptr(ev.y), D.ptr(ev.t), D.ptr(ev.p), len(ev), t_ref, vx, vy, bounds_w, bounds_h, ch, cw,
               flags, float(ev.p_scale), D.ptr(iwe), D.ptr(diwe), D.stream())
@@ -39,15 +144,26 @@ def _time_ms(fn, reps):
         fn()
         e1[i].record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in zip(e0, e1))
+    ts = [a.elapsed_time(b) for a, b in zip(e0, e1)]
     return float(sum(ts) / len(ts))
 
 
 def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps=10):
-    """HIP-event timing (on the launch stream) of the kernels one voxel call launches, for bench.py's roofline."""
+    """HIP-event timing (on the launch stream) of the stages one voxel call launches, for bench.py's roofline:
+    'bucket' = histogram + scans + scatter, 'tile' = the LDS accumulate kernel; 'direct' = the global-atomic kernel."""
     import torch
     impl = impl or default_impl()
     out = torch.zeros((B, H, W), dtype=torch.float32, device=xd.device)
-    ms = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="direct"), reps)
-    return {"impl": "direct", "dominant": "k_voxel_f32<VEC>", "dominant_ms": ms, "total_ms": ms,
-            "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
+    if not (can_tile((xd, yd, td, pd), impl) and B * 4 * 64 <= 32768):
+        ms = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="direct"), reps)
+        return {"impl": "direct", "dominant": "k_voxel_f32", "dominant_ms": ms, "total_ms": ms,
+                "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
+    tw, th = voxel_tile_shape(H, W, B)
+    total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled"), reps)
+    bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)
+    b_ms = _time_ms(lambda: bucket_events(xd, yd, td, pd, 0, H, W, tw, th), reps)
+    t_ms = _time_ms(lambda: _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th,
+                                      t_first, t_last, B, D.ptr(out), D.stream()), reps)
+    dom = ("k_tile_scatter(+hist,scan)", b_ms) if b_ms > t_ms else ("k_voxel_tiled", t_ms)
+    return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom[0], "dominant_ms": dom[1], "total_ms": total,
+            "kernels_ms": {"bucket(hist+scan+scatter)": round(b_ms, 4), "k_voxel_tiled": round(t_ms, 4)}}

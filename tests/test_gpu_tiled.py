@@ -1,0 +1,157 @@
+"""GPU (-m gpu): the tile-bucketed LDS path (evk_tiled.hip) forced on, against the oracle and against the direct
+(global-atomic) path, including the cases that stress its special handling: ragged sizes, empty tiles, events on tile
+borders, negative-wrap coordinates, flows larger than the LDS halo (time slices + global-atomic spill), the Q1 canvas
+quirk, adaptive lifespan slices."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+def close(a, ref, tol=TOL):
+    a, ref = f64(a), f64(ref)
+    assert a.shape == ref.shape
+    scale = max(np.max(np.abs(ref)), 1e-30)
+    err = np.max(np.abs(a - ref))
+    assert err <= tol * scale, "max err %.3e vs tol %.3e" % (err, tol * scale)
+
+
+@pytest.fixture()
+def E(monkeypatch):
+    import event_utils_amd as E
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    return E
+
+
+def _events(seed, n, H, W, real=False, t_hi=0.1):
+    rng = np.random.default_rng(seed)
+    if real:
+        x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+    else:
+        x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, t_hi, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    return x, y, t, p
+
+
+def test_bucketing_is_a_permutation(E):
+    """Every event appears exactly once in its own tile's segment, segments tile the record array."""
+    from event_utils_amd import tiled
+    n, H, W = 300_001, 100, 150
+    x, y, t, p = _events(3, n, H, W)
+    xd, yd, td, pd = (torch.from_numpy(a).cuda() for a in (x, y, t, p))
+    bk = tiled.bucket_events(xd, yd, td, pd, 0, H, W, 4, 3)
+    rec = bk.records.cpu().numpy(); bs = bk.bucket_start.cpu().numpy().astype(np.int64)
+    assert bs[0] == 0 and bs[-1] == n and np.all(np.diff(bs) >= 0)
+    tiles_x = -(-W // 16)
+    key = (rec[:, 1].astype(np.int64) >> 3) * tiles_x + (rec[:, 0].astype(np.int64) >> 4)
+    seg = np.searchsorted(bs, np.arange(n), side="right") - 1
+    assert np.array_equal(key, seg)
+    a = np.stack([x, y, t, p], 1)
+    assert np.array_equal(rec[np.lexsort(rec.T[::-1])], a[np.lexsort(a.T[::-1])])
+    # time order inside a tile is preserved up to intra-block interleaving: check it is at least mostly sorted
+    inv = sum(int(np.sum(np.diff(rec[bs[k]:bs[k + 1], 2]) < 0)) for k in range(0, len(bs) - 1, 7))
+    assert inv < 0.2 * n / 7
+
+
+@pytest.mark.parametrize("n", [5, 64, 1001, 50_000, 400_003])
+@pytest.mark.parametrize("shape", [(48, 64, 5), (50, 70, 3), (480, 640, 5), (7, 9, 2)])
+def test_voxel_tiled_vs_oracle(E, n, shape):
+    H, W, B = shape
+    x, y, t, p = _events(n + H, n, H, W)
+    x = x + np.float32(0.3)          # fractional coordinates: truncation
+    x[x >= W] = W - 1
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W))
+    close(v.cpu().numpy(), ref)
+
+
+def test_voxel_tiled_errors_and_wrap(E):
+    n, H, W = 2000, 40, 60
+    x, y, t, p = _events(1, n, H, W)
+    x[5] = -1.0; y[7] = -3.0                      # wrap like torch index_put_
+    ref = R.events_to_voxel_torch(x, y, t, p, 4, sensor_size=(H, W), accum="f64")
+    v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), 4, sensor_size=(H, W))
+    close(v.cpu().numpy(), ref)
+    x[11] = W + 2.0
+    with pytest.raises(IndexError):
+        E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), 4, sensor_size=(H, W))
+    # all events in one pixel (one hot tile, every other tile empty)
+    x[:] = 17; y[:] = 23
+    ref = R.events_to_voxel_torch(x, y, t, p, 4, sensor_size=(H, W), accum="f64")
+    v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), 4, sensor_size=(H, W))
+    close(v.cpu().numpy(), ref)
+
+
+def test_voxel_tiled_equals_direct_at_full_size(E, monkeypatch):
+    """configs[1] at full size: 10M events, 640x480x5; tiled vs direct (both HIP) and mass conservation."""
+    H, W, B, n = 480, 640, 5, 10_000_000
+    x, y, t, p = _events(1, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    vt = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    monkeypatch.setenv("EVK_IMPL", "direct")
+    vd = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    close(vt.cpu().numpy(), vd.cpu().numpy())
+    assert abs(vt.double().sum().item() - float(p.astype(np.float64).sum())) <= 1e-3 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("prm", [(0., 0.), (30., -20.), (-280., 310.), (2500., -1800.), (-9000., 12000.)])
+@pytest.mark.parametrize("shape", [(180, 240, 60_000), (480, 640, 300_000)])
+def test_iwe_tiled_vs_oracle(E, prm, shape):
+    H, W, n = shape
+    x, y, t, p = _events(H + n, n, H, W, real=True)
+    prm = np.array(prm)
+    ri, rd = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), compute_gradient=True,
+                       sensor_size=(H, W), accum="f64")
+    iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W))
+    close(iwe, ri); close(diwe, rd)
+    iwe2, none = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=False, use_polarity=False,
+                           sensor_size=(H, W))
+    ri2, _ = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), use_polarity=False,
+                       sensor_size=(H, W), accum="f64")
+    assert none is None
+    close(iwe2, ri2)
+
+
+def test_iwe_tiled_q1_canvas_and_unsorted_times(E):
+    """img_size larger than the hard-wired (181, 241) canvas (Q1), and a time column that is NOT sorted (the window
+    placement is only a hint; every event must still land)."""
+    H, W, n = 200, 300, 50_000
+    x, y, t, p = _events(9, n, 170, 230, real=True)
+    rng = np.random.default_rng(1)
+    t = rng.permutation(t)
+    t[-1] = 0.1
+    prm = np.array([120., -75.])
+    ri, rd = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), compute_gradient=True, accum="f64")
+    iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=True)
+    assert iwe.shape == (181, 241)
+    close(iwe, ri); close(diwe, rd)
+
+
+def test_objective_tiled_matches_golden_and_lifespan(E, golden):
+    g = golden("f8_objective")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    from event_utils_amd.events import DeviceEvents
+    ev = DeviceEvents.from_arrays(x, y, t, p)
+    w, obj = E.linvel_warp(), E.variance_objective()
+    obj.impl = "tiled"
+    for i, prm in enumerate(g["params"]):
+        for j, s in enumerate(g["sigmas"]):
+            f = obj.evaluate_function(prm, ev, None, None, None, w, (180, 240), blur_sigma=s)
+            gr = obj.evaluate_gradient(prm, ev, None, None, None, w, (180, 240), blur_sigma=s)
+            assert abs(f - g["f"][i, j]) <= TOL * abs(g["f"][i, j])
+            assert np.max(np.abs(f64(gr) - g["grad"][i, j])) <= TOL * np.max(np.abs(g["grad"][i, j])) + 1e-9
+    assert len(ev._buckets) == 1            # bucketed once, reused by all 30 evaluations
+    al = E.variance_objective(adaptive_lifespan=True, minimum_events=5000)
+    al.impl = "tiled"
+    al.iter_update(np.array([400., -250.]))
+    f = al.evaluate_function(np.array([40., -25.]), ev, None, None, None, w, (180, 240), blur_sigma=1.0)
+    assert abs(f - g["al_f"]) <= TOL * abs(g["al_f"])
