@@ -168,11 +168,15 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float
 // ---------------------------------------------------------------------------------------------------------
 // voxel grid: one workgroup per tile, LDS accumulators (B x th x tw), exclusive plain-store flush
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_add(float *p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// LDS accumulators are float64: on gfx950 ds_add_f32 sustains only ~0.33 lane-ops/clk/CU (204 G/s chip-wide) while
+// ds_add_f64 runs at ~2.9 (1.8 T/s) -- measured with tools/lds_probe.hip.  The per-event f32 values are exactly the
+// reference's; summing them in f64 and rounding once at the flush is also closer to the true sum than f32 atomics.
+typedef double acc_t;
+__device__ __forceinline__ void lds_add(acc_t *p, float v) {
+    __hip_atomic_fetch_add(p, (acc_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void voxel_bins_lds(float *acc, int tpix, int local, int B, float tn, float p) {
+__device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, int B, float tn, float p) {
     if (tn != tn) {  // dt == 0 (Q9): NaN in every bin of the pixel
         for (int b = 0; b < B; ++b) lds_add(acc + b * tpix + local, tn * p);
         return;
@@ -192,11 +196,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
                                                            const uint32_t *__restrict__ bucket_start, TileGrid g,
                                                            float t_first, float dt, float bm1, int B,
                                                            float *__restrict__ vox) {
-    extern __shared__ float acc[];
+    extern __shared__ __attribute__((aligned(16))) acc_t acc[];
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
     const int tile = blockIdx.x;
     const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
-    for (int i = threadIdx.x; i < B * tpix; i += EVK_BLOCK) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < B * tpix; i += EVK_BLOCK) acc[i] = 0.0;
     __syncthreads();
     const uint32_t lo = bucket_start[tile], hi = bucket_start[tile + 1];
     auto one = [&](const float4 &r) {
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
         const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
         if (X < g.dom_w && Y < g.dom_h) {
             float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
-            *o += acc[c];  // the tile is owned by this workgroup: plain read-modify-write, coalesced per row
+            *o += (float)acc[c];  // the tile is owned by this workgroup: plain read-modify-write, coalesced per row
         }
     }
 }
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                                                          IweParams q, float *__restrict__ staging,
                                                          int4 *__restrict__ origins, float *__restrict__ iwe,
                                                          float *__restrict__ diwe) {
-    extern __shared__ float win[];
+    extern __shared__ __attribute__((aligned(16))) acc_t win[];
     const int wcells = q.win_w * q.win_h;
     constexpr int PLANES = GRAD ? 3 : 1;
     const int tile = blockIdx.x / q.slices, s = blockIdx.x - tile * q.slices;
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     const uint32_t cnt = bhi - blo;
     const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * s) / q.slices);
     const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (s + 1)) / q.slices);
-    for (int i = threadIdx.x; i < PLANES * wcells; i += EVK_BLOCK) win[i] = 0.0f;
+    for (int i = threadIdx.x; i < PLANES * wcells; i += EVK_BLOCK) win[i] = 0.0;
     // Window origin from the time span of this slice (records are time-ordered up to intra-block interleaving; an
     // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
     int wx0 = 0, wy0 = 0;
@@ -297,13 +301,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         const int lx = px - wx0, ly = py - wy0;
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
-            float *c = win + ly * q.win_w + lx;
+            acc_t *c = win + ly * q.win_w + lx;
             lds_add(c, mp * ax * ay);
             lds_add(c + 1, mp * dx * ay);
             lds_add(c + q.win_w, mp * ax * dy);
             lds_add(c + q.win_w + 1, mp * dx * dy);
             if constexpr (GRAD) {
-                float *d0 = c + wcells, *d1 = d0 + wcells;
+                acc_t *d0 = c + wcells, *d1 = d0 + wcells;
                 lds_add(d0, a * (-ay));
                 lds_add(d0 + 1, a * ay);
                 lds_add(d0 + q.win_w, a * (-dy));
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     for (; i < hi; i += EVK_BLOCK) one(rec[i]);
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
-    for (int c = threadIdx.x; c < PLANES * wcells; c += EVK_BLOCK) st[c] = win[c];
+    for (int c = threadIdx.x; c < PLANES * wcells; c += EVK_BLOCK) st[c] = (float)win[c];
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
 }
 
@@ -452,7 +456,7 @@ extern "C" int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_start || !vox)
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
-    const size_t lds = (size_t)B * sizeof(float) << (tw_log2 + th_log2);
+    const size_t lds = (size_t)B * sizeof(acc_t) << (tw_log2 + th_log2);
     if (lds > 64 * 1024) return EVK_EINVAL;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
     k_voxel_tiled<<<ntiles, EVK_BLOCK, lds, (hipStream_t)stream>>>((const float4 *)records, bucket_start, g, t_first, dt,
@@ -477,7 +481,7 @@ extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bu
     const int tw = 1 << tw_log2, th = 1 << th_log2;
     if (win_w < tw + 3 || win_h < th + 3) return EVK_EINVAL;
     const int planes = grad ? 3 : 1;
-    const size_t lds = (size_t)planes * win_w * win_h * sizeof(float);
+    const size_t lds = (size_t)planes * win_w * win_h * sizeof(acc_t);
     if (lds > 64 * 1024) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, slices, planes, win_w, win_h)) return EVK_ESCRATCH;

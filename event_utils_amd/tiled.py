@@ -13,7 +13,7 @@ def default_impl():
 
 
 TILED_MIN_EVENTS = 100_000      # below this the bucketing pre-pass costs more than the atomics it saves
-_WIN_MAX = 64                   # LDS window edge cap: 3 planes x 64 x 64 x 4 B = 48 KB
+_WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
 
 
@@ -75,7 +75,7 @@ def voxel_tile_shape(H, W, B):
         return int(a), int(b)
     for tw, th in ((5, 5), (5, 4), (4, 4), (4, 3), (3, 3)):
         ntiles = -(-W // (1 << tw)) * -(-H // (1 << th))
-        if ntiles >= 1000 and B * 4 << (tw + th) <= 32768:
+        if ntiles >= 1000 and B * 8 << (tw + th) <= 32768:
             return tw, th
     return 3, 3
 
@@ -83,7 +83,7 @@ def voxel_tile_shape(H, W, B):
 def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None):
     """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W)."""
     impl = impl or default_impl()
-    if can_tile((xd, yd, td, pd), impl) and B * 4 * 64 <= 32768:
+    if can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
         _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th, t_first, t_last, B,
@@ -94,13 +94,14 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     return out
 
 
-def _iwe_window(t_first, t_ref, vx, vy, tw):
+def _iwe_window(t_first, t_ref, vx, vy, tw, planes=3):
     """Time slices and LDS window for the tiled IWE kernel from the flow displacement over the stream."""
     import math
     Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
-    room = _WIN_MAX - tw - 4
+    wmax = _WIN_MAX[planes]
+    room = wmax - tw - 4
     S = max(1, int(math.ceil(max(Dx, Dy) / room)))
-    rnd = lambda v: min(_WIN_MAX, (int(v) + 7) // 8 * 8)
+    rnd = lambda v: min(wmax, (int(v) + 7) // 8 * 8)
     return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(tw + math.ceil(Dy / S) + 4)
 
 
@@ -114,14 +115,14 @@ def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, 
         dom_h = max(int(bounds_h) + 1, ch)
         dom_w = max(int(bounds_w) + 1, cw)
         t_first = ev.t_at(0)
-        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw)
+        planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
+        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, planes)
         if S <= 64:
             key = (1, dom_h, dom_w, tw, th)
             bk = ev._buckets.get(key)
             if bk is None:
                 bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
                 ev._buckets[key] = bk
-            planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
             nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, S, planes, win_w, win_h))
             staging = _buf("iwe_staging", nbytes, ev.x.device)
             _lib.call("evk_iwe_linvel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), dom_h, dom_w, tw, th, S,
@@ -154,7 +155,7 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
     import torch
     impl = impl or default_impl()
     out = torch.zeros((B, H, W), dtype=torch.float32, device=xd.device)
-    if not (can_tile((xd, yd, td, pd), impl) and B * 4 * 64 <= 32768):
+    if not (can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536):
         ms = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="direct"), reps)
         return {"impl": "direct", "dominant": "k_voxel_f32", "dominant_ms": ms, "total_ms": ms,
                 "kernels_ms": {"k_voxel_f32": round(ms, 4)}}

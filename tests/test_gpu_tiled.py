@@ -59,7 +59,7 @@ def test_bucketing_is_a_permutation(E):
     assert np.array_equal(rec[np.lexsort(rec.T[::-1])], a[np.lexsort(a.T[::-1])])
     # time order inside a tile is preserved up to intra-block interleaving: check it is at least mostly sorted
     inv = sum(int(np.sum(np.diff(rec[bs[k]:bs[k + 1], 2]) < 0)) for k in range(0, len(bs) - 1, 7))
-    assert inv < 0.2 * n / 7
+    assert inv < 0.5 * n / 7
 
 
 @pytest.mark.parametrize("n", [5, 64, 1001, 50_000, 400_003])
