@@ -78,3 +78,11 @@ def reduce_scratch(device):
         nbytes = int(_lib.lib().evk_reduce_scratch_bytes())
         _scratch[key] = (torch.empty(nbytes // 8, dtype=torch.float64, device=device), nbytes)
     return _scratch[key]
+
+
+def out4(device):
+    """Persistent 4-double device result slot (objective evaluations return a few scalars)."""
+    key = (device.index, "out4")
+    if key not in _scratch:
+        _scratch[key] = torch.empty(4, dtype=torch.float64, device=device)
+    return _scratch[key]

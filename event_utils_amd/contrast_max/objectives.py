@@ -35,6 +35,20 @@ def gaussian_kernel1d(sigma, truncate=4.0):
     return phi / phi.sum(), radius
 
 
+_kernel_cache = {}
+
+
+def _blur_kernel(sigma):
+    """(host float64 weights, radius) for evk_*; radius -1 = no blur (blur_sigma <= 0, objectives.py:232)."""
+    if not sigma > 0:
+        return None, -1
+    key = float(sigma)
+    if key not in _kernel_cache:
+        w, radius = gaussian_kernel1d(key)
+        _kernel_cache[key] = (np.ascontiguousarray(w, dtype=np.float64), radius)
+    return _kernel_cache[key]
+
+
 def gaussian_filter_device(src, sigma, truncate=4.0):
     """scipy.ndimage.gaussian_filter(src, sigma) (mode='reflect') for a 2-D or 3-D float32 device tensor."""
     w, radius = gaussian_kernel1d(sigma, truncate)
@@ -215,12 +229,12 @@ class variance_objective(objective_function):
         else:
             iwe = D.to_device(iwe, torch.float32, dev)
         blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
-        if blur_sigma > 0:
-            iwe = gaussian_filter_device(iwe, blur_sigma)
-        out = torch.empty(4, dtype=torch.float64, device=dev)
-        scratch, nbytes = D.reduce_scratch(dev)
-        _lib.call("evk_variance_f32", D.ptr(iwe.contiguous()), iwe.numel(), D.ptr(out), D.ptr(scratch), nbytes,
-                  D.stream())
+        w, radius = _blur_kernel(blur_sigma)
+        iwe = iwe.contiguous()
+        out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+        # fused blur (both axes) + mean / variance reduction: one launch + a 1-block finalise
+        _lib.call("evk_objective_variance_f32", D.ptr(iwe), iwe.shape[0], iwe.shape[1],
+                  D.host_ptr(w) if w is not None else None, radius, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
         loss = out[1].item()
         return np.float32(-loss)
 
@@ -234,15 +248,14 @@ class variance_objective(objective_function):
         else:
             iwe, d_iwe = D.to_device(iwe, torch.float32, dev), D.to_device(d_iwe, torch.float32, dev)
         blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
-        if blur_sigma > 0:
-            if self.reference_exact:
-                d_iwe = gaussian_filter_device(d_iwe, blur_sigma)
-            else:
-                d_iwe = torch.stack([gaussian_filter_device(d_iwe[i], blur_sigma) for i in range(d_iwe.shape[0])])
-                iwe = gaussian_filter_device(iwe, blur_sigma)
-        out = torch.empty(4, dtype=torch.float64, device=dev)
-        scratch, nbytes = D.reduce_scratch(dev)
-        _lib.call("evk_variance_grad_f32", D.ptr(iwe.contiguous()), D.ptr(d_iwe.contiguous()), iwe.numel(), D.ptr(out),
-                  D.ptr(scratch), nbytes, D.stream())
+        w, radius = _blur_kernel(blur_sigma)
+        flags = 1 if self.reference_exact else 2       # EVK_POST_MIX (Q4) | EVK_POST_BLUR_IWE (consistent gradient)
+        if d_iwe.shape[0] != 2:
+            raise ValueError("d_iwe must have 2 channels (the reference hard-codes 2, image.py:210)")
+        iwe, d_iwe = iwe.contiguous(), d_iwe.contiguous()
+        out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+        _lib.call("evk_objective_variance_grad_f32", D.ptr(iwe), D.ptr(d_iwe), iwe.shape[0], iwe.shape[1],
+                  D.host_ptr(w) if w is not None else None, radius, flags, D.ptr(out), D.ptr(scratch), nbytes,
+                  D.stream())
         g = out[:2].cpu().numpy()
         return -(g.astype(np.float32))

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_blur_axis(const float *__restrict
 // deterministic two-stage reductions (per-block partials in fixed order, then one block)
 // ---------------------------------------------------------------------------------------------------------
 
-#define EVK_REDUCE_MAX_BLOCKS 512
+#define EVK_REDUCE_MAX_BLOCKS 4096
 #define EVK_REDUCE_K 5
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -119,6 +119,110 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// fused objective post-pass: [channel mix ->] blur axis 0 -> blur axis 1 -> per-block partial sums, one launch.
+// Arithmetic and summation order are those of k_blur_axis (bit-identical blurred values); the blurred images are
+// never written to memory.  MODE 0: variance of blur(iwe).  MODE 1: gradient sums with blur3d(diwe).
+// ---------------------------------------------------------------------------------------------------------
+#define EVK_POST_T 32
+#define EVK_POST_MIX 1u       // scipy's 3-D gaussian_filter on (2, H, W): also filter across the channel axis (Q4)
+#define EVK_POST_BLUR_IWE 2u  // gradient: use the blurred IWE (reference_exact=False); default is the raw IWE (Q5)
+
+__device__ __forceinline__ int reflect_idx(int q, int len) {
+    const int period = 2 * len;
+    int m = q % period;
+    if (m < 0) m += period;
+    return m >= len ? period - 1 - m : m;
+}
+
+// Blurs one plane over this block's 32x32 output tile; LOAD(gy, gx) returns the (already reflected) source pixel.
+template <typename LOAD>
+__device__ __forceinline__ void blur_tile(float *patch, float *inter, const BlurWeights &bw, int y0, int x0, int ch,
+                                          int cw, LOAD load, float (&res)[4]) {
+    const int r = bw.radius, PW = EVK_POST_T + 2 * r, PH = PW;
+    for (int i = threadIdx.x; i < PH * PW; i += EVK_BLOCK) {
+        const int py = i / PW, px = i - py * PW;
+        patch[i] = load(reflect_idx(y0 - r + py, ch), reflect_idx(x0 - r + px, cw));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < EVK_POST_T * PW; i += EVK_BLOCK) {  // axis 0 (rows)
+        const int y = i / PW, xx = i - y * PW;
+        const float *col = patch + (y + r) * PW + xx;
+        double acc = (double)col[0] * bw.w[r];
+        for (int j = r; j >= 1; --j) acc += ((double)col[-j * PW] + (double)col[j * PW]) * bw.w[r - j];
+        inter[i] = (float)acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // axis 1 (columns)
+        const int o = threadIdx.x + k * EVK_BLOCK;
+        const int y = o / EVK_POST_T, x = o - y * EVK_POST_T;
+        const float *row = inter + y * PW + x + r;
+        double acc = (double)row[0] * bw.w[r];
+        for (int j = r; j >= 1; --j) acc += ((double)row[-j] + (double)row[j]) * bw.w[r - j];
+        res[k] = (float)acc;
+    }
+    __syncthreads();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restrict__ iwe,
+                                                          const float *__restrict__ diwe, int ch, int cw,
+                                                          BlurWeights bw, uint32_t flags,
+                                                          double *__restrict__ partials) {
+    extern __shared__ float sm[];
+    const int r = bw.radius, PW = EVK_POST_T + 2 * r;
+    float *patch = sm, *inter = sm + PW * PW;
+    const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T;
+    const int y0 = (blockIdx.x / tiles_x) * EVK_POST_T, x0 = (blockIdx.x % tiles_x) * EVK_POST_T;
+    const int64_t plane = (int64_t)ch * cw;
+    double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
+    if constexpr (MODE == 0) {
+        float v[4];
+        blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
+            if (y < ch && x < cw) {
+                acc[0] += (double)v[k];
+                acc[1] += (double)v[k] * (double)v[k];
+            }
+        }
+    } else {
+        float d[2][4], a[4];
+        for (int c = 0; c < 2; ++c) {
+            auto load_mixed = [&](int gy, int gx) -> float {
+                const int64_t pix = (int64_t)gy * cw + gx;
+                if (!(flags & EVK_POST_MIX)) return diwe[c * plane + pix];
+                // axis-0 pass of scipy's 3-D filter over the length-2 channel axis (reflect), f64 -> f32
+                const float dv[2] = {diwe[pix], diwe[plane + pix]};
+                double s = (double)dv[c] * bw.w[r];
+                for (int j = r; j >= 1; --j)
+                    s += ((double)dv[reflect_idx(c - j, 2)] + (double)dv[reflect_idx(c + j, 2)]) * bw.w[r - j];
+                return (float)s;
+            };
+            blur_tile(patch, inter, bw, y0, x0, ch, cw, load_mixed, d[c]);
+        }
+        if (flags & EVK_POST_BLUR_IWE) {
+            blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, a);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
+            if (y < ch && x < cw) {
+                const double av = (flags & EVK_POST_BLUR_IWE) ? (double)a[k] : (double)iwe[(int64_t)y * cw + x];
+                acc[0] += av;
+                acc[1] += (double)d[0][k];
+                acc[2] += (double)d[1][k];
+                acc[3] += av * (double)d[0][k];
+                acc[4] += av * (double)d[1][k];
+            }
+        }
+    }
+    block_sum<EVK_REDUCE_K>(acc, partials + (int64_t)blockIdx.x * EVK_REDUCE_K);
+}
+
 }  // namespace evk
 
 using namespace evk;
@@ -173,4 +277,36 @@ extern "C" int evk_variance_f32(const float *img, int64_t n, double *out, void *
 extern "C" int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_t n, double *out, void *scratch,
                                      int64_t scratch_bytes, void *stream) {
     return launch_reduce<1>(iwe, diwe, n, out, scratch, scratch_bytes, stream);
+}
+
+template <int MODE>
+static int launch_post(const float *iwe, const float *diwe, int h, int w, const double *host_weights, int radius,
+                       uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!iwe || h <= 0 || w <= 0 || !out || !scratch || (MODE == 1 && !diwe)) return EVK_EINVAL;
+    if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
+    if (radius < 0)  // blur_sigma <= 0: plain reductions
+        return launch_reduce<MODE>(iwe, diwe, (int64_t)h * w, out, scratch, scratch_bytes, stream);
+    if (!host_weights || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
+    const int grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
+    if (grid > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
+    BlurWeights bw;
+    bw.radius = radius;
+    for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
+    const int PW = EVK_POST_T + 2 * radius;
+    const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    k_post_fused<MODE><<<grid, EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, flags, (double *)scratch);
+    k_reduce_final<MODE><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out);
+    return launch_status();
+}
+
+extern "C" int evk_objective_variance_f32(const float *iwe, int h, int w, const double *host_weights, int radius,
+                                          double *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    return launch_post<0>(iwe, nullptr, h, w, host_weights, radius, 0u, out, scratch, scratch_bytes, stream);
+}
+
+extern "C" int evk_objective_variance_grad_f32(const float *iwe, const float *diwe, int h, int w,
+                                               const double *host_weights, int radius, uint32_t flags, double *out,
+                                               void *scratch, int64_t scratch_bytes, void *stream) {
+    return launch_post<1>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream);
 }

@@ -8,6 +8,8 @@
 //   3. the tile is flushed with plain, coalesced stores: voxel tiles are owned exclusively; IWE windows (tile + halo,
 //      shifted by the flow) go to a staging area and a gather kernel sums the (<= a few) windows covering each pixel.
 // No global atomics remain on the hot path (only the rare event that lands outside its block's window uses one).
+#include <cstdlib>
+
 #include "evk_common.h"
 
 namespace evk {
@@ -165,6 +167,78 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float
     }
 }
 
+// Scatter with software write-combining.  A scattered 16-byte store costs a 32-byte HBM sector (PMC: the plain
+// scatter writes 314 MB for 160 MB of records), so every tile gets an R-slot LDS ring that holds the records of the
+// sliding window of positions [vstart, vstart + R) of this block's segment of that tile; after each phase of 4096
+// events the complete, G = R/2-aligned granules (G*16 bytes: 64 B for R = 8, 128 B for R = 16) are written out by
+// G consecutive lanes as one contiguous, aligned piece.  A record that does not fit the window (a hot tile) is stored
+// directly -- such stores are consecutive in memory anyway.
+template <int R>
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const float *__restrict__ x,
+                                                                        const float *__restrict__ y,
+                                                                        const float *__restrict__ t,
+                                                                        const float *__restrict__ p, int64_t n,
+                                                                        int64_t chunk, TileGrid g, int mode,
+                                                                        int ntiles,
+                                                                        const uint32_t *__restrict__ table,
+                                                                        const uint32_t *__restrict__ bucket_start,
+                                                                        float4 *__restrict__ rec) {
+    constexpr int G = R / 2;
+    extern __shared__ __attribute__((aligned(16))) float4 ring[];  // [ntiles][R]
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(ring + (size_t)ntiles * R);
+    uint32_t *vstart = cursor + ntiles;
+    for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+        const uint32_t c = bucket_start[i] + table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x];
+        cursor[i] = c;
+        vstart[i] = c;
+    }
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    const int64_t nq = (hi > lo) ? ((hi - lo + 3) >> 2) : 0;  // quads, the last one may be ragged
+    const int64_t nphase = (nq + blockDim.x - 1) / blockDim.x;
+    auto place = [&](float xv, float yv, float tv, float pv) {
+        const int key = tile_key(xv, yv, g, mode);
+        if (key < 0) return;
+        const uint32_t pos = atomicAdd(&cursor[key], 1u);
+        const float4 r = make_float4(xv, yv, tv, pv);
+        if (pos - vstart[key] < (uint32_t)R)
+            ring[(size_t)key * R + (pos & (R - 1))] = r;
+        else
+            rec[pos] = r;
+    };
+    for (int64_t ph = 0; ph <= nphase; ++ph) {
+        const int64_t q = ph * blockDim.x + threadIdx.x;
+        if (ph < nphase && q < nq) {
+            const int64_t base = lo + (q << 2);
+            if (base + 4 <= hi) {
+                const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q), tv = load4(t + lo, q),
+                                  pv = load4(p + lo, q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) place(xv.v[k], yv.v[k], tv.v[k], pv.v[k]);
+            } else {
+                for (int64_t i = base; i < hi; ++i) place(x[i], y[i], t[i], p[i]);
+            }
+        }
+        __syncthreads();
+        // flush: R consecutive lanes serve one tile; the last pass (ph == nphase) drains everything
+        const bool last = (ph == nphase);
+        const int sub = threadIdx.x & (R - 1);
+        for (int k = threadIdx.x / R; k < ntiles; k += blockDim.x / R) {
+            const uint32_t vs = vstart[k], c = cursor[k];
+            uint32_t end;  // flush positions [vs, end)
+            if (c - vs >= (uint32_t)R) end = vs + R;          // window full (overflow went direct): drain it
+            else if (last) end = c;
+            else end = (c / G) * G;                           // complete aligned granules only
+            const uint32_t pos = vs + sub;
+            if (end > vs && pos < end) rec[pos] = ring[(size_t)k * R + (pos & (R - 1))];
+            if (sub == 0 && end > vs) vstart[k] = (c - vs >= (uint32_t)R) ? c : end;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // voxel grid: one workgroup per tile, LDS accumulators (B x th x tw), exclusive plain-store flush
 // ---------------------------------------------------------------------------------------------------------
@@ -307,15 +381,15 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             lds_add(c + q.win_w, mp * ax * dy);
             lds_add(c + q.win_w + 1, mp * dx * dy);
             if constexpr (GRAD) {
-                acc_t *d0 = c + wcells, *d1 = d0 + wcells;
-                lds_add(d0, a * (-ay));
-                lds_add(d0 + 1, a * ay);
-                lds_add(d0 + q.win_w, a * (-dy));
-                lds_add(d0 + q.win_w + 1, a * dy);
-                lds_add(d1, a * (-ax));
-                lds_add(d1 + 1, a * (-dx));
-                lds_add(d1 + q.win_w, a * ax);
-                lds_add(d1 + q.win_w + 1, a * dx);
+                // The reference's 8 derivative contributions come in +/- pairs on neighbouring pixels
+                // (image.py:132-135): d0[y][x] gets -a*ay from px == x and +a*ay from px == x-1, etc.  Accumulate
+                // the 4 magnitudes (E0: a*ay, a*dy; E1: a*ax, a*dx) and take the finite difference at the flush:
+                // d0[y][x] = E0[y][x-1] - E0[y][x],  d1[y][x] = E1[y-1][x] - E1[y][x]   (8 LDS atomics, not 12).
+                acc_t *e0 = c + wcells, *e1 = e0 + wcells;
+                lds_add(e0, a * ay);
+                lds_add(e0 + q.win_w, a * dy);
+                lds_add(e1, a * ax);
+                lds_add(e1 + 1, a * dx);
             }
         } else {  // outside the window (flow larger than the halo, clamped outlier): straight to the image
             float *c = iwe + (int64_t)py * q.cw + px;
@@ -344,7 +418,15 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     for (; i < hi; i += EVK_BLOCK) one(rec[i]);
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
-    for (int c = threadIdx.x; c < PLANES * wcells; c += EVK_BLOCK) st[c] = (float)win[c];
+    for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
+        st[c] = (float)win[c];
+        if constexpr (GRAD) {
+            const int lx = c % q.win_w, ly = c / q.win_w;
+            const acc_t *e0 = win + wcells, *e1 = e0 + wcells;
+            st[wcells + c] = (float)((lx > 0 ? e0[c - 1] : 0.0) - e0[c]);
+            st[2 * wcells + c] = (float)((ly > 0 ? e1[c - q.win_w] : 0.0) - e1[c]);
+        }
+    }
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
 }
 
@@ -427,7 +509,7 @@ extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
 extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n,
                                      int key_mode, int dom_h, int dom_w, int tw_log2, int th_log2, float *records,
                                      uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
-                                     void *stream) {
+                                     int stages, void *stream) {
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
@@ -442,11 +524,40 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     chunk = (chunk + 3) & ~(int64_t)3;
     if (chunk == 0) chunk = 4;
     const size_t lds = (size_t)ntiles * sizeof(uint32_t);
-    k_tile_hist<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, n, chunk, g, key_mode, ntiles, table, oob);
-    k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
-    k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, bucket_start);
-    k_tile_scatter<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, t, p, n, chunk, g, key_mode, ntiles, table,
-                                                                   bucket_start, (float4 *)records);
+    if (stages & EVK_STAGE_HIST)
+        k_tile_hist<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, n, chunk, g, key_mode, ntiles, table, oob);
+    if (stages & EVK_STAGE_SCAN) {
+        k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
+        k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, bucket_start);
+    }
+    if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
+    // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
+    static const int variant = getenv("EVK_SCATTER") ? atoi(getenv("EVK_SCATTER")) : -1;  // tuning: 0 plain, 4/8/16
+    const size_t lds_budget = 160 * 1024 - 256;
+    int R = 0;
+    for (int r : {16, 8, 4})
+        if (!R && (size_t)ntiles * (r * 16 + 8) <= lds_budget) R = r;
+    if (variant == 0) R = 0;
+    if (variant > 0 && (size_t)ntiles * (variant * 16 + 8) <= lds_budget) R = variant;
+    const size_t lds_wc = (size_t)ntiles * (R * 16 + 8);
+#define EVK_SCATTER_WC(RR)                                                                                        \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void *)k_tile_scatter_wc<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_tile_scatter_wc<RR><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds_wc, s>>>(                               \
+            x, y, t, p, n, chunk, g, key_mode, ntiles, table, bucket_start, (float4 *)records);                   \
+    } while (0)
+    if (R == 16) EVK_SCATTER_WC(16);
+    else if (R == 8) EVK_SCATTER_WC(8);
+    else if (R == 4) EVK_SCATTER_WC(4);
+    else
+        k_tile_scatter<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, t, p, n, chunk, g, key_mode, ntiles,
+                                                                       table, bucket_start, (float4 *)records);
+#undef EVK_SCATTER_WC
     return launch_status();
 }
 

@@ -48,7 +48,7 @@ def can_tile(cols, impl):
     return impl == "tiled" or n >= TILED_MIN_EVENTS
 
 
-def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None):
+def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None):
     """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass)."""
     import torch
     L = _lib.lib()
@@ -57,13 +57,16 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
         raise _lib.EvkError("unsupported tiling %s of domain %s" % ((tw_log2, th_log2), (dom_h, dom_w)))
     n = xd.shape[0]
     dev = xd.device
-    records = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    bucket_start = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
+    if into is not None:
+        records, bucket_start = into.records, into.bucket_start
+    else:
+        records = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        bucket_start = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
     nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
     scratch = _buf("bucket", nbytes, dev)
     _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, key_mode, dom_h, dom_w, tw_log2,
               th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
-              oob.ptr if oob is not None else None, D.stream())
+              oob.ptr if oob is not None else None, stages, D.stream())
     return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles)
 
 
@@ -94,15 +97,26 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     return out
 
 
-def _iwe_window(t_first, t_ref, vx, vy, tw, planes=3):
+def iwe_tile_shape(dom_h, dom_w):
+    """Tile (log2 w, log2 h) for the IWE kernel: the largest tile that still gives >= ~4 workgroups per CU."""
+    env = os.environ.get("EVK_IWE_TILE")
+    if env:
+        a, b = env.split("x")
+        return int(a), int(b)
+    for tw, th in ((5, 5), (5, 4), (4, 4)):
+        if -(-dom_w // (1 << tw)) * -(-dom_h // (1 << th)) >= 1000:
+            return tw, th
+    return 4, 4
+
+
+def _iwe_window(t_first, t_ref, vx, vy, tw, th, planes=3):
     """Time slices and LDS window for the tiled IWE kernel from the flow displacement over the stream."""
     import math
     Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
     wmax = _WIN_MAX[planes]
-    room = wmax - tw - 4
-    S = max(1, int(math.ceil(max(Dx, Dy) / room)))
-    rnd = lambda v: min(wmax, (int(v) + 7) // 8 * 8)
-    return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(tw + math.ceil(Dy / S) + 4)
+    S = max(1, int(math.ceil(max(Dx / (wmax - tw - 4), Dy / (wmax - th - 4)))))
+    rnd = lambda v: min(wmax, (int(v) + 3) // 4 * 4)
+    return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(th + math.ceil(Dy / S) + 4)
 
 
 def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, impl=None):
@@ -111,13 +125,16 @@ def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, 
     import torch
     impl = impl or default_impl()
     if can_tile((ev.x, ev.y, ev.t, ev.p), impl) and math.isfinite(vx) and math.isfinite(vy):
-        tw = th = 5
         dom_h = max(int(bounds_h) + 1, ch)
         dom_w = max(int(bounds_w) + 1, cw)
+        tw, th = iwe_tile_shape(dom_h, dom_w)
         t_first = ev.t_at(0)
         planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
-        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, planes)
-        if S <= 64:
+        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, 1 << th, planes)
+        # windows the gather kernel must test per pixel; huge flows (line-search overshoots) use the direct kernel
+        Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
+        cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
+        if S <= 64 and cand <= 128:
             key = (1, dom_h, dom_w, tw, th)
             bk = ev._buckets.get(key)
             if bk is None:
@@ -162,9 +179,16 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
     tw, th = voxel_tile_shape(H, W, B)
     total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled"), reps)
     bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)
-    b_ms = _time_ms(lambda: bucket_events(xd, yd, td, pd, 0, H, W, tw, th), reps)
-    t_ms = _time_ms(lambda: _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th,
-                                      t_first, t_last, B, D.ptr(out), D.stream()), reps)
-    dom = ("k_tile_scatter(+hist,scan)", b_ms) if b_ms > t_ms else ("k_voxel_tiled", t_ms)
-    return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom[0], "dominant_ms": dom[1], "total_ms": total,
-            "kernels_ms": {"bucket(hist+scan+scatter)": round(b_ms, 4), "k_voxel_tiled": round(t_ms, 4)}}
+    ms = {}
+    run = lambda st: bucket_events(xd, yd, td, pd, 0, H, W, tw, th, stages=st, into=bk)
+    # the stages are not idempotent (the scan rewrites the histogram table in place): time the histogram alone, the
+    # scans as (hist + scan) - hist, then restore a consistent table with a full run and time the scatter alone
+    ms["k_tile_hist"] = _time_ms(lambda: run(1), reps)
+    ms["k_tile_scan_blocks+k_tile_scan_totals"] = max(_time_ms(lambda: run(3), reps) - ms["k_tile_hist"], 0.0)
+    run(7)
+    ms["k_tile_scatter_wc"] = _time_ms(lambda: run(4), reps)
+    ms["k_voxel_tiled"] = _time_ms(lambda: _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start),
+                                                     H, W, tw, th, t_first, t_last, B, D.ptr(out), D.stream()), reps)
+    dom = max(ms, key=ms.get)
+    return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom, "dominant_ms": ms[dom], "total_ms": total,
+            "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}

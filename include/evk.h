@@ -150,6 +150,19 @@ int evk_variance_f32(const float *img, int64_t n, double *out, void *scratch, in
 int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_t n, double *out, void *scratch,
                           int64_t scratch_bytes, void *stream);
 
+/* Fused objective post-pass (one launch + a 1-block finalise; the blurred images are never materialised):
+ * evaluate_function (objectives.py:231-236): out as evk_variance_f32 but of gaussian_filter(iwe) (host_weights /
+ * radius as in evk_gaussian_filter_f32; radius < 0 = no blur).  Bit-identical to the unfused sequence. */
+int evk_objective_variance_f32(const float *iwe, int h, int w, const double *host_weights, int radius, double *out,
+                               void *scratch, int64_t scratch_bytes, void *stream);
+
+#define EVK_POST_MIX 1u      /* scipy's 3-D filter of the (2, H, W) dIWE also mixes the two channels (quirk Q4) */
+#define EVK_POST_BLUR_IWE 2u /* use the blurred IWE in the gradient (reference_exact=False); default raw (Q5)    */
+/* evaluate_gradient (objectives.py:252-264): out as evk_variance_grad_f32 with diwe replaced by its blurred version. */
+int evk_objective_variance_grad_f32(const float *iwe, const float *diwe, int h, int w, const double *host_weights,
+                                    int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes,
+                                    void *stream);
+
 int64_t evk_reduce_scratch_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -166,12 +179,18 @@ int64_t evk_reduce_scratch_bytes(void);
 int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_log2);
 int64_t evk_bucket_scratch_bytes(int ntiles);
 
+#define EVK_STAGE_HIST 1    /* per-block tile histograms (reads x, y)                                            */
+#define EVK_STAGE_SCAN 2    /* prefix sums -> bucket_start                                                       */
+#define EVK_STAGE_SCATTER 4 /* write-combining scatter into records (reads x, y, t, p; needs stages 1|2 done)    */
+#define EVK_STAGE_ALL 7
+
 /* Counting sort of the SoA columns by tile: records = n x (x, y, t, p) float4 (16 B, contiguous per tile, time order
  * preserved across the 256 partition blocks), bucket_start = ntiles+1 uint32 offsets into records.
- * Columns and records must be 16-byte aligned (EVK_EALIGN otherwise); n < 2^32. */
+ * Columns and records must be 16-byte aligned (EVK_EALIGN otherwise); n < 2^32.  `stages` = EVK_STAGE_ALL normally;
+ * the stages can be launched one by one (same arguments, same scratch) to time them separately. */
 int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int key_mode,
                           int dom_h, int dom_w, int tw_log2, int th_log2, float *records, uint32_t *bucket_start,
-                          void *scratch, int64_t scratch_bytes, uint32_t *oob, void *stream);
+                          void *scratch, int64_t scratch_bytes, uint32_t *oob, int stages, void *stream);
 
 /* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image): one workgroup per tile, LDS
  * accumulators (B x tile), exclusive plain-store flush (vox += tile).  Same per-event arithmetic as evk_voxel_f32. */

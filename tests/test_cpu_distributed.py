@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the event-sharded N>1 path -- shard bounds, agreement on the global time range, one
+all-reduce of the partial grids -- with the oracle standing in for the per-shard kernels (no GPU here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import reference_np as R
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_local(xs, ys, ts, ps, B, sensor_size, t_first, t_last):
+    if len(xs) == 0:
+        return torch.zeros((B,) + tuple(sensor_size))
+    v = R.events_to_voxel_torch(np.asarray(xs), np.asarray(ys), np.asarray(ts), np.asarray(ps), B,
+                                sensor_size=sensor_size, accum="f64", t_range=(t_first, t_last))
+    return torch.from_numpy(v)
+
+
+def _worker(rank, world, port, n, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from event_utils_amd import distributed as DD
+    H, W, B = 24, 32, 5
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    lo, hi = DD.shard_bounds(n, rank, world)
+    assert DD.is_distributed()
+    tr = DD.global_time_range(t[lo] if hi > lo else np.inf, t[hi - 1] if hi > lo else -np.inf)
+    assert tr == (float(t[0]), float(t[-1]))
+    vox = DD.events_to_voxel_torch_sharded(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi], B, (H, W), local_fn=_oracle_local)
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    err = np.abs(vox.numpy().astype(np.float64) - ref).max()
+    # objective: every rank warps to the GLOBAL t_ref and all-reduces IWE+dIWE (here with the oracle as local kernel)
+    obj = R.variance_objective()
+    iwe_full, d_full = R.get_iwe(np.array([30., -20.]), *(a.astype(np.float64) for a in (x, y, t, p)), R.linvel_warp(),
+                                 (H, W), compute_gradient=True, sensor_size=(H, W), accum="f64")
+
+    class shard_warp(R.linvel_warp):           # warp a shard to the global reference time
+        def warp(self, xs, ys, ts, ps, t0, params, compute_grad=False):
+            return super().warp(xs, ys, ts, ps, float(t[-1]), params, compute_grad)
+    iwe, d = R.get_iwe(np.array([30., -20.]), *(a[lo:hi].astype(np.float64) for a in (x, y, t, p)), shard_warp(),
+                       (H, W), compute_gradient=True, sensor_size=(H, W), accum="f64")
+    buf = torch.from_numpy(np.concatenate([iwe[None], d]))
+    DD.all_reduce_sum_(buf)
+    err2 = np.abs(buf.numpy() - np.concatenate([iwe_full[None], d_full])).max()
+    np.save(os.path.join(out_dir, "err%d.npy" % rank), np.array([err, np.abs(ref).max(), err2, np.abs(d_full).max()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 3])
+def test_event_sharded_voxel_and_iwe_world2_gloo(tmp_path, n):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        err, scale, err2, scale2 = np.load(tmp_path / ("err%d.npy" % r))
+        assert err <= 1e-5 * scale and err2 <= 1e-5 * scale2
+
+
+def test_shard_bounds_partition():
+    from event_utils_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_a_noop():
+    from event_utils_amd import distributed as DD
+    assert not DD.is_distributed()
+    t = torch.ones(3)
+    assert DD.all_reduce_sum_(t) is t and DD.global_time_range(0.1, 0.9) == (0.1, 0.9)
