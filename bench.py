@@ -85,12 +85,13 @@ def main():
     else:
         t_first, t_last = float(t[0]), float(t[-1])
 
-    out = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     impl = args.impl or tiled.default_impl()
 
     def step():
-        out.zero_()
-        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=out, check=False, impl=impl)
+        # one complete voxelisation into `out`: bucketing + tile kernel (which writes every cell: no memset) on the
+        # tiled path, memset + global-atomic kernel on the direct path
+        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True)
         if world > 1:
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
 
@@ -123,8 +124,10 @@ def main():
     alg_bytes = 16.0 * n + out.numel() * 4.0
     dom_ms = kinfo["dominant_ms"]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(kinfo["dominant"], n)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kinfo["dominant"],
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kinfo["dominant"],
                 "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": alg_bytes,
                 "whole_call_ms": round(kinfo["total_ms"], 4),
                 "whole_call_frac": round(alg_bytes / (kinfo["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -152,31 +155,111 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_cmax(E, DeviceEvents, dev, impl):
-    """configs[2] shape: 10 M events, 640x480, linear-flow warp + IWE + variance (and + analytic gradient)."""
-    n = N_PER_GPU
-    x, y, t, p = synth(2, n, 0.0, 0.1, real_xy=True)
-    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
-    obj, w = E.variance_objective(), E.linvel_warp()
-    obj.sensor_size = (H, W)
-    obj.impl = impl
-    prm = np.array([30.0, -20.0])
-    res = {"workload": "configs[2]: 10M events, 640x480, get_iwe(linvel)+blur+variance; params (30,-20) px/s"}
+def pmc_traffic(kernel, n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950 correction applied).  PMC counters
+    cannot be collected from inside the timed process, so this is the recorded measurement for the default workload
+    (10 M events); None for any other size or when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if n != N_PER_GPU or not os.path.isfile(path):
+        return None, None
+    try:
+        ks = json.load(open(path))["kernels"]
+        for name, v in ks.items():
+            if kernel.split("(")[0] in name:
+                return v["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, per launch)"
+    except Exception:
+        pass
+    return None, None
+
+
+def _time_evals(obj, w, ev, prm, size, reps=10):
+    res = {}
     for name, fn in (("f", obj.evaluate_function), ("grad", obj.evaluate_gradient)):
         for _ in range(2):
-            fn(prm, ev, None, None, None, w, (H, W), 1.0)
+            fn(prm, ev, None, None, None, w, size, 1.0)
         torch.cuda.synchronize()
-        reps = 10
         t0 = time.perf_counter()
         for _ in range(reps):
-            fn(prm, ev, None, None, None, w, (H, W), 1.0)
+            fn(prm, ev, None, None, None, w, size, 1.0)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        n = len(ev)
         res[name + "_evals_per_s"] = round(1.0 / dt, 2)
         res[name + "_ms"] = round(dt * 1e3, 4)
         res[name + "_Mevents_per_s"] = round(n / dt / 1e6, 1)
         res[name + "_hbm_frac"] = round((16.0 * n) / dt / 1e9 / HBM_PEAK_GBS, 4)
     return res
+
+
+def structured_scene(seed, n, Hs, Ws, flow=(40.0, -25.0), t_hi=0.1):
+    """Moving vertical (+1) / horizontal (-1) edges: a scene whose contrast is maximised at `flow`."""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0.0, t_hi, n))
+    vert = rng.random(n) < 0.5
+    ex = rng.choice(np.arange(40, Ws - 40, 24), n) + rng.normal(0, 0.3, n)
+    ey = rng.choice(np.arange(40, Hs - 40, 24), n) + rng.normal(0, 0.3, n)
+    x0 = np.where(vert, ex, rng.uniform(30, Ws - 30, n))
+    y0 = np.where(vert, rng.uniform(30, Hs - 30, n), ey)
+    x = (x0 + (t - t[-1]) * flow[0]).astype(np.float32)
+    y = (y0 + (t - t[-1]) * flow[1]).astype(np.float32)
+    return x, y, t.astype(np.float32), np.where(vert, 1.0, -1.0).astype(np.float32)
+
+
+def bench_cmax(E, DeviceEvents, dev, impl):
+    """configs[2]: 10 M events, 640x480, warp + IWE + variance (and + analytic gradient) evaluations/s.
+    configs[3]: 50 M events, 1280x720: evaluations/s and a full optimize() loop (BFGS iterations/s)."""
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast
+    out = {}
+    x, y, t, p = synth(2, N_PER_GPU, 0.0, 0.1, real_xy=True)
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.sensor_size, obj.impl = (H, W), impl
+    c3 = {"workload": "configs[2]: 10M events, 640x480, get_iwe(linvel)+blur+variance; params (30,-20) px/s"}
+    c3.update(_time_evals(obj, w, ev, np.array([30.0, -20.0]), (H, W)))
+    out.update(c3)
+    del ev
+    # ---- configs[3]: 50 M events, 1280x720, full optimize() ----
+    H4, W4, n4 = 720, 1280, 50_000_000
+    x, y, t, p = structured_scene(3, n4, H4, W4)
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    obj = E.variance_objective()
+    obj.sensor_size, obj.impl = (H4, W4), impl
+    c4 = {"workload": "configs[3]: 50M events, 1280x720, moving-edge scene (true flow (40,-25) px/s)"}
+    c4.update(_time_evals(obj, w, ev, np.array([30.0, -20.0]), (H4, W4), reps=5))
+    for mode, numeric, exact in (("bfgs_numeric_grads(reference default)", True, True),
+                                 ("bfgs_analytic_consistent_grad", False, False)):
+        o = E.variance_objective()
+        o.sensor_size, o.impl, o.reference_exact = (H4, W4), impl, exact
+        cnt = {"f": 0, "g": 0, "it": 0}
+        f0, g0, it0 = o.evaluate_function, o.evaluate_gradient, o.iter_update
+
+        def fw(*a, **k):
+            cnt["f"] += 1
+            return f0(*a, **k)
+
+        def gw(*a, **k):
+            cnt["g"] += 1
+            return g0(*a, **k)
+
+        def iw(*a, **k):
+            cnt["it"] += 1
+            return it0(*a, **k)
+        o.evaluate_function, o.evaluate_gradient, o.iter_update = fw, gw, iw
+        import warnings
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            argmax = optimize_contrast(ev, None, None, None, w, o, numeric_grads=numeric, blur_sigma=1.0, img_size=(H4, W4))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        iters = max(cnt["it"] - 1, 1)      # the first iter_update is the explicit call before the optimiser
+        c4[mode] = {"argmax": [round(float(a), 3) for a in np.asarray(argmax, dtype=float)], "seconds": round(dt, 4),
+                    "bfgs_iters": iters, "f_evals": cnt["f"], "grad_evals": cnt["g"],
+                    "iters_per_s": round(iters / dt, 2), "evals_per_s": round((cnt["f"] + cnt["g"]) / dt, 2)}
+    out["c4"] = c4
+    return out
 
 
 def cpu_baseline(x, y, t, p):

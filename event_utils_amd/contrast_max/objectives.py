@@ -195,6 +195,27 @@ class objective_function(ABC):
             self.recompute_lifespan = False
         return ev.slice(int(self.s_idx), -1).scaled(100.0)
 
+    def _one_call(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, grad, post_flags):
+        """Whole evaluation in ONE library call (tiled.cmax_variance) -> 4 doubles on the host, or None when that
+        path does not apply (plugin warp, event-sharded run, direct-kernel fallback)."""
+        if getattr(warpfunc, "fused_kernel", None) != "linvel" or self.distributed or self.process_group is not None:
+            return None
+        ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
+        if len(ev) == 0:
+            return None
+        dev = ev.x.device
+        ss = (180, 240) if self.sensor_size is None else self.sensor_size
+        ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
+        flags = (0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if grad else 0)
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        w, radius = _blur_kernel(blur_sigma)
+        buf = tiled._buf("iwe_buf", (3 if grad else 1) * ch * cw * 4, dev)
+        out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+        ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
+                                 float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
+                                 impl=self.impl)
+        return out.cpu().numpy() if ok else None
+
     def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):
         fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
         if fused:
@@ -224,11 +245,14 @@ class variance_objective(objective_function):
                           blur_sigma=None, showimg=False, iwe=None):
         """-var(blur(iwe) - mean) over the whole padded image (objectives.py:211-236, Q6)."""
         dev = D.require_gpu()
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         if iwe is None:
+            res = self._one_call(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, False, 0)
+            if res is not None:
+                return np.float32(-res[1])
             iwe, _ = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, False)
         else:
             iwe = D.to_device(iwe, torch.float32, dev)
-        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         w, radius = _blur_kernel(blur_sigma)
         iwe = iwe.contiguous()
         out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
@@ -243,13 +267,16 @@ class variance_objective(objective_function):
         """-mean(2 (iwe-mean(iwe)) * blur(d_iwe)[i]) (objectives.py:238-264).  reference_exact keeps Q4 (3-D blur mixes
         the two channels) and Q5 (IWE is NOT blurred here)."""
         dev = D.require_gpu()
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        flags = 1 if self.reference_exact else 2       # EVK_POST_MIX (Q4) | EVK_POST_BLUR_IWE (consistent gradient)
         if iwe is None or d_iwe is None:
+            res = self._one_call(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, True, flags)
+            if res is not None:
+                return -(res[:2].astype(np.float32))
             iwe, d_iwe = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, True)
         else:
             iwe, d_iwe = D.to_device(iwe, torch.float32, dev), D.to_device(d_iwe, torch.float32, dev)
-        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         w, radius = _blur_kernel(blur_sigma)
-        flags = 1 if self.reference_exact else 2       # EVK_POST_MIX (Q4) | EVK_POST_BLUR_IWE (consistent gradient)
         if d_iwe.shape[0] != 2:
             raise ValueError("d_iwe must have 2 channels (the reference hard-codes 2, image.py:210)")
         iwe, d_iwe = iwe.contiguous(), d_iwe.contiguous()

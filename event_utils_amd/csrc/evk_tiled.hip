@@ -59,8 +59,7 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *_
     if (hi > n) hi = n;
     uint32_t dropped = 0;
     const int64_t nq = (hi > lo) ? ((hi - lo) >> 2) : 0;
-    for (int64_t q = threadIdx.x; q < nq; q += blockDim.x) {
-        const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q);
+    auto count4 = [&](const Vec4<float> &xv, const Vec4<float> &yv) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int key = tile_key(xv.v[k], yv.v[k], g, mode);
@@ -69,7 +68,15 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *_
             else
                 ++dropped;
         }
+    };
+    int64_t q = threadIdx.x;
+    for (; q + blockDim.x < nq; q += 2 * blockDim.x) {  // 4 independent 16-byte loads in flight per lane
+        const Vec4<float> xa = load4(x + lo, q), ya = load4(y + lo, q);
+        const Vec4<float> xb = load4(x + lo, q + blockDim.x), yb = load4(y + lo, q + blockDim.x);
+        count4(xa, ya);
+        count4(xb, yb);
     }
+    for (; q < nq; q += blockDim.x) count4(load4(x + lo, q), load4(y + lo, q));
     for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {  // ragged tail of the last block
         const int key = tile_key(x[i], y[i], g, mode);
         if (key >= 0)
@@ -208,13 +215,23 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const fl
         else
             rec[pos] = r;
     };
+    // software pipeline: the 4 column loads of phase ph+1 are issued before phase ph is placed and flushed, so HBM
+    // latency overlaps the LDS work and the two barriers of the flush
+    Vec4<float> xn, yn, tn, pn;
+    auto fetch = [&](int64_t ph) {
+        const int64_t q = ph * blockDim.x + threadIdx.x;
+        if (ph < nphase && q < nq && lo + (q << 2) + 4 <= hi) {
+            xn = load4(x + lo, q), yn = load4(y + lo, q), tn = load4(t + lo, q), pn = load4(p + lo, q);
+        }
+    };
+    fetch(0);
     for (int64_t ph = 0; ph <= nphase; ++ph) {
         const int64_t q = ph * blockDim.x + threadIdx.x;
+        const Vec4<float> xv = xn, yv = yn, tv = tn, pv = pn;
+        fetch(ph + 1);
         if (ph < nphase && q < nq) {
             const int64_t base = lo + (q << 2);
             if (base + 4 <= hi) {
-                const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q), tv = load4(t + lo, q),
-                                  pv = load4(p + lo, q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) place(xv.v[k], yv.v[k], tv.v[k], pv.v[k]);
             } else {
@@ -268,7 +285,7 @@ __device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, 
 
 __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec,
                                                            const uint32_t *__restrict__ bucket_start, TileGrid g,
-                                                           float t_first, float dt, float bm1, int B,
+                                                           float t_first, float dt, float bm1, int B, int overwrite,
                                                            float *__restrict__ vox) {
     extern __shared__ __attribute__((aligned(16))) acc_t acc[];
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
@@ -298,7 +315,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
         const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
         if (X < g.dom_w && Y < g.dom_h) {
             float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
-            *o += (float)acc[c];  // the tile is owned by this workgroup: plain read-modify-write, coalesced per row
+            // the tile is owned by this workgroup: plain, row-coalesced store (overwrite: the caller skipped the
+            // memset, every cell of every tile is written) or read-modify-write (accumulate into a default image)
+            *o = overwrite ? (float)acc[c] : *o + (float)acc[c];
         }
     }
 }
@@ -562,7 +581,8 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
 }
 
 extern "C" int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_start, int h, int wd, int tw_log2,
-                                   int th_log2, float t_first, float t_last, int B, float *vox, void *stream) {
+                                   int th_log2, float t_first, float t_last, int B, int overwrite, float *vox,
+                                   void *stream) {
     TileGrid g;
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_start || !vox)
         return EVK_EINVAL;
@@ -571,7 +591,7 @@ extern "C" int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_
     if (lds > 64 * 1024) return EVK_EINVAL;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
     k_voxel_tiled<<<ntiles, EVK_BLOCK, lds, (hipStream_t)stream>>>((const float4 *)records, bucket_start, g, t_first, dt,
-                                                                 bm1, B, vox);
+                                                                 bm1, B, overwrite, vox);
     return launch_status();
 }
 

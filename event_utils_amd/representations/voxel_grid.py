@@ -10,15 +10,17 @@ from .. import _device as D
 from .. import _lib
 
 
-def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None):
-    """Device-resident core of events_to_voxel_torch: accumulates into `out` (B, H, W) float32 (allocated if None)."""
+def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None, fresh=None):
+    """Device-resident core of events_to_voxel_torch.  out=None: a new (B, H, W) float32 grid is returned; else the
+    events are accumulated into `out` (fresh=True: `out` is overwritten instead, no memset needed)."""
     dev = xd.device
     H, W = int(sensor_size[0]), int(sensor_size[1])
     if out is None:
-        out = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+        out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        fresh = True
     oob = D.OobCounter(dev) if check else None
     from .. import tiled
-    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl)
+    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl, fresh=bool(fresh))
     if check:
         oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
     return out

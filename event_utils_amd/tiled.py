@@ -83,15 +83,18 @@ def voxel_tile_shape(H, W, B):
     return 3, 3
 
 
-def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None):
-    """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W)."""
+def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None, fresh=False):
+    """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W).  fresh=True: `out` is
+    uninitialised memory and is fully (over)written -- the tiled path then needs no memset at all."""
     impl = impl or default_impl()
     if can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
         _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th, t_first, t_last, B,
-                  D.ptr(out), D.stream())
+                  1 if fresh else 0, D.ptr(out), D.stream())
         return out
+    if fresh:
+        out.zero_()
     _lib.call("evk_voxel_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], t_first, t_last, B, H, W,
               D.ptr(out), oob.ptr if oob is not None else None, D.stream())
     return out
@@ -119,36 +122,62 @@ def _iwe_window(t_first, t_ref, vx, vy, tw, th, planes=3):
     return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(th + math.ceil(Dy / S) + 4)
 
 
+def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None):
+    """Launch plan of the tiled IWE kernel for DeviceEvents `ev` and this flow, or None when the direct kernel must be
+    used (float64 columns, unaligned views, too few events, a flow so large that the gather would test too many
+    windows).  Buckets the events on first use (cached on `ev`)."""
+    import math
+    impl = impl or default_impl()
+    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl) and math.isfinite(vx) and math.isfinite(vy)):
+        return None
+    dom_h = max(int(bounds_h) + 1, ch)
+    dom_w = max(int(bounds_w) + 1, cw)
+    tw, th = iwe_tile_shape(dom_h, dom_w)
+    t_first = ev.t_at(0)
+    planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
+    S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, 1 << th, planes)
+    # windows the gather kernel must test per pixel; huge flows (line-search overshoots) use the direct kernel
+    Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
+    cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
+    if S > 64 or cand > 128:
+        return None
+    key = (1, dom_h, dom_w, tw, th)
+    bk = ev._buckets.get(key)
+    if bk is None:
+        bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
+        ev._buckets[key] = bk
+    nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, S, planes, win_w, win_h))
+    staging = _buf("iwe_staging", nbytes, ev.x.device)
+    # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32
+    head = (D.ptr(bk.records), D.ptr(bk.bucket_start), dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref, vx, vy,
+            bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale))
+    return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk}
+
+
 def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, impl=None):
     """Fused get_iwe for the linear-flow model on DeviceEvents `ev`, accumulating into iwe (ch, cw) / diwe (2, ch, cw)."""
-    import math
     import torch
-    impl = impl or default_impl()
-    if can_tile((ev.x, ev.y, ev.t, ev.p), impl) and math.isfinite(vx) and math.isfinite(vy):
-        dom_h = max(int(bounds_h) + 1, ch)
-        dom_w = max(int(bounds_w) + 1, cw)
-        tw, th = iwe_tile_shape(dom_h, dom_w)
-        t_first = ev.t_at(0)
-        planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
-        S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, 1 << th, planes)
-        # windows the gather kernel must test per pixel; huge flows (line-search overshoots) use the direct kernel
-        Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
-        cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
-        if S <= 64 and cand <= 128:
-            key = (1, dom_h, dom_w, tw, th)
-            bk = ev._buckets.get(key)
-            if bk is None:
-                bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
-                ev._buckets[key] = bk
-            nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, S, planes, win_w, win_h))
-            staging = _buf("iwe_staging", nbytes, ev.x.device)
-            _lib.call("evk_iwe_linvel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), dom_h, dom_w, tw, th, S,
-                      win_w, win_h, t_first, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale),
-                      D.ptr(staging), nbytes, D.ptr(iwe), D.ptr(diwe), D.stream())
-            return
+    plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
+    if plan is not None:
+        _lib.call("evk_iwe_linvel_tiled_f32", *plan["head"], D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(iwe),
+                  D.ptr(diwe), D.stream())
+        return
     fn = "evk_iwe_linvel_f32" if ev.dtype == torch.float32 else "evk_iwe_linvel_f64"
     _lib.call(fn, D.ptr(ev.x), D.ptr(ev.y), D.ptr(ev.t), D.ptr(ev.p), len(ev), t_ref, vx, vy, bounds_w, bounds_h, ch, cw,
               flags, float(ev.p_scale), D.ptr(iwe), D.ptr(diwe), D.stream())
+
+
+def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights, radius, post_flags, buf, out, scratch,
+                  scratch_bytes, impl=None):
+    """One-call objective evaluation (evk_cmax_variance_tiled_f32) into `out` (4 doubles); returns False when the
+    tiled plan is not applicable (the caller then composes the direct kernels)."""
+    plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
+    if plan is None:
+        return False
+    _lib.call("evk_cmax_variance_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
+              post_flags, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
+              scratch_bytes, D.stream())
+    return True
 
 
 def _time_ms(fn, reps):
@@ -177,7 +206,8 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
         return {"impl": "direct", "dominant": "k_voxel_f32", "dominant_ms": ms, "total_ms": ms,
                 "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
     tw, th = voxel_tile_shape(H, W, B)
-    total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled"), reps)
+    total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True),
+                     reps)
     bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)
     ms = {}
     run = lambda st: bucket_events(xd, yd, td, pd, 0, H, W, tw, th, stages=st, into=bk)
@@ -188,7 +218,8 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
     run(7)
     ms["k_tile_scatter_wc"] = _time_ms(lambda: run(4), reps)
     ms["k_voxel_tiled"] = _time_ms(lambda: _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start),
-                                                     H, W, tw, th, t_first, t_last, B, D.ptr(out), D.stream()), reps)
+                                                     H, W, tw, th, t_first, t_last, B, 1, D.ptr(out), D.stream()),
+                                  reps)
     dom = max(ms, key=ms.get)
     return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom, "dominant_ms": ms[dom], "total_ms": total,
             "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}

@@ -193,9 +193,10 @@ int evk_bucket_events_f32(const float *x, const float *y, const float *t, const 
                           void *scratch, int64_t scratch_bytes, uint32_t *oob, int stages, void *stream);
 
 /* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image): one workgroup per tile, LDS
- * accumulators (B x tile), exclusive plain-store flush (vox += tile).  Same per-event arithmetic as evk_voxel_f32. */
+ * accumulators (B x tile), exclusive plain-store flush: vox += tile, or vox = tile when `overwrite` (the caller then
+ * needs no memset: every cell is written).  Same per-event arithmetic as evk_voxel_f32. */
 int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_start, int h, int wd, int tw_log2, int th_log2,
-                        float t_first, float t_last, int B, float *vox, void *stream);
+                        float t_first, float t_last, int B, int overwrite, float *vox, void *stream);
 
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
  * one workgroup per (tile, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted by
@@ -209,6 +210,17 @@ int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start,
                              double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w, uint32_t flags,
                              double p_scale, void *staging, int64_t staging_bytes, float *iwe, float *diwe,
                              void *stream);
+
+/* variance_objective.evaluate_function / evaluate_gradient (objectives.py:211-264) in ONE call on bucketed records:
+ * memset(iwe_buf) -> evk_iwe_linvel_tiled_f32 -> evk_objective_variance[_grad]_f32.  iwe_buf is (1, ch, cw) or, with
+ * EVK_IWE_GRADIENT, (3, ch, cw) float32 = IWE followed by the two dIWE planes (left filled, un-blurred).
+ * out: as evk_objective_variance_f32 / evk_objective_variance_grad_f32. */
+int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w, int tw_log2,
+                                int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
+                                double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                                uint32_t iwe_flags, double p_scale, const double *host_weights, int radius,
+                                uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf, double *out,
+                                void *scratch, int64_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }
