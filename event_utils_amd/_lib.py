@@ -34,13 +34,13 @@ SIGNATURES = {
     "evk_variance_grad_f32": [P, P, c_int64, P, P, c_int64, P],
     "evk_objective_variance_f32": [P, c_int, c_int, P, c_int, P, P, c_int64, P],
     "evk_objective_variance_grad_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
-    "evk_cmax_variance_tiled_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
+    "evk_cmax_variance_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, P, c_int, c_uint32,
                                     P, c_int64, P, P, P, c_int64, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
     "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P],
-    "evk_voxel_tiled_f32": [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P],
-    "evk_iwe_linvel_tiled_f32": [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
+    "evk_voxel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, c_int64, P],
+    "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, P, c_int64, P, P, P],
 }
 _SPECIAL = {
@@ -48,7 +48,10 @@ _SPECIAL = {
     "evk_error_string": ([c_int], c_char_p),
     "evk_reduce_scratch_bytes": ([], c_int64),
     "evk_bucket_scratch_bytes": ([c_int], c_int64),
-    "evk_iwe_tiled_staging_bytes": ([c_int, c_int, c_int, c_int, c_int], c_int64),
+    "evk_iwe_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int, c_int], c_int64),
+    "evk_voxel_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
+    "evk_bucket_index_len": ([c_int, c_int64], c_int64),
+    "evk_bucket_max_items": ([c_int, c_int64], c_int),
 }
 
 

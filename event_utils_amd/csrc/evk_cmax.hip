@@ -3,7 +3,7 @@
 // for the interpreter between the kernels of one evaluation.
 #include "evk_common.h"
 
-extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w,
+extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_start, int64_t n, int dom_h, int dom_w,
                                            int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
                                            double t_ref, double vx, double vy, double bounds_w, double bounds_h,
                                            int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale,
@@ -16,7 +16,7 @@ extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t 
     hipError_t e = hipMemsetAsync(iwe_buf, 0, (grad ? 3 : 1) * plane * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     float *diwe = grad ? iwe_buf + plane : nullptr;
-    int rc = evk_iwe_linvel_tiled_f32(records, bucket_start, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h,
+    int rc = evk_iwe_linvel_tiled_f32(records, bucket_start, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h,
                                       t_first, t_ref, vx, vy, bounds_w, bounds_h, canvas_h, canvas_w, iwe_flags, p_scale,
                                       staging, staging_bytes, iwe_buf, diwe, stream);
     if (rc != EVK_OK) return rc;

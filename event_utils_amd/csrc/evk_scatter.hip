@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_image_nearest_f32(const float *__
             // mask multiplies the INDICES only; the weight survives (image.py:93-95)
             const bool keep = !(xf >= clipx) && !(yf >= clipy);
             long long xi = keep ? (long long)xf : 0, yi = keep ? (long long)yf : 0;  // .long(): toward zero
-            if (wrap_index(xi, wd) && wrap_index(yi, h))
+            if (xf == xf && yf == yf && wrap_index(xi, wd) && wrap_index(yi, h))
                 atomic_add(img + yi * wd + xi, wv.v[k]);
             else
                 count_oob(oob);
@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_f32(const float *__restrict
         for (int k = 0; k < 4; ++k) {
             if (k >= cnt) break;
             long long xi = (long long)xv.v[k], yi = (long long)yv.v[k];
-            if (!(wrap_index(xi, wd) && wrap_index(yi, h))) {
+            // NaN.long() is INT64_MIN in torch (IndexError); the hardware conversion gives 0, so reject it explicitly
+            if (xv.v[k] != xv.v[k] || yv.v[k] != yv.v[k] || !(wrap_index(xi, wd) && wrap_index(yi, h))) {
                 count_oob(oob);
                 continue;
             }

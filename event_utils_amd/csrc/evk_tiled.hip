@@ -26,12 +26,14 @@ struct TileGrid {
 __device__ __forceinline__ int tile_key(float x, float y, const TileGrid &g, int mode) {
     int xi, yi;
     if (mode == EVK_KEY_NEAREST) {
-        long long xl = (long long)x, yl = (long long)y;
-        if (xl < 0) xl += g.dom_w;
-        if (yl < 0) yl += g.dom_h;
-        if (xl < 0 || xl >= g.dom_w || yl < 0 || yl >= g.dom_h) return -1;
-        xi = (int)xl;
-        yi = (int)yl;
+        // .long() truncation; a single saturating v_cvt_i32_f32 is enough: anything beyond int32 is out of the domain
+        // either way (NaN would convert to 0, so it is rejected explicitly: torch gives INT64_MIN -> IndexError)
+        if (x != x || y != y) return -1;
+        xi = (int)x;
+        yi = (int)y;
+        if (xi < 0) xi += g.dom_w;
+        if (yi < 0) yi += g.dom_h;
+        if (xi < 0 || xi >= g.dom_w || yi < 0 || yi >= g.dom_h) return -1;
     } else {
         const float fx = floorf(x), fy = floorf(y);
         xi = fx > 0.0f ? (fx < (float)(g.dom_w - 1) ? (int)fx : g.dom_w - 1) : 0;  // NaN -> 0
@@ -111,28 +113,64 @@ __global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__
     if (lane == 63) totals[tile] = incl;
 }
 
-// bucket_start[0..ntiles] = exclusive scan of totals (single block).
+// Bucket index (uint32), written by k_tile_scan_totals, read by the tile kernels:
+//   [0 .. T]        bucket_start : record offsets of the tiles (exclusive scan of the tile totals)
+//   [T+1 .. 2T+1]   part_start   : work-item offsets; tile k owns items part_start[k] .. part_start[k+1]-1 =
+//                                  max(1, ceil(count_k / cap)) parts -- a tile hotter than `cap` events is split over
+//                                  several workgroups so that clustered (real) event data cannot serialise on one CU
+//   [2T+2 .. 3T+1]  counters     : per-tile arrival counters of the split-tile combine (self-resetting)
+//   [3T+2 ..]       item_tile    : tile of every work item
+__host__ __device__ inline int64_t bucket_cap(int64_t n, int ntiles) {
+    const int64_t c = 4 * (n / (ntiles > 0 ? ntiles : 1));
+    return c > 32768 ? c : 32768;  // uniform data is never split; at most ntiles/4 extra items
+}
+__host__ __device__ inline int bucket_max_items(int64_t n, int ntiles) {
+    return ntiles + (int)(n / bucket_cap(n, ntiles)) + 1;
+}
+#define IDX_PART(T) ((T) + 1)
+#define IDX_COUNTER(T) (2 * (T) + 2)
+#define IDX_ITEM(T) (3 * (T) + 2)
+
 __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__restrict__ totals, int ntiles,
-                                                           uint32_t *__restrict__ bucket_start) {
+                                                           uint32_t cap, uint32_t *__restrict__ index) {
     __shared__ uint32_t part[1024];
+    uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *counters = index + IDX_COUNTER(ntiles),
+             *item_tile = index + IDX_ITEM(ntiles);
     const int per = (ntiles + 1023) / 1024;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
-    uint32_t s = 0;
-    for (int i = i0; i < i1; ++i) s += totals[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    auto block_exclusive = [&](uint32_t mine) -> uint32_t {  // Hillis-Steele; returns the exclusive prefix
+        part[threadIdx.x] = mine;
         __syncthreads();
-        part[threadIdx.x] += v;
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t ex = part[threadIdx.x] - mine;
         __syncthreads();
+        return ex;
+    };
+    uint32_t s = 0, np = 0;
+    for (int i = i0; i < i1; ++i) {
+        s += totals[i];
+        np += totals[i] > cap ? (totals[i] + cap - 1) / cap : 1u;
     }
-    uint32_t run = part[threadIdx.x] - s;
+    uint32_t run = block_exclusive(s);
     for (int i = i0; i < i1; ++i) {
         bucket_start[i] = run;
         run += totals[i];
     }
-    if (threadIdx.x == 1023) bucket_start[ntiles] = part[1023];
+    if (threadIdx.x == 1023) bucket_start[ntiles] = run;
+    uint32_t prun = block_exclusive(np);
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t parts = totals[i] > cap ? (totals[i] + cap - 1) / cap : 1u;
+        part_start[i] = prun;
+        counters[i] = 0;
+        for (uint32_t j = 0; j < parts; ++j) item_tile[prun + j] = (uint32_t)i;
+        prun += parts;
+    }
+    if (threadIdx.x == 1023) part_start[ntiles] = prun;
 }
 
 // Scatter: LDS cursors start at bucket_start[tile] + (this block's exclusive prefix); an LDS returning atomic hands
@@ -283,22 +321,29 @@ __device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, 
     }
 }
 
-__global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec,
-                                                           const uint32_t *__restrict__ bucket_start, TileGrid g,
-                                                           float t_first, float dt, float bm1, int B, int overwrite,
-                                                           float *__restrict__ vox) {
+__global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec, uint32_t *__restrict__ index,
+                                                           TileGrid g, float t_first, float dt, float bm1, int B,
+                                                           int overwrite, float *__restrict__ vox,
+                                                           float *__restrict__ staging) {
     extern __shared__ __attribute__((aligned(16))) acc_t acc[];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *item_tile = index + IDX_ITEM(ntiles);
+    if (blockIdx.x >= part_start[ntiles]) return;  // the grid is the host's upper bound on the work items
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
-    const int tile = blockIdx.x;
+    const int tile = (int)item_tile[blockIdx.x];
+    const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
+    const uint32_t part_id = blockIdx.x - first_item;
     const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
     for (int i = threadIdx.x; i < B * tpix; i += EVK_BLOCK) acc[i] = 0.0;
     __syncthreads();
-    const uint32_t lo = bucket_start[tile], hi = bucket_start[tile + 1];
+    const uint32_t blo = bucket_start[tile], cnt = bucket_start[tile + 1] - blo;
+    const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * part_id) / nparts);
+    const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (part_id + 1)) / nparts);
     auto one = [&](const float4 &r) {
-        long long xl = (long long)r.x, yl = (long long)r.y;
-        if (xl < 0) xl += g.dom_w;
-        if (yl < 0) yl += g.dom_h;
-        const int local = (((int)yl - ty0) << g.tw_log2) + ((int)xl - tx0);
+        int xi = (int)r.x, yi = (int)r.y;  // same conversion as tile_key (the record is known to be in this tile)
+        if (xi < 0) xi += g.dom_w;
+        if (yi < 0) yi += g.dom_h;
+        const int local = ((yi - ty0) << g.tw_log2) + (xi - tx0);
         const float tn = (r.z - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
         voxel_bins_lds(acc, tpix, local, B, tn, r.w);
     };
@@ -310,16 +355,51 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
     for (; i < hi; i += EVK_BLOCK) one(rec[i]);
     __syncthreads();
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
-    for (int c = threadIdx.x; c < B * tpix; c += EVK_BLOCK) {
-        const int b = c / tpix, l = c - b * tpix;
-        const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
-        if (X < g.dom_w && Y < g.dom_h) {
-            float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
-            // the tile is owned by this workgroup: plain, row-coalesced store (overwrite: the caller skipped the
-            // memset, every cell of every tile is written) or read-modify-write (accumulate into a default image)
-            *o = overwrite ? (float)acc[c] : *o + (float)acc[c];
+    auto flush = [&](auto value_of) {
+        for (int c = threadIdx.x; c < B * tpix; c += EVK_BLOCK) {
+            const int b = c / tpix, l = c - b * tpix;
+            const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
+            if (X < g.dom_w && Y < g.dom_h) {
+                float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
+                // the tile is owned by this workgroup: plain, row-coalesced store (overwrite: the caller skipped
+                // the memset, every cell of every tile is written) or read-modify-write (accumulate)
+                const float v = value_of(c);
+                *o = overwrite ? v : *o + v;
+            }
+        }
+    };
+    if (nparts == 1) {
+        flush([&](int c) { return (float)acc[c]; });
+        return;
+    }
+    // Split (hot) tile: every part stores its partial tile, the LAST part to arrive sums them in part order
+    // (deterministic) and writes the output.  Hand-off per cdna_hip_programming.md G16: drained plain stores ->
+    // barrier -> one-lane agent release -> counter; last arriver: one-lane agent acquire -> barrier -> plain loads.
+    const int cells = B * tpix;
+    float *mine = staging + (int64_t)blockIdx.x * cells;
+    for (int c = threadIdx.x; c < cells; c += EVK_BLOCK) mine[c] = (float)acc[c];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t *counter = index + IDX_COUNTER(ntiles) + tile;
+        const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == nparts - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
         }
     }
+    __syncthreads();
+    if (!is_last) return;
+    const float *parts = staging + (int64_t)first_item * cells;
+    flush([&](int c) {
+        float sum = 0.0f;
+        for (uint32_t p = 0; p < nparts; ++p) sum += parts[(int64_t)p * cells + c];
+        return sum;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -358,18 +438,25 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
 
 template <bool GRAD>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
-                                                         const uint32_t *__restrict__ bucket_start, TileGrid g,
+                                                         const uint32_t *__restrict__ index, TileGrid g,
                                                          IweParams q, float *__restrict__ staging,
                                                          int4 *__restrict__ origins, float *__restrict__ iwe,
                                                          float *__restrict__ diwe) {
     extern __shared__ __attribute__((aligned(16))) acc_t win[];
     const int wcells = q.win_w * q.win_h;
     constexpr int PLANES = GRAD ? 3 : 1;
-    const int tile = blockIdx.x / q.slices, s = blockIdx.x - tile * q.slices;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *item_tile = index + IDX_ITEM(ntiles);
+    // work item = one part of a tile (hot tiles are split); each item is cut into q.slices time slices
+    const uint32_t item = blockIdx.x / q.slices, sl = blockIdx.x - item * q.slices;
+    if (item >= part_start[ntiles]) return;
+    const int tile = (int)item_tile[item];
+    const uint32_t nparts = part_start[tile + 1] - part_start[tile], part_id = item - part_start[tile];
+    const uint32_t nsub = nparts * q.slices, sub = part_id * q.slices + sl;
     const uint32_t blo = bucket_start[tile], bhi = bucket_start[tile + 1];
     const uint32_t cnt = bhi - blo;
-    const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * s) / q.slices);
-    const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (s + 1)) / q.slices);
+    const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * sub) / nsub);
+    const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (sub + 1)) / nsub);
     for (int i = threadIdx.x; i < PLANES * wcells; i += EVK_BLOCK) win[i] = 0.0;
     // Window origin from the time span of this slice (records are time-ordered up to intra-block interleaving; an
     // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
@@ -453,13 +540,15 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
 // most max_shift, can reach the pixel) and ADDS the sum to the image (which already holds the rare direct atomics).
 template <bool GRAD>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restrict__ staging,
-                                                          const int4 *__restrict__ origins, TileGrid g, int slices,
+                                                          const int4 *__restrict__ origins,
+                                                          const uint32_t *__restrict__ index, TileGrid g, int slices,
                                                           int win_w, int win_h, int ch, int cw, int sx_lo, int sx_hi,
                                                           int sy_lo, int sy_hi, float *__restrict__ iwe,
                                                           float *__restrict__ diwe) {
     constexpr int PLANES = GRAD ? 3 : 1;
     const int wcells = win_w * win_h;
     const int64_t plane = (int64_t)ch * cw;
+    const uint32_t *part_start = index + IDX_PART(g.tiles_x * g.tiles_y);
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < plane;
          pix += (int64_t)gridDim.x * blockDim.x) {
         const int X = (int)(pix % cw), Y = (int)(pix / cw);
@@ -473,8 +562,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
             for (int tx = tx_a; tx <= tx_b; ++tx) {
                 if (tx < 0 || tx >= g.tiles_x) continue;
                 const int tile = ty * g.tiles_x + tx;
-                for (int s = 0; s < slices; ++s) {
-                    const int w = tile * slices + s;
+                const int w0 = (int)part_start[tile] * slices, w1 = (int)part_start[tile + 1] * slices;
+                for (int w = w0; w < w1; ++w) {
                     const int4 o = origins[w];
                     if (!o.z) continue;
                     const int lx = X - o.x, ly = Y - o.y;
@@ -520,6 +609,13 @@ extern "C" int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_lo
     return nt <= EVK_MAX_TILES ? nt : EVK_EINVAL;
 }
 
+extern "C" int64_t evk_bucket_index_len(int ntiles, int64_t n) {
+    if (ntiles <= 0 || n < 0) return 0;
+    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items(n, ntiles);
+}
+
+extern "C" int evk_bucket_max_items(int ntiles, int64_t n) { return ntiles > 0 && n >= 0 ? bucket_max_items(n, ntiles) : 0; }
+
 extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
     if (ntiles <= 0) return 0;
     return ((int64_t)EVK_BUCKET_BLOCKS * ntiles + ntiles) * (int64_t)sizeof(uint32_t);
@@ -547,7 +643,7 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
         k_tile_hist<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, n, chunk, g, key_mode, ntiles, table, oob);
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
-        k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, bucket_start);
+        k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles), bucket_start);
     }
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
@@ -580,26 +676,33 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     return launch_status();
 }
 
-extern "C" int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_start, int h, int wd, int tw_log2,
+extern "C" int64_t evk_voxel_tiled_staging_bytes(int ntiles, int64_t n, int B, int tw_log2, int th_log2) {
+    return (int64_t)bucket_max_items(n, ntiles) * ((int64_t)B << (tw_log2 + th_log2)) * (int64_t)sizeof(float);
+}
+
+extern "C" int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n, int h, int wd, int tw_log2,
                                    int th_log2, float t_first, float t_last, int B, int overwrite, float *vox,
-                                   void *stream) {
+                                   void *staging, int64_t staging_bytes, void *stream) {
     TileGrid g;
-    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_start || !vox)
+    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_index || !vox || !staging ||
+        n < 0)
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     const size_t lds = (size_t)B * sizeof(acc_t) << (tw_log2 + th_log2);
     if (lds > 64 * 1024) return EVK_EINVAL;
+    if (staging_bytes < evk_voxel_tiled_staging_bytes(ntiles, n, B, tw_log2, th_log2)) return EVK_ESCRATCH;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
-    k_voxel_tiled<<<ntiles, EVK_BLOCK, lds, (hipStream_t)stream>>>((const float4 *)records, bucket_start, g, t_first, dt,
-                                                                 bm1, B, overwrite, vox);
+    k_voxel_tiled<<<bucket_max_items(n, ntiles), EVK_BLOCK, lds, (hipStream_t)stream>>>(
+        (const float4 *)records, bucket_index, g, t_first, dt, bm1, B, overwrite, vox, (float *)staging);
     return launch_status();
 }
 
-extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int slices, int planes, int win_w, int win_h) {
-    return (int64_t)ntiles * slices * ((int64_t)planes * win_w * win_h * sizeof(float) + sizeof(int4));
+extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h) {
+    return (int64_t)bucket_max_items(n, ntiles) * slices *
+           ((int64_t)planes * win_w * win_h * (int64_t)sizeof(float) + (int64_t)sizeof(int4));
 }
 
-extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w,
+extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start, int64_t n, int dom_h, int dom_w,
                                         int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
                                         double t_ref, double vx, double vy, double bounds_w, double bounds_h, int canvas_h,
                                         int canvas_w, uint32_t flags, double p_scale, void *staging,
@@ -615,7 +718,7 @@ extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bu
     const size_t lds = (size_t)planes * win_w * win_h * sizeof(acc_t);
     if (lds > 64 * 1024) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
-    if (staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, slices, planes, win_w, win_h)) return EVK_ESCRATCH;
+    if (n < 0 || staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, n, slices, planes, win_w, win_h)) return EVK_ESCRATCH;
     IweParams q;
     q.t_ref = t_ref, q.vx = vx, q.vy = vy, q.bw = bounds_w, q.bh = bounds_h, q.p_scale = p_scale;
     q.clipx = (float)(canvas_w - 1), q.clipy = (float)(canvas_h - 1);
@@ -626,18 +729,18 @@ extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bu
     if (!(fabs(Dx) < 1e6 && fabs(Dy) < 1e6)) return EVK_EINVAL;
     q.sx_lo = (int)floor(fmin(0.0, Dx)) - 1, q.sx_hi = (int)floor(fmax(0.0, Dx)) - 1;
     q.sy_lo = (int)floor(fmin(0.0, Dy)) - 1, q.sy_hi = (int)floor(fmax(0.0, Dy)) - 1;
-    const int nwin = ntiles * slices;
+    const int nwin = bucket_max_items(n, ntiles) * slices;
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;
     const int ggrid = stream_grid((int64_t)canvas_h * canvas_w);
     if (grad) {
         k_iwe_tiled<true><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
-        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
+        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_start, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
                                                        q.sy_lo, q.sy_hi, iwe, diwe);
     } else {
         k_iwe_tiled<false><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
-        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
+        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_start, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
                                                        q.sy_lo, q.sy_hi, iwe, diwe);
     }
     return launch_status();

@@ -30,8 +30,8 @@ def _buf(key, nbytes, device):
 class Buckets:
     """Events partitioned by tile: `records` (n_kept, 4) float32 (x, y, t, p), `bucket_start` (ntiles+1) offsets."""
 
-    def __init__(self, records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles):
-        self.records, self.bucket_start = records, bucket_start
+    def __init__(self, records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n):
+        self.records, self.bucket_start, self.n = records, bucket_start, n   # bucket_start = the whole bucket index
         self.key_mode, self.dom_h, self.dom_w = key_mode, dom_h, dom_w
         self.tw_log2, self.th_log2, self.ntiles = tw_log2, th_log2, ntiles
 
@@ -61,13 +61,13 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
         records, bucket_start = into.records, into.bucket_start
     else:
         records = torch.empty((n, 4), dtype=torch.float32, device=dev)
-        bucket_start = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
+        bucket_start = torch.empty(int(L.evk_bucket_index_len(ntiles, n)), dtype=torch.int32, device=dev)
     nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
     scratch = _buf("bucket", nbytes, dev)
     _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, key_mode, dom_h, dom_w, tw_log2,
               th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
               oob.ptr if oob is not None else None, stages, D.stream())
-    return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles)
+    return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n)
 
 
 def voxel_tile_shape(H, W, B):
@@ -83,6 +83,14 @@ def voxel_tile_shape(H, W, B):
     return 3, 3
 
 
+def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh):
+    """evk_voxel_tiled_f32 on bucketed events `bk` (staging for the parts of split hot tiles is persistent scratch)."""
+    nbytes = int(_lib.lib().evk_voxel_tiled_staging_bytes(bk.ntiles, bk.n, B, bk.tw_log2, bk.th_log2))
+    staging = _buf("voxel_staging", nbytes, out.device)
+    _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, H, W, bk.tw_log2, bk.th_log2,
+              t_first, t_last, B, 1 if fresh else 0, D.ptr(out), D.ptr(staging), nbytes, D.stream())
+
+
 def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None, fresh=False):
     """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W).  fresh=True: `out` is
     uninitialised memory and is fully (over)written -- the tiled path then needs no memset at all."""
@@ -90,8 +98,7 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     if can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
-        _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), H, W, tw, th, t_first, t_last, B,
-                  1 if fresh else 0, D.ptr(out), D.stream())
+        voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh)
         return out
     if fresh:
         out.zero_()
@@ -146,10 +153,10 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None):
     if bk is None:
         bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
         ev._buckets[key] = bk
-    nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, S, planes, win_w, win_h))
+    nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, bk.n, S, planes, win_w, win_h))
     staging = _buf("iwe_staging", nbytes, ev.x.device)
     # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32
-    head = (D.ptr(bk.records), D.ptr(bk.bucket_start), dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref, vx, vy,
+    head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref, vx, vy,
             bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale))
     return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk}
 
@@ -217,9 +224,7 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
     ms["k_tile_scan_blocks+k_tile_scan_totals"] = max(_time_ms(lambda: run(3), reps) - ms["k_tile_hist"], 0.0)
     run(7)
     ms["k_tile_scatter_wc"] = _time_ms(lambda: run(4), reps)
-    ms["k_voxel_tiled"] = _time_ms(lambda: _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start),
-                                                     H, W, tw, th, t_first, t_last, B, 1, D.ptr(out), D.stream()),
-                                  reps)
+    ms["k_voxel_tiled"] = _time_ms(lambda: voxel_tiled(bk, t_first, t_last, B, H, W, out, True), reps)
     dom = max(ms, key=ms.get)
     return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom, "dominant_ms": ms[dom], "total_ms": total,
             "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}

@@ -178,45 +178,54 @@ int64_t evk_reduce_scratch_bytes(void);
 /* number of tiles of a (dom_h, dom_w) domain cut into 2^th_log2 x 2^tw_log2 tiles; <0 if unsupported (> 8192). */
 int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_log2);
 int64_t evk_bucket_scratch_bytes(int ntiles);
+/* length (uint32 entries) of the bucket index for n events: tile offsets (ntiles+1), work-item offsets (ntiles+1),
+ * per-tile arrival counters (ntiles) and the item -> tile map (evk_bucket_max_items entries).  A tile holding more than
+ * max(32768, 4n/ntiles) events is split into several work items, so clustered event data cannot serialise on one CU. */
+int64_t evk_bucket_index_len(int ntiles, int64_t n);
+int evk_bucket_max_items(int ntiles, int64_t n);
 
 #define EVK_STAGE_HIST 1    /* per-block tile histograms (reads x, y)                                            */
-#define EVK_STAGE_SCAN 2    /* prefix sums -> bucket_start                                                       */
+#define EVK_STAGE_SCAN 2    /* prefix sums -> bucket index                                                       */
 #define EVK_STAGE_SCATTER 4 /* write-combining scatter into records (reads x, y, t, p; needs stages 1|2 done)    */
 #define EVK_STAGE_ALL 7
 
 /* Counting sort of the SoA columns by tile: records = n x (x, y, t, p) float4 (16 B, contiguous per tile, time order
- * preserved across the 256 partition blocks), bucket_start = ntiles+1 uint32 offsets into records.
+ * preserved across the 256 partition blocks), bucket_index = evk_bucket_index_len(ntiles, n) uint32 (see above).
  * Columns and records must be 16-byte aligned (EVK_EALIGN otherwise); n < 2^32.  `stages` = EVK_STAGE_ALL normally;
  * the stages can be launched one by one (same arguments, same scratch) to time them separately. */
 int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int key_mode,
-                          int dom_h, int dom_w, int tw_log2, int th_log2, float *records, uint32_t *bucket_start,
+                          int dom_h, int dom_w, int tw_log2, int th_log2, float *records, uint32_t *bucket_index,
                           void *scratch, int64_t scratch_bytes, uint32_t *oob, int stages, void *stream);
 
-/* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image): one workgroup per tile, LDS
- * accumulators (B x tile), exclusive plain-store flush: vox += tile, or vox = tile when `overwrite` (the caller then
- * needs no memset: every cell is written).  Same per-event arithmetic as evk_voxel_f32. */
-int evk_voxel_tiled_f32(const float *records, const uint32_t *bucket_start, int h, int wd, int tw_log2, int th_log2,
-                        float t_first, float t_last, int B, int overwrite, float *vox, void *stream);
+/* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image; n = the event count that was
+ * bucketed): one workgroup per work item, LDS accumulators (B x tile, float64), exclusive plain-store flush: vox += tile,
+ * or vox = tile when `overwrite` (the caller then needs no memset: every cell is written).  The parts of a split tile
+ * meet in `staging` (evk_voxel_tiled_staging_bytes) and the last one to arrive sums them in part order.
+ * Same per-event arithmetic as evk_voxel_f32. */
+int64_t evk_voxel_tiled_staging_bytes(int ntiles, int64_t n, int B, int tw_log2, int th_log2);
+int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n, int h, int wd, int tw_log2, int th_log2,
+                        float t_first, float t_last, int B, int overwrite, float *vox, void *staging,
+                        int64_t staging_bytes, void *stream);
 
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
- * one workgroup per (tile, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted by
- * the slice's displacement), stores it to `staging`; a gather kernel adds the windows covering each canvas pixel to
+ * one workgroup per (work item, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted
+ * by the slice's displacement), stores it to `staging`; a gather kernel adds the windows covering each canvas pixel to
  * iwe / diwe.  Events falling outside their window use a global atomic (correct for any flow; slices / win_* only
  * tune speed).  t_first = earliest event time (bounds the window shifts).  Same per-event arithmetic as
  * evk_iwe_linvel_f32. */
-int64_t evk_iwe_tiled_staging_bytes(int ntiles, int slices, int planes, int win_w, int win_h);
-int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w, int tw_log2,
-                             int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
-                             double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w, uint32_t flags,
-                             double p_scale, void *staging, int64_t staging_bytes, float *iwe, float *diwe,
-                             void *stream);
+int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h);
+int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                             int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
+                             double vx, double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                             uint32_t flags, double p_scale, void *staging, int64_t staging_bytes, float *iwe,
+                             float *diwe, void *stream);
 
 /* variance_objective.evaluate_function / evaluate_gradient (objectives.py:211-264) in ONE call on bucketed records:
  * memset(iwe_buf) -> evk_iwe_linvel_tiled_f32 -> evk_objective_variance[_grad]_f32.  iwe_buf is (1, ch, cw) or, with
  * EVK_IWE_GRADIENT, (3, ch, cw) float32 = IWE followed by the two dIWE planes (left filled, un-blurred).
  * out: as evk_objective_variance_f32 / evk_objective_variance_grad_f32. */
-int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_start, int dom_h, int dom_w, int tw_log2,
-                                int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
+int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                                int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
                                 double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
                                 uint32_t iwe_flags, double p_scale, const double *host_weights, int radius,
                                 uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf, double *out,

@@ -49,7 +49,7 @@ def test_bucketing_is_a_permutation(E):
     x, y, t, p = _events(3, n, H, W)
     xd, yd, td, pd = (torch.from_numpy(a).cuda() for a in (x, y, t, p))
     bk = tiled.bucket_events(xd, yd, td, pd, 0, H, W, 4, 3)
-    rec = bk.records.cpu().numpy(); bs = bk.bucket_start.cpu().numpy().astype(np.int64)
+    rec = bk.records.cpu().numpy(); bs = bk.bucket_start.cpu().numpy().astype(np.int64)[:bk.ntiles + 1]
     assert bs[0] == 0 and bs[-1] == n and np.all(np.diff(bs) >= 0)
     tiles_x = -(-W // 16)
     key = (rec[:, 1].astype(np.int64) >> 3) * tiles_x + (rec[:, 0].astype(np.int64) >> 4)
@@ -155,3 +155,46 @@ def test_objective_tiled_matches_golden_and_lifespan(E, golden):
     al.iter_update(np.array([400., -250.]))
     f = al.evaluate_function(np.array([40., -25.]), ev, None, None, None, w, (180, 240), blur_sigma=1.0)
     assert abs(f - g["al_f"]) <= TOL * abs(g["al_f"])
+
+
+@pytest.mark.parametrize("shape", [(48, 64, 5, 400_000), (480, 640, 5, 3_000_000)])
+def test_voxel_hot_tiles_are_split_and_combined(E, shape):
+    """Clustered events (as real event data are): most events in a few pixels -> their tiles exceed the per-item cap,
+    are split over several workgroups and recombined by the last-arriving part.  Repeated calls check that the arrival
+    counters reset themselves; accumulate mode (out pre-filled) and overwrite mode are both covered."""
+    from event_utils_amd import tiled
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    H, W, B, n = shape
+    x, y, t, p = _events(77, n, H, W)
+    rng = np.random.default_rng(5)
+    hot = rng.random(n) < 0.7
+    x[hot] = (W // 2 + rng.integers(0, 3, hot.sum())).astype(np.float32)
+    y[hot] = (H // 3 + rng.integers(0, 2, hot.sum())).astype(np.float32)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    tw, th = tiled.voxel_tile_shape(H, W, B)
+    bk = tiled.bucket_events(*cols, 0, H, W, tw, th)
+    idx = bk.bucket_start.cpu().numpy()
+    part_start = idx[bk.ntiles + 1: 2 * bk.ntiles + 2]
+    assert part_start[-1] > bk.ntiles, "the hot tile should have been split"
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    for _ in range(3):
+        v = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+        close(v.cpu().numpy(), ref)
+    base = torch.full((B, H, W), 2.5, device="cuda")
+    _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), out=base)
+    close(base.cpu().numpy() - 2.5, ref, 1e-4)
+    assert np.all(bk.bucket_start.cpu().numpy()[2 * bk.ntiles + 2: 3 * bk.ntiles + 2] == 0)
+
+
+def test_iwe_hot_tiles(E):
+    H, W, n = 180, 240, 500_000
+    x, y, t, p = _events(31, n, H, W, real=True)
+    rng = np.random.default_rng(6)
+    hot = rng.random(n) < 0.8
+    x[hot] = (100 + 4 * rng.random(hot.sum())).astype(np.float32)
+    y[hot] = (60 + 4 * rng.random(hot.sum())).astype(np.float32)
+    for prm in (np.array([30., -20.]), np.array([-400., 250.])):
+        ri, rd = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), compute_gradient=True,
+                           sensor_size=(H, W), accum="f64")
+        iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W))
+        close(iwe, ri); close(diwe, rd)
