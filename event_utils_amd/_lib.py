@@ -5,7 +5,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libevk.so")
+LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk.so")   # EVK_LIB_PATH: A/B builds
 
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2

@@ -45,8 +45,12 @@ __device__ __forceinline__ int tile_key(float x, float y, const TileGrid &g, int
 // ---------------------------------------------------------------------------------------------------------
 // bucketing: histogram -> scan -> scatter
 // ---------------------------------------------------------------------------------------------------------
+#ifndef EVK_BUCKET_THREADS
 #define EVK_BUCKET_THREADS 1024
+#endif
+#ifndef EVK_BUCKET_BLOCKS
 #define EVK_BUCKET_BLOCKS 256  // one 1024-thread workgroup per CU; table is [tile][EVK_BUCKET_BLOCKS]
+#endif
 
 // Block b owns the contiguous event range [b*chunk, (b+1)*chunk) (chunk % 4 == 0); table[b][tile] = its count.
 __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *__restrict__ x,
@@ -95,21 +99,35 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *_
 // One wavefront per tile: lane l owns blocks 4l..4l+3 (one 16-byte load), wave-wide scan by shuffles.
 __global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__ table, int ntiles,
                                                           uint32_t *__restrict__ totals) {
-    static_assert(EVK_BUCKET_BLOCKS == 256, "lane l owns 4 blocks");
+    static_assert(EVK_BUCKET_BLOCKS % 256 == 0, "lane l owns EVK_BUCKET_BLOCKS / 64 consecutive blocks");
+    constexpr int PER = EVK_BUCKET_BLOCKS / 64;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
-    uint4 *row = reinterpret_cast<uint4 *>(table + (int64_t)tile * EVK_BUCKET_BLOCKS);
-    const uint4 c = row[lane];
-    const uint32_t sum = c.x + c.y + c.z + c.w;
+    uint32_t *row = table + (int64_t)tile * EVK_BUCKET_BLOCKS + lane * PER;
+    uint32_t c[PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + k);
+        c[k] = v.x, c[k + 1] = v.y, c[k + 2] = v.z, c[k + 3] = v.w;
+        sum += v.x + v.y + v.z + v.w;
+    }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = __shfl_up(incl, off, 64);
         if (lane >= off) incl += v;
     }
-    const uint32_t base = incl - sum;
-    row[lane] = make_uint4(base, base + c.x, base + c.x + c.y, base + c.x + c.y + c.z);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t v = c[k];
+        c[k] = run;
+        run += v;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) *reinterpret_cast<uint4 *>(row + k) = make_uint4(c[k], c[k + 1], c[k + 2], c[k + 3]);
     if (lane == 63) totals[tile] = incl;
 }
 
@@ -648,7 +666,7 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
     static const int variant = getenv("EVK_SCATTER") ? atoi(getenv("EVK_SCATTER")) : -1;  // tuning: 0 plain, 4/8/16
-    const size_t lds_budget = 160 * 1024 - 256;
+    const size_t lds_budget = (160 * 1024) / (EVK_BUCKET_BLOCKS / 256) - 256;  // all partition blocks co-resident
     int R = 0;
     for (int r : {16, 8, 4})
         if (!R && (size_t)ntiles * (r * 16 + 8) <= lds_budget) R = r;
