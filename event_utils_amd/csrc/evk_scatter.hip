@@ -305,6 +305,33 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_f64(const int32_t *__restri
     });
 }
 
+// Windowed voxelisation (voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch, voxel_grid.py:37-112): S consecutive
+// event ranges [seg[s], seg[s+1]) -> S independent voxel grids in ONE launch.  blockIdx.y = window; each window
+// normalises time with ITS first / last event exactly as the per-window reference call does (voxel_grid.py:133-134).
+__global__ void __launch_bounds__(EVK_BLOCK) k_voxel_segments_f32(const float *__restrict__ x,
+                                                                  const float *__restrict__ y,
+                                                                  const float *__restrict__ t,
+                                                                  const float *__restrict__ p,
+                                                                  const int64_t *__restrict__ seg, int B, int h, int wd,
+                                                                  float *__restrict__ vox, uint32_t *oob) {
+    const int s = blockIdx.y;
+    const int64_t lo = seg[s], hi = seg[s + 1];
+    if (hi <= lo) return;
+    const float t_first = t[lo], dt = t[hi - 1] - t_first, bm1 = (float)(B - 1);
+    const int64_t plane = (int64_t)h * wd;
+    float *out = vox + (int64_t)s * B * plane;
+    for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+        const float xf = x[i], yf = y[i];
+        long long xi = (long long)xf, yi = (long long)yf;
+        if (xf != xf || yf != yf || !(wrap_index(xi, wd) && wrap_index(yi, h))) {
+            count_oob(oob);
+            continue;
+        }
+        const float tn = (t[i] - t_first) / dt * bm1;
+        voxel_bins<float>(out, plane, yi * wd + xi, B, tn, p[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // warp / mask (elementwise, float64) and the fused linear-flow IWE
 // ---------------------------------------------------------------------------------------------------------
@@ -544,6 +571,19 @@ extern "C" int evk_voxel_f64(const int32_t *x, const int32_t *y, const double *t
     else
         k_voxel_f64<false><<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, n, t_first, dt, bm1, B, h,
                                                                               wd, vox, oob);
+    return launch_status();
+}
+
+extern "C" int evk_voxel_segments_f32(const float *x, const float *y, const float *t, const float *p,
+                                      const int64_t *seg, int nseg, int64_t max_seg_len, int B, int h, int wd,
+                                      float *vox, uint32_t *oob, void *stream) {
+    if (nseg < 0 || B <= 0 || h <= 0 || wd <= 0 || !vox || (nseg > 0 && (!x || !y || !t || !p || !seg))) return EVK_EINVAL;
+    if (nseg == 0 || max_seg_len <= 0) return EVK_OK;
+    if (nseg > 65535) return EVK_EINVAL;
+    int bx = stream_grid(max_seg_len);
+    const int cap = (EVK_NUM_CU * 8 + nseg - 1) / nseg;   // keep the whole grid around 8 blocks per CU
+    if (bx > cap) bx = cap < 1 ? 1 : cap;
+    k_voxel_segments_f32<<<dim3(bx, nseg), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, seg, B, h, wd, vox, oob);
     return launch_status();
 }
 

@@ -96,13 +96,40 @@ def events_to_neg_pos_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_
     return voxel_pos, voxel_neg
 
 
+def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
+    """All windows [bounds[k], bounds[k+1]) of the stream in ONE launch (evk_voxel_segments_f32) -> list of (B, H, W)
+    float32 tensors on xs.device (views of one (S, B, H, W) allocation)."""
+    device = xs.device
+    if ts.dtype == torch.float64 or ps.dtype == torch.float64:
+        raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
+                           "destination and Double for the source.")
+    nseg = len(bounds) - 1
+    if nseg <= 0:
+        return []
+    dev = D.require_gpu()
+    H, W = int(sensor_size[0]), int(sensor_size[1])
+    xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
+    td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
+    seg = torch.as_tensor(np.asarray(bounds, dtype=np.int64), device=dev)
+    out = torch.zeros((nseg, B, H, W), dtype=torch.float32, device=dev)
+    oob = D.OobCounter(dev)
+    max_len = int(np.max(np.diff(np.asarray(bounds, dtype=np.int64))))
+    _lib.call("evk_voxel_segments_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), D.ptr(seg), nseg, max_len, B, H, W,
+              D.ptr(out), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+    out = out.to(device)
+    return [out[k] for k in range(nseg)]
+
+
 def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temporal_bilinear=True):
-    """One voxel grid per n consecutive events (reference: voxel_grid.py:37-57)."""
-    voxels = []
-    for idx in range(0, len(xs) - n, n):
-        voxels.append(events_to_voxel_torch(xs[idx:idx + n], ys[idx:idx + n], ts[idx:idx + n], ps[idx:idx + n], B,
-                                            sensor_size=sensor_size, temporal_bilinear=temporal_bilinear))
-    return voxels
+    """One voxel grid per n consecutive events (reference: voxel_grid.py:37-57; note its range(0, len-n, n) drops the
+    last full window when len is a multiple of n -- kept).  All windows are built in one kernel launch."""
+    if not temporal_bilinear:
+        raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:144-147)")
+    starts = list(range(0, len(xs) - n, n))
+    if not starts:
+        return []
+    return _voxel_windows(xs, ys, ts, ps, B, starts + [starts[-1] + n], sensor_size)
 
 
 def events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t0, t1, device=None, np_ts=None, sensor_size=(180, 240),
@@ -122,10 +149,19 @@ def events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t0, t1, device=None, np_ts
 
 
 def voxel_grids_fixed_t_torch(xs, ys, ts, ps, B, t, sensor_size=(180, 240), temporal_bilinear=True):
-    """One voxel grid per time window of width t (reference: voxel_grid.py:59-80)."""
-    voxels = []
+    """One voxel grid per time window of width t (reference: voxel_grid.py:59-80 via events_to_voxel_timesync_torch
+    :82-112: window k = events with t_start_k <= ts < t_start_k + t, searchsorted on the host).  The windows are
+    consecutive, so all of them are built in one kernel launch."""
+    if not temporal_bilinear:
+        raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:144-147)")
     np_ts = ts.cpu().numpy()
-    for t_start in np.arange(ts[0].item(), ts[-1].item() - t, t):
-        voxels.append(events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t_start, t_start + t, np_ts=np_ts,
-                                                     sensor_size=sensor_size, temporal_bilinear=temporal_bilinear))
-    return voxels
+    t_starts = np.arange(ts[0].item(), ts[-1].item() - t, t)
+    if len(t_starts) == 0:
+        return []
+    lo = np.searchsorted(np_ts, t_starts)
+    hi = np.searchsorted(np_ts, t_starts + t)
+    assert np.all(lo < hi)                                  # voxel_grid.py:108
+    if np.array_equal(hi[:-1], lo[1:]):                     # contiguous windows: one launch
+        return _voxel_windows(xs, ys, ts, ps, B, list(lo) + [hi[-1]], sensor_size)
+    return [events_to_voxel_torch(xs[a:b], ys[a:b], ts[a:b], ps[a:b], B, sensor_size=sensor_size,
+                                  temporal_bilinear=temporal_bilinear) for a, b in zip(lo, hi)]

@@ -99,6 +99,14 @@ int evk_image_drv_f64(const double *x, const double *y, const double *p, const d
 int evk_voxel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first,
                   float t_last, int B, int h, int wd, float *vox, uint32_t *oob, void *stream);
 
+/* Windowed voxelisation: voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch (voxel_grid.py:37-80) call
+ * events_to_voxel_torch once per window; this builds all nseg grids in ONE launch.  seg = nseg+1 device int64 offsets
+ * (window s = events [seg[s], seg[s+1])), each window normalises time with its own first / last event
+ * (voxel_grid.py:133-134).  vox is (nseg, B, h, wd) float32, accumulated into.  max_seg_len sizes the grid. */
+int evk_voxel_segments_f32(const float *x, const float *y, const float *t, const float *p, const int64_t *seg,
+                           int nseg, int64_t max_seg_len, int B, int h, int wd, float *vox, uint32_t *oob,
+                           void *stream);
+
 /* events_to_voxel (voxel_grid.py:184-217), numpy path: integer coordinates on the (h+1, wd+1) canvas of
  * events_to_image (x == wd / y == h are legal and cropped away, image.py:17,44), float64 arithmetic and output. */
 int evk_voxel_f64(const int32_t *x, const int32_t *y, const double *t, const double *p, int64_t n, double t_first,
