@@ -80,9 +80,9 @@ def reduce_scratch(device):
     return _scratch[key]
 
 
-def out4(device):
-    """Persistent 4-double device result slot (objective evaluations return a few scalars)."""
-    key = (device.index, "out4")
+def out4(device, n=4):
+    """Persistent n-double device result slot (objective evaluations return a few scalars)."""
+    key = (device.index, "out%d" % n)
     if key not in _scratch:
-        _scratch[key] = torch.empty(4, dtype=torch.float64, device=device)
+        _scratch[key] = torch.empty(n, dtype=torch.float64, device=device)
     return _scratch[key]

@@ -27,12 +27,18 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
     elif x0 is None:
         x0 = np.array([0, 0])
     objective.iter_update(x0)
-    if getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function):
+    fused = getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function)
+    if fused:
         ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
         args = (ev, None, None, None, warp_function, img_size, blur_sigma)      # resident events, uploaded once
     else:
         args = (xs, ys, ts, ps, warp_function, img_size, blur_sigma)
-    if numeric_grads:
+    if numeric_grads and hasattr(objective, "evaluate_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
+        # same forward differences (epsilon = 1) scipy would take internally, but the three evaluations of one
+        # gradient estimate share a single pass over the events
+        argmax = optimizer(objective.evaluate_function, x0, fprime=objective.evaluate_numeric_gradient, args=args,
+                           disp=False, callback=objective.iter_update)
+    elif numeric_grads:
         argmax = optimizer(objective.evaluate_function, x0, args=args, epsilon=1, disp=False,
                            callback=objective.iter_update)
     else:

@@ -262,6 +262,45 @@ class variance_objective(objective_function):
         loss = out[1].item()
         return np.float32(-loss)
 
+    def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                                  blur_sigma=None, epsilon=1.0):
+        """Forward-difference gradient of evaluate_function with absolute step `epsilon` -- exactly what
+        scipy.optimize.fmin_bfgs(..., epsilon=1) estimates internally on the reference's default path
+        (events_cmax.py:343: x1 = x + eps*e_i, grad_i = (f(x1) - f(x)) / (x1_i - x_i)) -- but f(x), f(x + eps e1),
+        f(x + eps e2) are evaluated in ONE pass over the events.  Falls back to three separate
+        evaluations when the batched kernel does not apply."""
+        x0 = np.asarray(params, dtype=np.float64)
+        pts = [x0.copy()]
+        for i in range(len(x0)):
+            x1 = x0.copy()
+            x1[i] = x0[i] + epsilon
+            pts.append(x1)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        fs = None
+        if (len(x0) == 2 and getattr(warpfunc, "fused_kernel", None) == "linvel" and not self.distributed
+                and self.process_group is None):
+            ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
+            if len(ev):
+                dev = ev.x.device
+                ss = (180, 240) if self.sensor_size is None else self.sensor_size
+                ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
+                flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
+                t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+                w, radius = _blur_kernel(blur_sigma)
+                buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
+                out, (scratch, nbytes) = D.out4(dev, 12), D.reduce_scratch(dev)
+                if tiled.cmax_variance_batch3(ev, float(t_ref), [float(q[0]) for q in pts], [float(q[1]) for q in pts],
+                                              float(img_size[1]), float(img_size[0]), ch, cw, flags, w, radius, buf,
+                                              out, scratch, nbytes, impl=self.impl):
+                    res = out.cpu().numpy().reshape(3, 4)
+                    fs = [np.float32(-res[k, 1]) for k in range(3)]
+        if fs is None:
+            fs = [self.evaluate_function(q, xs, ys, ts, ps, warpfunc, img_size, blur_sigma) for q in pts]
+        grad = np.empty(len(x0), dtype=np.float64)
+        for i in range(len(x0)):
+            grad[i] = (np.float64(fs[i + 1]) - np.float64(fs[0])) / (pts[i + 1][i] - x0[i])
+        return grad
+
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
         """-mean(2 (iwe-mean(iwe)) * blur(d_iwe)[i]) (objectives.py:238-264).  reference_exact keeps Q4 (3-D blur mixes

@@ -95,6 +95,8 @@ template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
                                                             int64_t n, double *__restrict__ out) {
     double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
+    partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
+    out += 4 * blockIdx.x;
     for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
 #pragma unroll
         for (int k = 0; k < EVK_REDUCE_K; ++k) acc[k] += partials[(int64_t)b * EVK_REDUCE_K + k];
@@ -177,6 +179,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T;
     const int y0 = (blockIdx.x / tiles_x) * EVK_POST_T, x0 = (blockIdx.x % tiles_x) * EVK_POST_T;
     const int64_t plane = (int64_t)ch * cw;
+    iwe += blockIdx.y * plane;                                         // MODE 0 batched over image planes
+    partials += (int64_t)blockIdx.y * gridDim.x * EVK_REDUCE_K;
     double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
     if constexpr (MODE == 0) {
         float v[4];
@@ -281,22 +285,30 @@ extern "C" int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_
 
 template <int MODE>
 static int launch_post(const float *iwe, const float *diwe, int h, int w, const double *host_weights, int radius,
-                       uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream) {
-    if (!iwe || h <= 0 || w <= 0 || !out || !scratch || (MODE == 1 && !diwe)) return EVK_EINVAL;
+                       uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream,
+                       int nplanes = 1) {
+    if (!iwe || h <= 0 || w <= 0 || !out || !scratch || (MODE == 1 && !diwe) || nplanes < 1 || nplanes > 8)
+        return EVK_EINVAL;
     if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
-    if (radius < 0)  // blur_sigma <= 0: plain reductions
-        return launch_reduce<MODE>(iwe, diwe, (int64_t)h * w, out, scratch, scratch_bytes, stream);
+    if (radius < 0) {  // blur_sigma <= 0: plain reductions
+        for (int k = 0; k < nplanes; ++k) {
+            const int rc = launch_reduce<MODE>(iwe + (int64_t)k * h * w, diwe, (int64_t)h * w, out + 4 * k, scratch,
+                                               scratch_bytes, stream);
+            if (rc != EVK_OK) return rc;
+        }
+        return EVK_OK;
+    }
     if (!host_weights || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
     const int grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
-    if (grid > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
+    if (grid * nplanes > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
     BlurWeights bw;
     bw.radius = radius;
     for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
     const int PW = EVK_POST_T + 2 * radius;
     const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    k_post_fused<MODE><<<grid, EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, flags, (double *)scratch);
-    k_reduce_final<MODE><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out);
+    k_post_fused<MODE><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, flags, (double *)scratch);
+    k_reduce_final<MODE><<<nplanes, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out);
     return launch_status();
 }
 
@@ -309,4 +321,10 @@ extern "C" int evk_objective_variance_grad_f32(const float *iwe, const float *di
                                                const double *host_weights, int radius, uint32_t flags, double *out,
                                                void *scratch, int64_t scratch_bytes, void *stream) {
     return launch_post<1>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream);
+}
+
+extern "C" int evk_objective_variance_planes_f32(const float *imgs, int nplanes, int h, int w,
+                                                 const double *host_weights, int radius, double *out, void *scratch,
+                                                 int64_t scratch_bytes, void *stream) {
+    return launch_post<0>(imgs, nullptr, h, w, host_weights, radius, 0u, out, scratch, scratch_bytes, stream, nplanes);
 }

@@ -431,14 +431,15 @@ struct IweParams {
     int win_w, win_h;  // LDS / staging window capacity (cells)
     int abs_p, grad;
     int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
+    double vxb[2], vyb[2];           // MODE 2 (batch of 3 nearby flows): flows 1 and 2 (flow 0 is vx, vy)
 };
 
 // Same per-event arithmetic as evk_scatter.hip's iwe_event (kept textually identical: parity depends on it).
-__device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &q, int &px, int &py, float &dx,
-                                              float &dy, float &mp, float &jf) {
+__device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &q, double vx, double vy, int &px,
+                                              int &py, float &dx, float &dy, float &mp, float &jf) {
     const double dt = (double)r.z - q.t_ref;
-    const double xw = (double)r.x - dt * q.vx;
-    const double yw = (double)r.y - dt * q.vy;
+    const double xw = (double)r.x - dt * vx;
+    const double yw = (double)r.y - dt * vy;
     if (xw <= 0.0 || xw > q.bw || yw <= 0.0 || yw > q.bh) return false;
     const double ps = (double)r.w * q.p_scale;
     const double pd = q.abs_p ? fabs(ps) : ps;
@@ -454,7 +455,9 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
     return true;
 }
 
-template <bool GRAD>
+// MODE 0: IWE.  MODE 1: IWE + dIWE (gradient).  MODE 2: three IWEs for three nearby flows in one pass over the events
+// (forward-difference numeric gradient: f(v), f(v + eps e1), f(v + eps e2) share every event load).
+template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
                                                          const uint32_t *__restrict__ index, TileGrid g,
                                                          IweParams q, float *__restrict__ staging,
@@ -462,7 +465,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                                                          float *__restrict__ diwe) {
     extern __shared__ __attribute__((aligned(16))) acc_t win[];
     const int wcells = q.win_w * q.win_h;
-    constexpr int PLANES = GRAD ? 3 : 1;
+    constexpr bool GRAD = (MODE == 1);
+    constexpr int PLANES = MODE == 0 ? 1 : 3;
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *item_tile = index + IDX_ITEM(ntiles);
     // work item = one part of a tile (hot tiles are split); each item is cut into q.slices time slices
@@ -481,9 +485,16 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     int wx0 = 0, wy0 = 0;
     if (hi > lo) {
         const double ta = (double)rec[lo].z - q.t_ref, tb = (double)rec[hi - 1].z - q.t_ref;
-        const double dxa = -ta * q.vx, dxb = -tb * q.vx, dya = -ta * q.vy, dyb = -tb * q.vy;
+        double dxm = fmin(-ta * q.vx, -tb * q.vx), dym = fmin(-ta * q.vy, -tb * q.vy);
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                dxm = fmin(dxm, fmin(-ta * q.vxb[k], -tb * q.vxb[k]));
+                dym = fmin(dym, fmin(-ta * q.vyb[k], -tb * q.vyb[k]));
+            }
+        }
         const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
-        int sx = (int)floor(fmin(dxa, dxb)) - 1, sy = (int)floor(fmin(dya, dyb)) - 1;
+        int sx = (int)floor(dxm) - 1, sy = (int)floor(dym) - 1;
         sx = sx < q.sx_lo ? q.sx_lo : (sx > q.sx_hi ? q.sx_hi : sx);  // the gather kernel relies on these bounds
         sy = sy < q.sy_lo ? q.sy_lo : (sy > q.sy_hi ? q.sy_hi : sy);
         wx0 = tx0 + sx;
@@ -491,15 +502,16 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     }
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
-    auto one = [&](const float4 &r) {
+    // one flow, one IWE plane (`wp` in LDS, `gp` in the image); GRAD adds the derivative planes behind it
+    auto splat = [&](const float4 &r, double vx, double vy, acc_t *wp, float *gp) {
         int px, py;
         float dx, dy, mp, jf;
-        if (!iwe_event_f32(r, q, px, py, dx, dy, mp, jf)) return;
+        if (!iwe_event_f32(r, q, vx, vy, px, py, dx, dy, mp, jf)) return;
         const float ax = 1.0f - dx, ay = 1.0f - dy;
         const int lx = px - wx0, ly = py - wy0;
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
-            acc_t *c = win + ly * q.win_w + lx;
+            acc_t *c = wp + ly * q.win_w + lx;
             lds_add(c, mp * ax * ay);
             lds_add(c + 1, mp * dx * ay);
             lds_add(c + q.win_w, mp * ax * dy);
@@ -516,7 +528,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                 lds_add(e1 + 1, a * dx);
             }
         } else {  // outside the window (flow larger than the halo, clamped outlier): straight to the image
-            float *c = iwe + (int64_t)py * q.cw + px;
+            float *c = gp + (int64_t)py * q.cw + px;
             atomic_add(c, mp * ax * ay);
             atomic_add(c + 1, mp * dx * ay);
             atomic_add(c + q.cw, mp * ax * dy);
@@ -534,6 +546,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             }
         }
     };
+    auto one = [&](const float4 &r) {
+        splat(r, q.vx, q.vy, win, iwe);
+        if constexpr (MODE == 2) {  // planes 1, 2 of the (3, ch, cw) buffer = diwe, diwe + plane
+            splat(r, q.vxb[0], q.vyb[0], win + wcells, diwe);
+            splat(r, q.vxb[1], q.vyb[1], win + 2 * wcells, diwe + plane);
+        }
+    };
     uint32_t i = lo + threadIdx.x;
     for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {
         const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
@@ -549,6 +568,10 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             const acc_t *e0 = win + wcells, *e1 = e0 + wcells;
             st[wcells + c] = (float)((lx > 0 ? e0[c - 1] : 0.0) - e0[c]);
             st[2 * wcells + c] = (float)((ly > 0 ? e1[c - q.win_w] : 0.0) - e1[c]);
+        }
+        if constexpr (MODE == 2) {
+            st[wcells + c] = (float)win[wcells + c];
+            st[2 * wcells + c] = (float)win[2 * wcells + c];
         }
     }
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
@@ -720,46 +743,75 @@ extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices
            ((int64_t)planes * win_w * win_h * (int64_t)sizeof(float) + (int64_t)sizeof(int4));
 }
 
-extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_start, int64_t n, int dom_h, int dom_w,
-                                        int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
-                                        double t_ref, double vx, double vy, double bounds_w, double bounds_h, int canvas_h,
-                                        int canvas_w, uint32_t flags, double p_scale, void *staging,
-                                        int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
+static int launch_iwe_tiled(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                            int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
+                            const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h,
+                            int canvas_w, uint32_t flags, double p_scale, void *staging, int64_t staging_bytes,
+                            float *iwe, float *diwe, void *stream) {
     TileGrid g;
-    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_start || !iwe || !staging)
+    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_index || !iwe || !staging)
         return EVK_EINVAL;
-    const bool grad = flags & EVK_IWE_GRADIENT;
-    if ((grad && !diwe) || slices < 1 || slices > 256 || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
+    const int planes = mode == 0 ? 1 : 3;
+    if ((planes == 3 && !diwe) || slices < 1 || slices > 256 || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
     const int tw = 1 << tw_log2, th = 1 << th_log2;
     if (win_w < tw + 3 || win_h < th + 3) return EVK_EINVAL;
-    const int planes = grad ? 3 : 1;
     const size_t lds = (size_t)planes * win_w * win_h * sizeof(acc_t);
     if (lds > 64 * 1024) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (n < 0 || staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, n, slices, planes, win_w, win_h)) return EVK_ESCRATCH;
     IweParams q;
-    q.t_ref = t_ref, q.vx = vx, q.vy = vy, q.bw = bounds_w, q.bh = bounds_h, q.p_scale = p_scale;
+    q.t_ref = t_ref, q.vx = vx[0], q.vy = vy[0], q.bw = bounds_w, q.bh = bounds_h, q.p_scale = p_scale;
     q.clipx = (float)(canvas_w - 1), q.clipy = (float)(canvas_h - 1);
     q.ch = canvas_h, q.cw = canvas_w, q.slices = slices, q.win_w = win_w, q.win_h = win_h;
-    q.abs_p = (flags & EVK_IWE_ABS_POLARITY) ? 1 : 0, q.grad = grad;
+    q.abs_p = (flags & EVK_IWE_ABS_POLARITY) ? 1 : 0, q.grad = (mode == 1);
+    const int nflow = mode == 2 ? 3 : 1;
+    for (int k = 0; k < 2; ++k) q.vxb[k] = mode == 2 ? vx[k + 1] : vx[0], q.vyb[k] = mode == 2 ? vy[k + 1] : vy[0];
     // displacement of an event at time t is -(t - t_ref) * v; over [t_first, t_ref] it spans [min(0, D), max(0, D)]
-    const double Dx = -(t_first - t_ref) * vx, Dy = -(t_first - t_ref) * vy;
-    if (!(fabs(Dx) < 1e6 && fabs(Dy) < 1e6)) return EVK_EINVAL;
-    q.sx_lo = (int)floor(fmin(0.0, Dx)) - 1, q.sx_hi = (int)floor(fmax(0.0, Dx)) - 1;
-    q.sy_lo = (int)floor(fmin(0.0, Dy)) - 1, q.sy_hi = (int)floor(fmax(0.0, Dy)) - 1;
+    double dx_lo = 0.0, dx_hi = 0.0, dy_lo = 0.0, dy_hi = 0.0;
+    for (int k = 0; k < nflow; ++k) {
+        const double Dx = -(t_first - t_ref) * vx[k], Dy = -(t_first - t_ref) * vy[k];
+        if (!(fabs(Dx) < 1e6 && fabs(Dy) < 1e6)) return EVK_EINVAL;
+        dx_lo = fmin(dx_lo, Dx), dx_hi = fmax(dx_hi, Dx), dy_lo = fmin(dy_lo, Dy), dy_hi = fmax(dy_hi, Dy);
+    }
+    q.sx_lo = (int)floor(dx_lo) - 1, q.sx_hi = (int)floor(dx_hi) - 1;
+    q.sy_lo = (int)floor(dy_lo) - 1, q.sy_hi = (int)floor(dy_hi) - 1;
     const int nwin = bucket_max_items(n, ntiles) * slices;
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;
     const int ggrid = stream_grid((int64_t)canvas_h * canvas_w);
-    if (grad) {
-        k_iwe_tiled<true><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
-        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_start, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
-                                                       q.sy_lo, q.sy_hi, iwe, diwe);
+    const float4 *rec = (const float4 *)records;
+    if (mode == 0) {
+        k_iwe_tiled<0><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
+        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
     } else {
-        k_iwe_tiled<false><<<nwin, EVK_BLOCK, lds, s>>>((const float4 *)records, bucket_start, g, q, st, origins, iwe, diwe);
-        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_start, g, slices, win_w, win_h, canvas_h, canvas_w, q.sx_lo, q.sx_hi,
-                                                       q.sy_lo, q.sy_hi, iwe, diwe);
+        if (mode == 1) k_iwe_tiled<1><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
+        else k_iwe_tiled<2><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
+        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+                                                      canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
     }
     return launch_status();
+}
+
+extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
+                                        int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
+                                        double t_first, double t_ref, double vx, double vy, double bounds_w,
+                                        double bounds_h, int canvas_h, int canvas_w, uint32_t flags, double p_scale,
+                                        void *staging, int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
+    return launch_iwe_tiled((flags & EVK_IWE_GRADIENT) ? 1 : 0, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2,
+                            slices, win_w, win_h, t_first, t_ref, &vx, &vy, bounds_w, bounds_h, canvas_h, canvas_w,
+                            flags, p_scale, staging, staging_bytes, iwe, diwe, stream);
+}
+
+extern "C" int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
+                                               int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
+                                               double t_first, double t_ref, const double *host_vx,
+                                               const double *host_vy, double bounds_w, double bounds_h, int canvas_h,
+                                               int canvas_w, uint32_t flags, double p_scale, void *staging,
+                                               int64_t staging_bytes, float *iwe3, void *stream) {
+    if (!host_vx || !host_vy || !iwe3 || (flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
+    return launch_iwe_tiled(2, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
+                            t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, staging,
+                            staging_bytes, iwe3, iwe3 + (size_t)canvas_h * canvas_w, stream);
 }

@@ -129,22 +129,27 @@ def _iwe_window(t_first, t_ref, vx, vy, tw, th, planes=3):
     return S, rnd(tw + math.ceil(Dx / S) + 4), rnd(th + math.ceil(Dy / S) + 4)
 
 
-def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None):
+def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, batch=None):
     """Launch plan of the tiled IWE kernel for DeviceEvents `ev` and this flow, or None when the direct kernel must be
     used (float64 columns, unaligned views, too few events, a flow so large that the gather would test too many
-    windows).  Buckets the events on first use (cached on `ev`)."""
+    windows).  Buckets the events on first use (cached on `ev`).  batch = (vxs, vys): three nearby flows evaluated in
+    one pass (the window is sized for their envelope; vx, vy are then ignored)."""
     import math
     impl = impl or default_impl()
-    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl) and math.isfinite(vx) and math.isfinite(vy)):
+    vxs, vys = ((vx,), (vy,)) if batch is None else batch
+    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl) and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
         return None
     dom_h = max(int(bounds_h) + 1, ch)
     dom_w = max(int(bounds_w) + 1, cw)
     tw, th = iwe_tile_shape(dom_h, dom_w)
     t_first = ev.t_at(0)
-    planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
-    S, win_w, win_h = _iwe_window(t_first, t_ref, vx, vy, 1 << tw, 1 << th, planes)
+    planes = 3 if (flags & _lib.EVK_IWE_GRADIENT or batch is not None) else 1
+    span = abs(t_first - t_ref)
+    # envelope of the displacements (+1 px when the flows of a batch differ, their windows are shared)
+    Dx = max(abs(v) for v in vxs) * span + (1.0 if batch is not None else 0.0)
+    Dy = max(abs(v) for v in vys) * span + (1.0 if batch is not None else 0.0)
+    S, win_w, win_h = _iwe_window(0.0, 1.0, Dx, Dy, 1 << tw, 1 << th, planes)
     # windows the gather kernel must test per pixel; huge flows (line-search overshoots) use the direct kernel
-    Dx, Dy = abs((t_first - t_ref) * vx), abs((t_first - t_ref) * vy)
     cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
     if S > 64 or cand > 128:
         return None
@@ -155,10 +160,18 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None):
         ev._buckets[key] = bk
     nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, bk.n, S, planes, win_w, win_h))
     staging = _buf("iwe_staging", nbytes, ev.x.device)
-    # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32
-    head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref, vx, vy,
-            bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale))
-    return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk}
+    # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32 (the batch entry points take
+    # two host arrays instead of the scalars vx, vy)
+    if batch is None:
+        flow = (vx, vy)
+        keep = None
+    else:
+        import numpy as np
+        keep = (np.ascontiguousarray(vxs, dtype=np.float64), np.ascontiguousarray(vys, dtype=np.float64))
+        flow = (D.host_ptr(keep[0]), D.host_ptr(keep[1]))
+    head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
+        flow + (bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale))
+    return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk, "keep": keep}
 
 
 def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, impl=None):
@@ -183,6 +196,19 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
         return False
     _lib.call("evk_cmax_variance_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
               post_flags, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
+              scratch_bytes, D.stream())
+    return True
+
+
+def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags, weights, radius, buf, out12, scratch,
+                         scratch_bytes, impl=None):
+    """f at three nearby flows in one pass over the events (evk_cmax_variance_batch3_tiled_f32) -> out12 (3 x 4
+    doubles); False when the tiled plan is not applicable."""
+    plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
+    if plan is None:
+        return False
+    _lib.call("evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None,
+              radius, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch),
               scratch_bytes, D.stream())
     return True
 

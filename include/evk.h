@@ -239,6 +239,29 @@ int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_ind
                                 uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf, double *out,
                                 void *scratch, int64_t scratch_bytes, void *stream);
 
+/* ---- batched evaluation: three NEARBY flows in one pass over the events ----------------
+ * The reference's default optimiser path (numeric_grads=True, events_cmax.py:343) lets scipy estimate the gradient by
+ * forward differences with epsilon = 1: f(v), f(v + e1), f(v + e2) = three full get_iwe passes.  These entry points
+ * read every event once and accumulate the three IWEs side by side (iwe3 = (3, ch, cw)); host_vx / host_vy are 3
+ * doubles each (host pointers).  The flows must be close (they share one LDS window per workgroup; an event outside it
+ * still lands through a global atomic, so distant flows are merely slower). */
+int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                                    int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
+                                    double t_ref, const double *host_vx, const double *host_vy, double bounds_w,
+                                    double bounds_h, int canvas_h, int canvas_w, uint32_t flags, double p_scale,
+                                    void *staging, int64_t staging_bytes, float *iwe3, void *stream);
+/* evk_objective_variance_f32 for nplanes stacked images: out = nplanes x 4 doubles. */
+int evk_objective_variance_planes_f32(const float *imgs, int nplanes, int h, int w, const double *host_weights,
+                                      int radius, double *out, void *scratch, int64_t scratch_bytes, void *stream);
+/* memset -> batch3 IWE -> gather -> fused blur + variance of each plane: out12 = 3 x 4 doubles. */
+int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
+                                       int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
+                                       double t_first, double t_ref, const double *host_vx, const double *host_vy,
+                                       double bounds_w, double bounds_h, int canvas_h, int canvas_w, uint32_t iwe_flags,
+                                       double p_scale, const double *host_weights, int radius, void *staging,
+                                       int64_t staging_bytes, float *iwe3, double *out12, void *scratch,
+                                       int64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

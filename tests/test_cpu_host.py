@@ -121,3 +121,29 @@ def test_f32_lossless_policy():
     assert _f32_lossless(np.array([0.5, 0.25, 3.0]))
     assert not _f32_lossless(np.array([0.1]))
     assert _f32_lossless(np.array([0.1], dtype=np.float32))
+
+
+def test_numeric_gradient_formula_equals_scipy_internal_forward_differences(golden):
+    """evaluate_numeric_gradient must reproduce what fmin_bfgs(..., epsilon=1) estimates internally (the reference's
+    default path, events_cmax.py:343).  No GPU: the product objective's evaluate_function is replaced by the oracle's."""
+    import warnings
+    import scipy.optimize as opt
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    g = golden("f8_objective")
+    x, y, t, p = (np.asarray(g[k], dtype=np.float64) for k in ("xs", "ys", "ts", "ps"))
+    robj, rw = R.variance_objective(), R.linvel_warp()
+    obj = E.variance_objective()
+    obj.evaluate_function = lambda prm, *a, **k: robj.evaluate_function(prm, x, y, t, p, rw, (180, 240), 1.0)
+    args = (None, None, None, None, object(), (180, 240), 1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = opt.fmin_bfgs(obj.evaluate_function, np.array([0, 0]), args=args, epsilon=1, disp=False)
+        b = opt.fmin_bfgs(obj.evaluate_function, np.array([0, 0]), fprime=obj.evaluate_numeric_gradient, args=args,
+                          disp=False)
+    assert np.allclose(a, g_numeric_argmax(golden), atol=1e-9)
+    assert np.allclose(a, b, atol=1e-9)
+
+
+def g_numeric_argmax(golden):
+    return golden("f9_optimize_trace")["numeric_argmax"]
