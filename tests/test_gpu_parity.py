@@ -380,6 +380,8 @@ def test_f9_optimize(E, golden, mode):
         trace.append(("g", np.array(prm, float), None, f64(v)))
         return v
     obj.evaluate_function, obj.evaluate_gradient = frec, grec
+    ng0, ngrads = obj.evaluate_numeric_gradient, []
+    obj.evaluate_numeric_gradient = lambda prm, *a, **k: (ngrads.append((np.array(prm, float), ng0(prm, *a, **k))), ngrads[-1][1])[1]
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -387,6 +389,15 @@ def test_f9_optimize(E, golden, mode):
     # first evaluations are pinned tightly (same params in, same values out); the rest of the BFGS trajectory
     # amplifies 1e-7-level summation-order noise, so the end point is compared loosely
     k = 0
+    if mode == "numeric":
+        # the reference's trace starts f(0,0), f(1,0), f(0,1) (scipy's internal forward differences, epsilon=1);
+        # here the three values come from ONE batched pass: f(0,0) and the first gradient estimate must agree
+        gf = g["numeric_f"]
+        assert np.allclose(g["numeric_params"][:3], [[0, 0], [1, 0], [0, 1]])
+        assert trace[0][0] == "f" and abs(trace[0][2] - gf[0]) <= TOL * abs(gf[0])
+        assert np.allclose(ngrads[0][0], [0, 0])
+        assert np.max(np.abs(ngrads[0][1] - np.array([gf[1] - gf[0], gf[2] - gf[0]]))) <= 2 * TOL * abs(gf[0])
+        trace = []
     for kind, prm, fv, gv in trace[:4]:
         assert kind == str(g[mode + "_kind"][k]) and np.allclose(prm, g[mode + "_params"][k], atol=1e-6)
         if kind == "f":
