@@ -85,18 +85,37 @@ def main():
     else:
         t_first, t_last = float(t[0]), float(t[-1])
 
-    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     impl = args.impl or tiled.default_impl()
+    # N > 1: the all-reduce of step i (RCCL, its own stream) overlaps the kernels of step i+1 (double-buffered grids);
+    # every grid is fully reduced before the clock stops.  EVK_BENCH_SYNC_ALLREDUCE=1 serialises them instead.
+    overlap = world > 1 and os.environ.get("EVK_BENCH_SYNC_ALLREDUCE", "0") != "1"
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2 if overlap else 1)]
+    works = [None] * len(outs)
+    out = outs[0]
 
-    def step():
-        # one complete voxelisation into `out`: bucketing + tile kernel (which writes every cell: no memset) on the
-        # tiled path, memset + global-atomic kernel on the direct path
-        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True)
+    def step(i):
+        # one complete voxelisation: bucketing + tile kernel (which writes every cell: no memset) on the tiled path,
+        # memset + global-atomic kernel on the direct path; then the grid is summed over the ranks
+        k = i % len(outs)
+        if works[k] is not None:
+            works[k].wait()          # stream-level: this buffer's previous all-reduce has finished
+            works[k] = None
+        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=outs[k], check=False, impl=impl, fresh=True)
         if world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+            if overlap:
+                works[k] = dist.all_reduce(outs[k], op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                dist.all_reduce(outs[k], op=dist.ReduceOp.SUM)
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for k, wk in enumerate(works):
+            if wk is not None:
+                wk.wait()
+                works[k] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -105,8 +124,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev0[i].record()
-        step()
+        step(i)
         ev1[i].record()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,7 +160,9 @@ def main():
         "config": {"workload": "configs[1]: 10M events/GPU, 640x480, events_to_voxel_torch 5 temporal bins "
                                "(temporal-bilinear, nearest pixel), uniform-random events, columns resident in HBM",
                    "events_per_gpu": n, "sensor": [H, W], "bins": B, "impl": kinfo["impl"],
-                   "parallelism": "event-sharded x%d, all-reduce of the (B,H,W) grid" % world if world > 1 else "single GPU"},
+                   "parallelism": ("event-sharded x%d, RCCL all-reduce of the (B,H,W) grid per step%s"
+                                   % (world, ", overlapped with the next step's kernels" if overlap else ""))
+                   if world > 1 else "single GPU"},
         "device_ms_per_step": round(dev_ms, 4),
         "roofline": roofline,
     }

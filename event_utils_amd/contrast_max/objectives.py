@@ -21,7 +21,7 @@ from .. import _device as D
 from .. import _lib
 from .. import tiled
 from ..events import DeviceEvents
-from ..representations.image import _events_to_image_drv_device
+from ..representations.image import _events_to_image_drv_device, image_to_event_weights
 from ..util.event_util import events_bounds_mask
 
 
@@ -95,15 +95,12 @@ def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, 
     Image of warped events and its derivative w.r.t. the motion parameters (reference: objectives.py:165-199):
     warp at t0 = ts[-1] (:186) -> events_bounds_mask(0, img_size[1], 0, img_size[0]) (:187) -> multiply everything by
     the mask (:188-190) -> events_to_image_drv with its DEFAULT sensor_size (:191-192, quirk Q1; pass sensor_size to
-    override).  Returns numpy float32 (iwe, d_iwe | None [, (xs, ys)]).
+    override).  Returns numpy float32 (iwe, d_iwe | None [, (xs, ys)] [, per-event contrast]).
     linvel_warp uses the fused kernel; any other warp_function plugin is called as upstream and its output goes
     through the generic mask + splat kernels.
     """
-    if return_per_event_contrast:
-        raise NotImplementedError("return_per_event_contrast (image_to_event_weights gather, image.py:138-160) is a "
-                                  "'next' row of the hot-path table")
     fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
-    if fused and not return_events:
+    if fused and not return_events and not return_per_event_contrast:
         ev = _as_device_events(xs, ys, ts, ps)
         iwe, diwe = iwe_device(params, ev, img_size, compute_gradient, use_polarity, sensor_size)
         return iwe.cpu().numpy(), (diwe.cpu().numpy() if diwe is not None else None)
@@ -123,9 +120,11 @@ def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, 
     iwe, diwe = _events_to_image_drv_device(xw, yw, pm, jx, jy, kw.get("sensor_size", (180, 240)), True, 'bilinear',
                                             True, compute_gradient)
     returnval = [iwe.cpu().numpy(), diwe.cpu().numpy() if diwe is not None else None]
+    to_np = (lambda a: a.cpu().numpy()) if isinstance(xw, torch.Tensor) else (lambda a: a)
     if return_events:
-        to_np = (lambda a: a.cpu().numpy()) if isinstance(xw, torch.Tensor) else (lambda a: a)
         returnval.append((to_np(xw), to_np(yw)))
+    if return_per_event_contrast:       # local contrast of every warped event in the IWE (objectives.py:196-198)
+        returnval.append(to_np(image_to_event_weights(xw, yw, iwe)))
     return tuple(returnval)
 
 

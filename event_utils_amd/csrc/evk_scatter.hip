@@ -232,6 +232,63 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_image_drv_f64(const double *__res
     });
 }
 
+// image_to_event_weights (image.py:138-160): bilinear GATHER of a float32 image at float64 event coordinates.
+__global__ void __launch_bounds__(EVK_BLOCK) k_image_gather_f64(const double *__restrict__ x,
+                                                                const double *__restrict__ y, int64_t n,
+                                                                const float *__restrict__ img, int h, int wd,
+                                                                double *__restrict__ out, uint32_t *oob) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double clipx = (double)(wd - 1), clipy = (double)(h - 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double xv = x[i], yv = y[i];
+        const double mask = ((xv >= clipx) ? 0.0 : 1.0) * ((yv >= clipy) ? 0.0 : 1.0);
+        long long x0 = (long long)floor(xv * mask), y0 = (long long)floor(yv * mask);
+        const double dx = xv - (double)x0, dy = yv - (double)y0;  // fractions of the UNMASKED coordinate (upstream)
+        const double wx = 1.0 - dx, wy = 1.0 - dy;
+        long long x1 = x0 + 1, y1 = y0 + 1;
+        if (!(wrap_index(x0, wd) && wrap_index(x1, wd) && wrap_index(y0, h) && wrap_index(y1, h))) {
+            count_oob(oob);
+            out[i] = 0.0;
+            continue;
+        }
+        double w = (double)img[y0 * wd + x0] * wx * wy;
+        w += (double)img[y0 * wd + x1] * dx * wy;
+        w += (double)img[y1 * wd + x0] * wx * dy;
+        w += (double)img[y1 * wd + x1] * dx * dy;
+        out[i] = w * mask;
+    }
+}
+
+// Average-timestamp images (image.py:219-353): four bilinear splats per event -- normalised timestamp and count, for
+// positive and non-positive events.  nts = (t - ta) / td (mode 0), (-t + ta) / td (mode 1), t (mode 2), float32.
+// Upstream quirk kept: clipped events are moved to pixel (0, 0) but keep their weights (masked_ps is never used).
+__global__ void __launch_bounds__(EVK_BLOCK) k_timestamp_images_f32(const float *__restrict__ x,
+                                                                    const float *__restrict__ y,
+                                                                    const float *__restrict__ t,
+                                                                    const float *__restrict__ p, int64_t n, int h,
+                                                                    int wd, float clipx, float clipy, int mode,
+                                                                    float ta, float td, float *__restrict__ out,
+                                                                    uint32_t *oob) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = (int64_t)h * wd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xf = x[i], yf = y[i], tf = t[i];
+        const float mask = (!(xf >= clipx) && !(yf >= clipy)) ? 1.0f : 0.0f;
+        const float fx = floorf(xf), fy = floorf(yf);
+        Splat s;
+        s.dx = xf - fx;
+        s.dy = yf - fy;
+        s.px = (long long)(fx * mask);
+        s.py = (long long)(fy * mask);
+        const float nts = mode == 0 ? (tf - ta) / td : (mode == 1 ? (-tf + ta) / td : tf);
+        const bool pos = p[i] > 0.0f;  // pos_events_mask = ps > 0, neg_events_mask = ps <= 0 (NaN: neither)
+        const bool neg = p[i] <= 0.0f;
+        if (!pos && !neg) continue;
+        float *val = out + (pos ? 0 : 2) * plane, *cnt = val + plane;
+        if (!splat_iwe(val, h, wd, s, nts) || !splat_iwe(cnt, h, wd, s, 1.0f)) count_oob(oob);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // voxel grid: single pass, <= 2 bins per event
 // ---------------------------------------------------------------------------------------------------------
@@ -542,6 +599,25 @@ extern "C" int evk_image_drv_f64(const double *x, const double *y, const double 
     else
         k_image_drv_f64<false><<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, p, jx, jy, n, h, wd, clipx,
                                                                                   clipy, img, d_img, oob);
+    return launch_status();
+}
+
+extern "C" int evk_image_gather_bilinear_f64(const double *x, const double *y, int64_t n, const float *img, int h,
+                                             int wd, double *out, uint32_t *oob, void *stream) {
+    if (n < 0 || h <= 1 || wd <= 1 || !img || (n > 0 && (!x || !y || !out))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_image_gather_f64<<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, n, img, h, wd, out, oob);
+    return launch_status();
+}
+
+extern "C" int evk_timestamp_images_f32(const float *x, const float *y, const float *t, const float *p, int64_t n,
+                                        int h, int wd, float clipx, float clipy, int mode, float ta, float td,
+                                        float *out4, uint32_t *oob, void *stream) {
+    if (n < 0 || h <= 1 || wd <= 1 || !out4 || mode < 0 || mode > 2 || (n > 0 && (!x || !y || !t || !p)))
+        return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_timestamp_images_f32<<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, n, h, wd, clipx, clipy, mode,
+                                                                              ta, td, out4, oob);
     return launch_status();
 }
 

@@ -173,3 +173,82 @@ def events_to_image_drv(xn, yn, pn, jacobian_xn, jacobian_yn, device=None, senso
     img, d_img = _events_to_image_drv_device(xn, yn, pn, jacobian_xn, jacobian_yn, sensor_size, clip_out_of_range,
                                              interpolation, padding, compute_gradient)
     return img.cpu().numpy(), (d_img.cpu().numpy() if d_img is not None else None)
+
+
+def image_to_event_weights(xs, ys, img):
+    """
+    Value of `img` at every event by reverse bilinear interpolation (reference: image.py:138-160); events with
+    x >= W-1 or y >= H-1 get 0.  numpy in -> float64 numpy out; device tensors in -> device tensor out.
+    """
+    dev = D.require_gpu()
+    on_device = isinstance(xs, torch.Tensor)
+    xd, yd = D.to_device(xs, torch.float64, dev), D.to_device(ys, torch.float64, dev)
+    imgd = D.to_device(img, torch.float32, dev)
+    out = torch.empty_like(xd)
+    oob = D.OobCounter(dev)
+    _lib.call("evk_image_gather_bilinear_f64", D.ptr(xd), D.ptr(yd), xd.shape[0], D.ptr(imgd), imgd.shape[0],
+              imgd.shape[1], D.ptr(out), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(imgd.shape),))
+    return out if on_device else out.cpu().numpy()
+
+
+def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv):
+    """(4, H, W) float32 device tensor [ts_pos, cnt_pos, ts_neg, cnt_neg]; the count planes start at ONE (upstream
+    quirk, image.py:269,271: img_*_cnt = torch.ones)."""
+    dev = xd.device
+    clipx, clipy = _clip_thresholds(img_size, clip_out_of_range, interpolation, padding)
+    out = torch.zeros((4,) + tuple(img_size), dtype=torch.float32, device=dev)
+    out[1].fill_(1.0)
+    out[3].fill_(1.0)
+    oob = D.OobCounter(dev)
+    _lib.call("evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], img_size[0], img_size[1],
+              clipx, clipy, mode, float(ta), float(tdiv), D.ptr(out), oob.ptr, D.stream())
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),))
+    return out
+
+
+def events_to_timestamp_image(xn, yn, ts, pn, device=None, sensor_size=(180, 240), clip_out_of_range=True,
+                              interpolation='bilinear', padding=True, normalize_timestamps=True):
+    """
+    Average-timestamp images of the positive and non-positive events (Zhu et al.; reference: image.py:219-283).
+    numpy in -> two float32 numpy images.  Timestamps are normalised as (ts - ts[0]) / (ts[-1] - ts[0]... upstream
+    divides by (ts[-1] + 1e-6) of the ts[0]-shifted float32 column (:251) -- kept.
+    """
+    dev = D.require_gpu()
+    img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
+    tsf = (np.asarray(ts) - ts[0]).astype(np.float32)                       # torch.from_numpy(ts - t0).float()
+    xd, yd = D.to_device(np.asarray(xn), torch.float32, dev), D.to_device(np.asarray(yn), torch.float32, dev)
+    td, pd = D.to_device(tsf, torch.float32, dev), D.to_device(np.asarray(pn), torch.float32, dev)
+    if normalize_timestamps:
+        mode, ta, tdiv = 0, tsf[0], np.float32(tsf[-1] + np.float32(1e-6))
+    else:
+        mode, ta, tdiv = 2, 0.0, 1.0
+    img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)
+    img = img.cpu().numpy()
+    img_pos, img_pos_cnt, img_neg, img_neg_cnt = img[0], img[1], img[2], img[3]
+    img_pos_cnt[img_pos_cnt == 0] = 1
+    img_neg_cnt[img_neg_cnt == 0] = 1
+    return img_pos / img_pos_cnt, img_neg / img_neg_cnt
+
+
+def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(180, 240), clip_out_of_range=True,
+                                    interpolation='bilinear', padding=True, timestamp_reverse=False):
+    """
+    Torch twin (reference: image.py:285-353): nts = (ts - ts[0]) / (ts[-1] - ts[0] + 1e-6), or
+    (-ts + ts[-1]) / (...) with timestamp_reverse.  Tensors in -> two float32 tensors on `device`.
+    """
+    if device is None:
+        device = xs.device
+    dev = D.require_gpu()
+    xs, ys, ps, ts = xs.squeeze(), ys.squeeze(), ps.squeeze(), ts.squeeze()
+    img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
+    xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
+    td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
+    t_first, t_last = np.float32(td[0].item()), np.float32(td[-1].item())
+    tdiv = np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
+    mode, ta = (1, t_last) if timestamp_reverse else (0, t_first)
+    img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)
+    img_pos, img_pos_cnt, img_neg, img_neg_cnt = img[0], img[1], img[2], img[3]
+    img_pos_cnt[img_pos_cnt == 0] = 1
+    img_neg_cnt[img_neg_cnt == 0] = 1
+    return img_pos.div(img_pos_cnt).to(device), img_neg.div(img_neg_cnt).to(device)

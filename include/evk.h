@@ -87,6 +87,20 @@ int evk_image_drv_f64(const double *x, const double *y, const double *p, const d
                       int64_t n, int h, int wd, float clipx, float clipy, float *img, float *d_img, uint32_t *oob,
                       void *stream);
 
+/* image_to_event_weights (image.py:138-160): out[i] = bilinear interpolation of img (h, wd) float32 at (x[i], y[i])
+ * (float64), 0 for events with x >= wd-1 or y >= h-1.  Used by get_iwe(return_per_event_contrast=True)
+ * (objectives.py:196-198). */
+int evk_image_gather_bilinear_f64(const double *x, const double *y, int64_t n, const float *img, int h, int wd,
+                                  double *out, uint32_t *oob, void *stream);
+
+/* events_to_timestamp_image[_torch] (image.py:219-353): out4 = (4, h, wd) float32 = [sum of normalised timestamps of
+ * positive events, count of positive events, the same two for non-positive events], bilinear splat, accumulated into
+ * (the caller initialises the count planes to ONE as upstream does, image.py:269,271).  Normalised timestamp
+ * nts = (t - ta)/td (mode 0), (-t + ta)/td (mode 1, timestamp_reverse), t (mode 2), in float32. */
+int evk_timestamp_images_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
+                             float clipx, float clipy, int mode, float ta, float td, float *out4, uint32_t *oob,
+                             void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Voxel grid (temporal-bilinear, spatially nearest)
  * ---------------------------------------------------------------------------------------------------------- */

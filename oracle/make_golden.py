@@ -185,6 +185,36 @@ def main():
         out[tag + "_iwe"], out[tag + "_diwe"] = iwe, diwe
     save("f7_iwe_sized", **out)
 
+    # ---- F11 gather / per-event contrast / timestamp images ("next" rows of the scope table) --------
+    H, Wd, n = 180, 240, 8000
+    x, y, t, p = gen_events(110, n, H, Wd, real_xy=True)
+    prm = np.array([30., -20.])
+    out = dict(xs=x.astype(np.float32), ys=y.astype(np.float32), ts=t.astype(np.float32), ps=p.astype(np.int8),
+               versions=versions, params=prm)
+    r = O.get_iwe(prm, x, y, t, p, w, (H, Wd), return_events=True, return_per_event_contrast=True)
+    out["iwe"], out["ev_x"], out["ev_y"], out["contrast"] = r[0], r[2][0], r[2][1], r[3]
+    rng = np.random.default_rng(111)
+    gimg = rng.normal(size=(H + 1, Wd + 1)).astype(np.float32)
+    gx = rng.uniform(0, Wd + 2, 3000)
+    gy = rng.uniform(0, H + 2, 3000)
+    out["g_img"], out["g_x"], out["g_y"] = gimg, gx, gy
+    out["g_w"] = I.image_to_event_weights(gx, gy, gimg)
+    xi = rng.uniform(0, Wd + 1.5, n)
+    yi = rng.uniform(0, H + 1.5, n)
+    out["ti_x"], out["ti_y"] = xi.astype(np.float32), yi.astype(np.float32)
+    tsn = t + 3.0
+    out["ti_ts64"] = tsn
+    a, b = I.events_to_timestamp_image(out["ti_x"].astype(np.float64), out["ti_y"].astype(np.float64), tsn, p)
+    out["ti_np_pos"], out["ti_np_neg"] = a, b
+    a, b = I.events_to_timestamp_image(out["ti_x"].astype(np.float64), out["ti_y"].astype(np.float64), tsn, p,
+                                       padding=False, normalize_timestamps=False)
+    out["ti_np_nopad_pos"], out["ti_np_nopad_neg"] = a, b
+    tt = [torch.from_numpy(v) for v in (out["ti_x"], out["ti_y"], tsn.astype(np.float32), p.astype(np.float32))]
+    for rev in (False, True):
+        a, b = I.events_to_timestamp_image_torch(*tt, timestamp_reverse=rev)
+        out["ti_t_pos_rev%d" % rev], out["ti_t_neg_rev%d" % rev] = a.numpy(), b.numpy()
+    save("f11_gather_timestamp", **out)
+
     # ---- F10 gaussian_filter (2-D and 3-D two-channel) ----------------------------------------------
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(100)

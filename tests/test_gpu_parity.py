@@ -446,3 +446,28 @@ def test_voxel_windows_fixed_n_and_fixed_t(E):
     close(vp.numpy(), R.events_to_voxel_torch(x, y, t, (p > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
     close(vn.numpy(), R.events_to_voxel_torch(x, y, t, (p <= 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
     assert V.voxel_grids_fixed_n_torch(tx[:10], ty[:10], tt[:10], tp[:10], B, 10, sensor_size=(H, W)) == []
+
+
+# ------------------------------------------------------------------------------------------------ F11 next rows
+def test_f11_gather_contrast_and_timestamp_images(E, golden):
+    g = golden("f11_gather_timestamp")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    r = E.get_iwe(g["params"], x, y, t, p, E.linvel_warp(), (180, 240), return_events=True, return_per_event_contrast=True)
+    close(r[0], g["iwe"])
+    assert r[1] is None and np.array_equal(r[2][0], g["ev_x"]) and np.array_equal(r[2][1], g["ev_y"])
+    close(r[3], g["contrast"])
+    w = E.image_to_event_weights(g["g_x"], g["g_y"], g["g_img"])
+    assert w.dtype == np.float64 and np.array_equal(w, g["g_w"])       # pure gather: bit-exact
+    xi, yi = f64(g["ti_x"]), f64(g["ti_y"])
+    a, b = E.events_to_timestamp_image(xi, yi, g["ti_ts64"], p)
+    assert a.dtype == np.float32
+    close(a, g["ti_np_pos"]); close(b, g["ti_np_neg"])
+    a, b = E.events_to_timestamp_image(xi, yi, g["ti_ts64"], p, padding=False, normalize_timestamps=False)
+    close(a, g["ti_np_nopad_pos"]); close(b, g["ti_np_nopad_neg"])
+    tt = [torch.from_numpy(v) for v in (g["ti_x"], g["ti_y"], g["ti_ts64"].astype(np.float32), p.astype(np.float32))]
+    for rev in (False, True):
+        a, b = E.events_to_timestamp_image_torch(*tt, timestamp_reverse=rev)
+        assert a.dtype == torch.float32 and a.device.type == "cpu"
+        close(a.numpy(), g["ti_t_pos_rev%d" % rev]); close(b.numpy(), g["ti_t_neg_rev%d" % rev])
+    with pytest.raises(IndexError):
+        E.image_to_event_weights(np.array([-500.0]), np.array([1.0]), g["g_img"])

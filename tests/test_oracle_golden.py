@@ -168,3 +168,22 @@ def test_f9_optimize_trace(golden, mode):
     assert np.allclose(argmax, g[mode + "_argmax"], rtol=0, atol=1e-9)
     assert [k for k, _ in trace] == list(g[mode + "_kind"])
     assert np.allclose(np.array([q for _, q in trace]), g[mode + "_params"], rtol=0, atol=1e-9)
+
+
+def test_f11_gather_contrast_timestamp_images(golden):
+    g = golden("f11_gather_timestamp")
+    x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
+    r = R.get_iwe(g["params"], x, y, t, p, R.linvel_warp(), (180, 240), return_events=True, return_per_event_contrast=True)
+    assert np.array_equal(r[0], g["iwe"]) and r[1] is None
+    assert np.array_equal(r[2][0], g["ev_x"]) and np.array_equal(r[2][1], g["ev_y"])
+    assert np.array_equal(r[3], g["contrast"])
+    assert np.array_equal(R.image_to_event_weights(g["g_x"], g["g_y"], g["g_img"]), g["g_w"])
+    xi, yi = f64(g["ti_x"]), f64(g["ti_y"])
+    a, b = R.events_to_timestamp_image(xi, yi, g["ti_ts64"], p)
+    assert a.dtype == np.float32 and np.array_equal(a, g["ti_np_pos"]) and np.array_equal(b, g["ti_np_neg"])
+    a, b = R.events_to_timestamp_image(xi, yi, g["ti_ts64"], p, padding=False, normalize_timestamps=False)
+    assert np.array_equal(a, g["ti_np_nopad_pos"]) and np.array_equal(b, g["ti_np_nopad_neg"])
+    for rev in (False, True):
+        a, b = R.events_to_timestamp_image_torch(g["ti_x"], g["ti_y"], g["ti_ts64"].astype(np.float32), p.astype(np.float32),
+                                                 timestamp_reverse=rev)
+        assert np.array_equal(a, g["ti_t_pos_rev%d" % rev]) and np.array_equal(b, g["ti_t_neg_rev%d" % rev])
