@@ -12,7 +12,11 @@ def default_impl():
     return os.environ.get("EVK_IMPL", "auto")
 
 
-TILED_MIN_EVENTS = 100_000      # below this the bucketing pre-pass costs more than the atomics it saves
+# 'auto' thresholds, measured (profiles/r01_direct_tiled_crossover.txt): the single-shot voxel call pays ~40 us of fixed
+# bucketing cost, the direct kernel 2 global atomics per event at ~21 G/s -> crossover ~350 k events; the IWE path
+# re-uses its buckets over many evaluations and has 4-12 atomics per event -> crossover ~150 k events
+TILED_MIN_EVENTS = 350_000
+TILED_MIN_EVENTS_IWE = 150_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
 
@@ -36,7 +40,7 @@ class Buckets:
         self.tw_log2, self.th_log2, self.ntiles = tw_log2, th_log2, ntiles
 
 
-def can_tile(cols, impl):
+def can_tile(cols, impl, min_events=None):
     """Tiled path preconditions: float32, contiguous, 16-byte aligned columns, n < 2^32; under 'auto' also enough
     events to amortise the bucketing pre-pass."""
     import torch
@@ -45,7 +49,7 @@ def can_tile(cols, impl):
         return False
     if not all(c.dtype == torch.float32 and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in cols):
         return False
-    return impl == "tiled" or n >= TILED_MIN_EVENTS
+    return impl == "tiled" or n >= (TILED_MIN_EVENTS if min_events is None else min_events)
 
 
 def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None):
@@ -137,7 +141,7 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     import math
     impl = impl or default_impl()
     vxs, vys = ((vx,), (vy,)) if batch is None else batch
-    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl) and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
+    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl, TILED_MIN_EVENTS_IWE) and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
         return None
     dom_h = max(int(bounds_h) + 1, ch)
     dom_w = max(int(bounds_w) + 1, cw)
