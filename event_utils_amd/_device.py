@@ -73,7 +73,7 @@ _scratch = {}
 
 
 def reduce_scratch(device):
-    key = (device.index, "reduce")
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "reduce")
     if key not in _scratch:
         nbytes = int(_lib.lib().evk_reduce_scratch_bytes())
         _scratch[key] = (torch.empty(nbytes // 8, dtype=torch.float64, device=device), nbytes)
@@ -82,7 +82,7 @@ def reduce_scratch(device):
 
 def out4(device, n=4):
     """Persistent n-double device result slot (objective evaluations return a few scalars)."""
-    key = (device.index, "out%d" % n)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "out%d" % n)
     if key not in _scratch:
         _scratch[key] = torch.empty(n, dtype=torch.float64, device=device)
     return _scratch[key]

@@ -324,3 +324,159 @@ class variance_objective(objective_function):
                   D.stream())
         g = out[:2].cpu().numpy()
         return -(g.astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other objectives of the reference (objectives.py:266-596): same IWE, a different scalar reduction.
+# Upstream these classes skip objective_function.__init__ (so e.g. soe has no pixel_crossings and cannot go through
+# optimize()); here they all inherit the full base state, which is a superset of the upstream behaviour.
+# Not provided: rms_objective (upstream takes np.linalg.norm(iwe, 2) of a MATRIX, i.e. its largest singular value, :282)
+# and zhu_timestamp_objective (calls the undefined events_to_zhu_timestamp_image, :545).
+# ---------------------------------------------------------------------------------------------------------------
+class _reduction_objective(objective_function):
+    def _stats(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, p=0.0, thresh=0.0):
+        """[mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count(v > thresh), max v] of the blurred IWE."""
+        dev = D.require_gpu()
+        if iwe is None:
+            iwe, _ = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, False)
+        else:
+            iwe = D.to_device(iwe, torch.float32, dev)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        w, radius = _blur_kernel(blur_sigma)
+        iwe = iwe.contiguous()
+        out, (scratch, nbytes) = D.out4(dev, 8), D.reduce_scratch(dev)
+        _lib.call("evk_objective_stats_f32", D.ptr(iwe), iwe.shape[0], iwe.shape[1],
+                  D.host_ptr(w) if w is not None else None, radius, float(p), float(thresh), D.ptr(out), D.ptr(scratch),
+                  nbytes, D.stream())
+        return out.cpu().numpy(), iwe.numel()
+
+    def _gradsums(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, gfun, gparam, blur_iwe):
+        """(sum g(a) d0, sum g(a) d1, number of pixels) with d = 3-D blurred dIWE (Q4) and a = raw or blurred IWE."""
+        dev = D.require_gpu()
+        if iwe is None or d_iwe is None:
+            iwe, d_iwe = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, True)
+        else:
+            iwe, d_iwe = D.to_device(iwe, torch.float32, dev), D.to_device(d_iwe, torch.float32, dev)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        w, radius = _blur_kernel(blur_sigma)
+        iwe, d_iwe = iwe.contiguous(), d_iwe.contiguous()
+        out, (scratch, nbytes) = D.out4(dev, 8), D.reduce_scratch(dev)
+        flags = 1 | (2 if blur_iwe else 0)
+        _lib.call("evk_objective_gradsums_f32", D.ptr(iwe), D.ptr(d_iwe), iwe.shape[0], iwe.shape[1],
+                  D.host_ptr(w) if w is not None else None, radius, flags, gfun, float(gparam), D.ptr(out),
+                  D.ptr(scratch), nbytes, D.stream())
+        r = out.cpu().numpy()
+        return np.array([r[6], r[7]]), iwe.numel()
+
+
+class sos_objective(_reduction_objective):
+    """Sum of squares (reference: objectives.py:308-353): -mean(blur(iwe)^2); gradient -mean(blur3d(d_iwe)[i] * 2 iwe)
+    with the un-blurred IWE."""
+
+    def __init__(self, adaptive_lifespan=False, minimum_events=10000):
+        super().__init__(name="sos", use_polarity=True, has_derivative=True, default_blur=1.0,
+                         adaptive_lifespan=adaptive_lifespan, pixel_crossings=5, minimum_events=minimum_events)
+        self.current_num_events = minimum_events
+        self.div = 1
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, n = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe)
+        return np.float32(-(st[3] / n) / (self.div * self.div))
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        g, n = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 0, 0.0, False)
+        return -(2.0 * g / n / (self.div * self.div)).astype(np.float32)
+
+
+class soe_objective(_reduction_objective):
+    """Sum of exponentials (reference: objectives.py:355-399): -mean(exp(blur(iwe))), |polarity|, default blur 2.5."""
+
+    def __init__(self):
+        super().__init__(name="soe", use_polarity=False, has_derivative=True, default_blur=2.5)
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, n = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe)
+        return -(st[4] / n)
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        g, n = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 1, 0.0, True)
+        return -(g / n)
+
+
+class moa_objective(_reduction_objective):
+    """Max of accumulations (reference: objectives.py:401-426): -max(blur(iwe)); no analytic derivative."""
+
+    def __init__(self):
+        super().__init__(name="moa", use_polarity=False, has_derivative=False, default_blur=3.0)
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, _ = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe)
+        return np.float32(-st[7])
+
+    def evaluate_gradient(self, iwe=None, d_iwe=None, blur_sigma=None, showimg=False):
+        return None
+
+
+class isoa_objective(_reduction_objective):
+    """Inverse sum of accumulations (reference: objectives.py:428-474): +count(blur(iwe) > thresh) (positive, as
+    upstream); gradient -sum(blur3d(d_iwe)[i] * [blur(iwe) > thresh])."""
+
+    def __init__(self, thresh=0.5):
+        super().__init__(name="isoa", use_polarity=False, has_derivative=True, default_blur=1.0)
+        self.thresh = thresh
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, _ = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, thresh=self.thresh)
+        return np.int64(round(st[6]))
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        g, _ = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 2, self.thresh, True)
+        return -(g.astype(np.float32))
+
+
+class sosa_objective(_reduction_objective):
+    """Sum of suppressed accumulations (reference: objectives.py:476-520): -sum(exp(-p blur(iwe)));
+    gradient -sum(blur3d(d_iwe)[i] * (-p exp(-p blur(iwe))))."""
+
+    def __init__(self, p=3):
+        super().__init__(name="sosa", use_polarity=False, has_derivative=True, default_blur=2.0)
+        self.p = p
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, _ = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, p=self.p)
+        return -st[5]
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        g, _ = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 3, self.p, True)
+        return -(-self.p * g)
+
+
+class r1_objective(_reduction_objective):
+    """R1 (reference: objectives.py:560-596): -sos*sosa, or -sos while sosa keeps growing (stateful last_sosa)."""
+
+    def __init__(self, p=3):
+        super().__init__(name="r1", use_polarity=False, has_derivative=False, default_blur=1.0)
+        self.p = p
+        self.last_sosa = 0
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        st, n = self._stats(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, p=self.p)
+        sos, sosa = st[3] / n, st[5]
+        if sosa > self.last_sosa:
+            return -sos
+        self.last_sosa = sosa
+        return -sos * sosa
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        return None

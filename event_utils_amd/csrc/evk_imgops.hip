@@ -91,12 +91,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_partial(const float *__res
     block_sum<EVK_REDUCE_K>(acc, partials + (int64_t)blockIdx.x * EVK_REDUCE_K);
 }
 
-template <int MODE>
+// WIDE: additionally out[4..7] = the raw sums tot[1..4] (generic objectives); stride of `out` per plane stays 4 or 8.
+template <int MODE, bool WIDE = false>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
                                                             int64_t n, double *__restrict__ out) {
     double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
     partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
-    out += 4 * blockIdx.x;
+    out += (WIDE ? 8 : 4) * blockIdx.x;
     for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
 #pragma unroll
         for (int k = 0; k < EVK_REDUCE_K; ++k) acc[k] += partials[(int64_t)b * EVK_REDUCE_K + k];
@@ -117,6 +118,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
             out[1] = 2.0 * inv * (tot[4] - mean * tot[2]);
             out[2] = mean;
             out[3] = tot[0];
+        }
+        if constexpr (WIDE) {
+            out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
         }
     }
 }
@@ -168,11 +172,32 @@ __device__ __forceinline__ void blur_tile(float *patch, float *inter, const Blur
     __syncthreads();
 }
 
+// weight function g(a) of the generic gradient sums  sum_pix g(a) * blur(d_iwe)[i]
+#define EVK_G_IDENT 0   // a                 (variance, sos)
+#define EVK_G_EXP 1     // exp(a)            (soe)
+#define EVK_G_STEP 2    // a > gparam ? 1:0  (isoa)
+#define EVK_G_EXPNEG 3  // exp((double)(float)(-gparam*a))   (sosa; the reference forms -p*iwe in float32 first)
+struct PostParams {
+    uint32_t flags;
+    int gfun;
+    double gparam;  // MODE 1: parameter of g;  MODE 2: p of sum(exp(-p v))
+    double thresh;  // MODE 2: threshold of count(v > thresh)
+    unsigned int *max_bits;  // MODE 2: running max of v as order-preserving uint bits (atomicMax)
+};
+
+__device__ __forceinline__ unsigned int float_order_bits(float f) {  // monotone map float -> uint
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// MODE 0: sum v, sum v^2 of the blurred image.  MODE 1: sum g(a), sum d0, sum d1, sum g(a) d0, sum g(a) d1.
+// MODE 2: sum v, sum v^2, sum exp(v), sum exp(-p v), count(v > thresh) and max v of the blurred image.
 template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restrict__ iwe,
                                                           const float *__restrict__ diwe, int ch, int cw,
-                                                          BlurWeights bw, uint32_t flags,
+                                                          BlurWeights bw, PostParams pp,
                                                           double *__restrict__ partials) {
+    const uint32_t flags = pp.flags;
     extern __shared__ float sm[];
     const int r = bw.radius, PW = EVK_POST_T + 2 * r;
     float *patch = sm, *inter = sm + PW * PW;
@@ -182,16 +207,28 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     iwe += blockIdx.y * plane;                                         // MODE 0 batched over image planes
     partials += (int64_t)blockIdx.y * gridDim.x * EVK_REDUCE_K;
     double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 2) {
         float v[4];
         blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
+        float vmax = -__builtin_inff();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
             if (y < ch && x < cw) {
                 acc[0] += (double)v[k];
                 acc[1] += (double)v[k] * (double)v[k];
+                if constexpr (MODE == 2) {
+                    acc[2] += exp((double)v[k]);
+                    acc[3] += exp(-pp.gparam * (double)v[k]);
+                    acc[4] += ((double)v[k] > pp.thresh) ? 1.0 : 0.0;
+                    vmax = fmaxf(vmax, v[k]);
+                }
             }
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+            if ((threadIdx.x & 63) == 0 && vmax > -__builtin_inff()) atomicMax(pp.max_bits, float_order_bits(vmax));
         }
     } else {
         float d[2][4], a[4];
@@ -215,7 +252,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
         for (int k = 0; k < 4; ++k) {
             const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
             if (y < ch && x < cw) {
-                const double av = (flags & EVK_POST_BLUR_IWE) ? (double)a[k] : (double)iwe[(int64_t)y * cw + x];
+                const float af = (flags & EVK_POST_BLUR_IWE) ? a[k] : iwe[(int64_t)y * cw + x];
+                double av = (double)af;
+                if (pp.gfun == EVK_G_EXP) av = exp(av);
+                else if (pp.gfun == EVK_G_STEP) av = (av > pp.gparam) ? 1.0 : 0.0;
+                else if (pp.gfun == EVK_G_EXPNEG) av = exp((double)((float)(-pp.gparam) * af));
                 acc[0] += av;
                 acc[1] += (double)d[0][k];
                 acc[2] += (double)d[1][k];
@@ -307,7 +348,9 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     const int PW = EVK_POST_T + 2 * radius;
     const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    k_post_fused<MODE><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, flags, (double *)scratch);
+    PostParams pp;
+    pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr;
+    k_post_fused<MODE><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     k_reduce_final<MODE><<<nplanes, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out);
     return launch_status();
 }
@@ -327,4 +370,74 @@ extern "C" int evk_objective_variance_planes_f32(const float *imgs, int nplanes,
                                                  const double *host_weights, int radius, double *out, void *scratch,
                                                  int64_t scratch_bytes, void *stream) {
     return launch_post<0>(imgs, nullptr, h, w, host_weights, radius, 0u, out, scratch, scratch_bytes, stream, nplanes);
+}
+
+// Generic objective reductions (the other objectives of objectives.py:266-596 differ from the variance objective only
+// in these scalars): one fused blur + partial-sum launch and a finalise.
+__global__ void k_stats_finish(const double *__restrict__ wide, const unsigned int *__restrict__ max_bits,
+                               double *__restrict__ out) {
+    // wide = k_reduce_final<0, true> output: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
+    for (int k = 0; k < 7; ++k) out[k] = wide[k];
+    const unsigned int b = *max_bits;
+    const unsigned int u = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+    out[7] = (double)__uint_as_float(u);
+}
+
+static int blur_setup(int h, int w, const double *host_weights, int radius, BlurWeights &bw, int &grid, size_t &lds) {
+    if (!host_weights || radius < 0 || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
+    grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
+    if (grid > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
+    bw.radius = radius;
+    for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
+    const int PW = EVK_POST_T + 2 * radius;
+    lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
+    return EVK_OK;
+}
+
+static const double kIdentityWeight[1] = {1.0};
+
+extern "C" int evk_objective_stats_f32(const float *img, int h, int w, const double *host_weights, int radius, double p,
+                                       double thresh, double *out8, void *scratch, int64_t scratch_bytes,
+                                       void *stream) {
+    if (!img || h <= 0 || w <= 0 || !out8 || !scratch) return EVK_EINVAL;
+    if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
+    if (radius < 0) host_weights = kIdentityWeight, radius = 0;  // no blur = a 1-tap kernel
+    BlurWeights bw;
+    int grid;
+    size_t lds;
+    int rc = blur_setup(h, w, host_weights, radius, bw, grid, lds);
+    if (rc != EVK_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // tail of the scratch: 8 doubles of wide sums + the running max
+    double *wide = (double *)scratch + (int64_t)EVK_REDUCE_MAX_BLOCKS * EVK_REDUCE_K - 16;
+    unsigned int *max_bits = (unsigned int *)(wide + 8);
+    if (grid * EVK_REDUCE_K > EVK_REDUCE_MAX_BLOCKS * EVK_REDUCE_K - 16) return EVK_EINVAL;
+    hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(unsigned int), s);
+    if (e != hipSuccess) return (int)e;
+    PostParams pp;
+    pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits;
+    k_post_fused<2><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
+    k_reduce_final<0, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, wide);
+    k_stats_finish<<<1, 1, 0, s>>>(wide, max_bits, out8);
+    return launch_status();
+}
+
+extern "C" int evk_objective_gradsums_f32(const float *iwe, const float *diwe, int h, int w,
+                                          const double *host_weights, int radius, uint32_t flags, int gfun,
+                                          double gparam, double *out8, void *scratch, int64_t scratch_bytes,
+                                          void *stream) {
+    if (!iwe || !diwe || h <= 0 || w <= 0 || !out8 || !scratch || gfun < 0 || gfun > 3) return EVK_EINVAL;
+    if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
+    if (radius < 0) host_weights = kIdentityWeight, radius = 0, flags &= ~EVK_POST_MIX;  // sigma <= 0: nothing is blurred
+    BlurWeights bw;
+    int grid;
+    size_t lds;
+    int rc = blur_setup(h, w, host_weights, radius, bw, grid, lds);
+    if (rc != EVK_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    PostParams pp;
+    pp.flags = flags, pp.gfun = gfun, pp.gparam = gparam, pp.thresh = 0.0, pp.max_bits = nullptr;
+    k_post_fused<1><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
+    k_reduce_final<1, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out8);
+    return launch_status();
 }

@@ -24,10 +24,11 @@ _persist = {}
 def _buf(key, nbytes, device):
     """Grow-only persistent device scratch (avoids re-allocating tens of MB per objective evaluation)."""
     import torch
-    b = _persist.get((key, device.index))
+    k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)   # per stream: calls are stream-ordered
+    b = _persist.get(k)
     if b is None or b.numel() < nbytes:
         b = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-        _persist[(key, device.index)] = b
+        _persist[k] = b
     return b
 
 

@@ -185,6 +185,25 @@ int evk_objective_variance_grad_f32(const float *iwe, const float *diwe, int h, 
                                     int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes,
                                     void *stream);
 
+/* ---- generic objective reductions: the objectives of objectives.py:266-596 other than the variance one differ only in
+ * the scalar they take from the (blurred) IWE -----------------------------------------------------------------------
+ * evk_objective_stats_f32: v = gaussian_filter(img) (radius < 0: v = img);
+ *   out8 = [mean v, var v, sum v, sum v^2, sum exp(v), sum exp(-p v), count(v > thresh), max v]
+ *   (sos :329, soe :373-374, moa :421, isoa :450, sosa :497-498, r1 :584-586; exponentials in float64). */
+int evk_objective_stats_f32(const float *img, int h, int w, const double *host_weights, int radius, double p,
+                            double thresh, double *out8, void *scratch, int64_t scratch_bytes, void *stream);
+
+#define EVK_G_IDENT 0  /* g(a) = a                                    variance :257, sos :349                        */
+#define EVK_G_EXP 1    /* g(a) = exp(a)                               soe :395                                        */
+#define EVK_G_STEP 2   /* g(a) = a > gparam ? 1 : 0                   isoa :468-469                                   */
+#define EVK_G_EXPNEG 3 /* g(a) = exp((double)(float)(-gparam * a))    sosa :513 (forms -p*iwe in float32 first)       */
+/* evk_objective_gradsums_f32: d = gaussian_filter(diwe) (3-D with EVK_POST_MIX), a = iwe or, with EVK_POST_BLUR_IWE,
+ * gaussian_filter(iwe);  out8 = [.., .., .., sum g(a), sum d0, sum d1, sum g(a) d0, sum g(a) d1] (out8[0..2] as
+ * evk_objective_variance_grad_f32). */
+int evk_objective_gradsums_f32(const float *iwe, const float *diwe, int h, int w, const double *host_weights, int radius,
+                               uint32_t flags, int gfun, double gparam, double *out8, void *scratch,
+                               int64_t scratch_bytes, void *stream);
+
 int64_t evk_reduce_scratch_bytes(void);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -255,6 +255,29 @@ def main():
         out["al_grad"] = obj_al.evaluate_gradient(np.array([40., -25.]), x, y, t, p, w, (H, Wd), blur_sigma=1.0)
     save("f8_objective", **out)
 
+    # ---- F12 the other objectives (reductions of the same IWE; "next" row) --------------------------
+    params12 = np.array([[0, 0], [40, -25], [-10, 60]], dtype=np.float64)
+    out = dict(params=params12, versions=versions)
+    objs = {"sos": O.sos_objective(), "soe": O.soe_objective(), "moa": O.moa_objective(), "isoa": O.isoa_objective(),
+            "sosa": O.sosa_objective()}
+    for name, ob in objs.items():
+        fvals, gvals = [], []
+        for prm in params12:
+            for s in (None, 0.0):
+                fvals.append(np.float64(ob.evaluate_function(prm, x, y, t, p, w, (H, Wd), blur_sigma=s)))
+                if ob.has_derivative:
+                    if name == "sos":
+                        ob.pixel_crossings = 5      # evaluate_gradient calls an undefined find_lifespan (:345): patch in
+                        O.find_lifespan = lambda ts_, prm_, pc_: (None, None)
+                    gvals.append(np.asarray(ob.evaluate_gradient(prm, x, y, t, p, w, (H, Wd), blur_sigma=s), dtype=np.float64))
+        out[name + "_f"] = np.array(fvals)
+        if gvals:
+            out[name + "_g"] = np.array(gvals)
+    r1 = O.r1_objective()
+    out["r1_f"] = np.array([np.float64(r1.evaluate_function(prm, x, y, t, p, w, (H, Wd))) for prm in
+                            (params12[0], params12[1], params12[1], params12[2])])
+    save("f12_other_objectives", **out)
+
     # ---- F9 optimize trace ---------------------------------------------------------------------------
     out = dict(versions=versions)
     for mode in ("numeric", "analytic"):

@@ -471,3 +471,39 @@ def test_f11_gather_contrast_and_timestamp_images(E, golden):
         close(a.numpy(), g["ti_t_pos_rev%d" % rev]); close(b.numpy(), g["ti_t_neg_rev%d" % rev])
     with pytest.raises(IndexError):
         E.image_to_event_weights(np.array([-500.0]), np.array([1.0]), g["g_img"])
+
+
+def test_f12_other_objectives(E, golden):
+    """sos / soe / moa / isoa / sosa / r1 (objectives.py:308-596): same IWE, different scalar reductions."""
+    from event_utils_amd.contrast_max import objectives as O
+    from event_utils_amd.events import DeviceEvents
+    g8, g = golden("f8_objective"), golden("f12_other_objectives")
+    ev = DeviceEvents.from_arrays(*(f64(g8[k]) for k in ("xs", "ys", "ts", "ps")))
+    w = E.linvel_warp()
+    objs = {"sos": O.sos_objective(), "soe": O.soe_objective(), "moa": O.moa_objective(), "isoa": O.isoa_objective(),
+            "sosa": O.sosa_objective()}
+    for name, ob in objs.items():
+        k = 0
+        for prm in g["params"]:
+            for s in (None, 0.0):
+                f = f64(ob.evaluate_function(prm, ev, None, None, None, w, (180, 240), blur_sigma=s))
+                rf = g[name + "_f"][k]
+                if name == "isoa":
+                    assert abs(f - rf) <= 2, (name, f, rf)          # a count: pixels within 1e-7 of the threshold may flip
+                else:
+                    assert abs(f - rf) <= 2e-5 * abs(rf) + 1e-12, (name, k, f, rf)
+                if ob.has_derivative:
+                    gr = f64(ob.evaluate_gradient(prm, ev, None, None, None, w, (180, 240), blur_sigma=s))
+                    rg = g[name + "_g"][k]
+                    tol = 2e-5 * np.max(np.abs(rg)) + 1e-9
+                    if name == "isoa":
+                        tol = 0.02 * np.max(np.abs(rg)) + 1e-3
+                    assert np.max(np.abs(gr - rg)) <= tol, (name, k, gr, rg)
+                k += 1
+    r1 = O.r1_objective()
+    P = g["params"]
+    vals = [f64(r1.evaluate_function(q, ev, None, None, None, w, (180, 240))) for q in (P[0], P[1], P[1], P[2])]
+    assert np.max(np.abs(np.array(vals) - g["r1_f"]) / np.abs(g["r1_f"])) <= 2e-5
+    # these objectives now also work through optimize() (upstream several of them lack the base-class state)
+    argmax = E.optimize(ev, None, None, None, w, O.sos_objective(), numeric_grads=False, img_size=(180, 240))
+    assert np.all(np.isfinite(np.asarray(argmax, float)))

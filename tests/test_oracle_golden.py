@@ -187,3 +187,23 @@ def test_f11_gather_contrast_timestamp_images(golden):
         a, b = R.events_to_timestamp_image_torch(g["ti_x"], g["ti_y"], g["ti_ts64"].astype(np.float32), p.astype(np.float32),
                                                  timestamp_reverse=rev)
         assert np.array_equal(a, g["ti_t_pos_rev%d" % rev]) and np.array_equal(b, g["ti_t_neg_rev%d" % rev])
+
+
+def test_f12_other_objectives(golden):
+    g8, g = golden("f8_objective"), golden("f12_other_objectives")
+    x, y, t, p = f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"])
+    w = R.linvel_warp()
+    objs = {"sos": R.sos_objective(), "soe": R.soe_objective(), "moa": R.moa_objective(), "isoa": R.isoa_objective(),
+            "sosa": R.sosa_objective()}
+    for name, ob in objs.items():
+        k = 0
+        for prm in g["params"]:
+            for s in (None, 0.0):
+                assert np.float64(ob.evaluate_function(prm, x, y, t, p, w, (180, 240), blur_sigma=s)) == g[name + "_f"][k], name
+                if ob.has_derivative:
+                    assert np.array_equal(f64(ob.evaluate_gradient(prm, x, y, t, p, w, (180, 240), blur_sigma=s)), g[name + "_g"][k]), name
+                k += 1
+    r1 = R.r1_objective()
+    P = g["params"]
+    vals = [np.float64(r1.evaluate_function(q, x, y, t, p, w, (180, 240))) for q in (P[0], P[1], P[1], P[2])]
+    assert np.array_equal(np.array(vals), g["r1_f"])
