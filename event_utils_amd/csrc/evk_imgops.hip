@@ -119,7 +119,10 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
             out[2] = mean;
             out[3] = tot[0];
         }
-        if constexpr (WIDE) {
+        if constexpr (WIDE && MODE == 0) {  // stats: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
+            out[4] = tot[2], out[5] = tot[3], out[6] = tot[4], out[7] = 0.0;
+        }
+        if constexpr (WIDE && MODE == 1) {  // gradient sums: [.., .., mean, sum g, sum d0, sum d1, sum g d0, sum g d1]
             out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
         }
     }

