@@ -323,6 +323,19 @@ __device__ __forceinline__ void lds_add(acc_t *p, float v) {
     __hip_atomic_fetch_add(p, (acc_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Streams records [lo, hi) through f with 4 independent 16-byte loads in flight per lane.  (A software-pipelined
+// variant -- next step's loads issued before this step's atomics -- measured no faster: the kernels are LDS-atomic or
+// HBM bound with 28-32 resident waves per CU already overlapping each other.)
+template <typename F>
+__device__ __forceinline__ void stream_records(const float4 *__restrict__ rec, uint32_t lo, uint32_t hi, F f) {
+    uint32_t i = lo + threadIdx.x;
+    for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {
+        const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
+        f(r0), f(r1), f(r2), f(r3);
+    }
+    for (; i < hi; i += EVK_BLOCK) f(rec[i]);
+}
+
 __device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, int B, float tn, float p) {
     if (tn != tn) {  // dt == 0 (Q9): NaN in every bin of the pixel
         for (int b = 0; b < B; ++b) lds_add(acc + b * tpix + local, tn * p);
@@ -365,12 +378,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
         const float tn = (r.z - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
         voxel_bins_lds(acc, tpix, local, B, tn, r.w);
     };
-    uint32_t i = lo + threadIdx.x;
-    for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {  // 4 independent 16-byte loads in flight per lane
-        const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
-        one(r0), one(r1), one(r2), one(r3);
-    }
-    for (; i < hi; i += EVK_BLOCK) one(rec[i]);
+    stream_records(rec, lo, hi, one);
     __syncthreads();
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
     auto flush = [&](auto value_of) {
@@ -553,12 +561,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             splat(r, q.vxb[1], q.vyb[1], win + 2 * wcells, diwe + plane);
         }
     };
-    uint32_t i = lo + threadIdx.x;
-    for (; i + 3 * EVK_BLOCK < hi; i += 4 * EVK_BLOCK) {
-        const float4 r0 = rec[i], r1 = rec[i + EVK_BLOCK], r2 = rec[i + 2 * EVK_BLOCK], r3 = rec[i + 3 * EVK_BLOCK];
-        one(r0), one(r1), one(r2), one(r3);
-    }
-    for (; i < hi; i += EVK_BLOCK) one(rec[i]);
+    stream_records(rec, lo, hi, one);
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
     for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
@@ -669,7 +672,7 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
-    if (ntiles > EVK_MAX_TILES || n < 0 || n >= (int64_t)1 << 32 || (key_mode != 0 && key_mode != 1)) return EVK_EINVAL;
+    if (ntiles > EVK_MAX_TILES || n < 0 || n > (int64_t)4000000000LL || (key_mode != 0 && key_mode != 1)) return EVK_EINVAL;
     if (!bucket_start || !scratch || (n > 0 && (!x || !y || !t || !p || !records))) return EVK_EINVAL;
     if (scratch_bytes < evk_bucket_scratch_bytes(ntiles)) return EVK_ESCRATCH;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p) && aligned16(records))) return EVK_EALIGN;

@@ -46,7 +46,7 @@ def can_tile(cols, impl, min_events=None):
     events to amortise the bucketing pre-pass."""
     import torch
     n = cols[0].shape[0]
-    if impl not in ("tiled", "auto") or n == 0 or n >= 2 ** 32:
+    if impl not in ("tiled", "auto") or n == 0 or n > 4_000_000_000:
         return False
     if not all(c.dtype == torch.float32 and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in cols):
         return False
