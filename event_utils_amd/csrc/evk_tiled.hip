@@ -156,16 +156,27 @@ __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__res
              *item_tile = index + IDX_ITEM(ntiles);
     const int per = (ntiles + 1023) / 1024;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
-    auto block_exclusive = [&](uint32_t mine) -> uint32_t {  // Hillis-Steele; returns the exclusive prefix
-        part[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
+    auto block_exclusive = [&](uint32_t mine) -> uint32_t {  // wave shuffle scans + one scan of the 16 wave totals
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
         }
-        const uint32_t ex = part[threadIdx.x] - mine;
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t w = lane < 16 ? part[lane] : 0u, wi = w;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t v = __shfl_up(wi, off, 64);
+                if (lane >= off) wi += v;
+            }
+            if (lane < 16) part[16 + lane] = wi - w;  // exclusive prefix of the wave totals
+        }
+        __syncthreads();
+        const uint32_t ex = part[16 + wave] + incl - mine;
         __syncthreads();
         return ex;
     };
@@ -179,7 +190,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__res
         bucket_start[i] = run;
         run += totals[i];
     }
-    if (threadIdx.x == 1023) bucket_start[ntiles] = run;
+    if (threadIdx.x == 1023) bucket_start[ntiles] = run;   // thread 1023 ends at the grand total
     uint32_t prun = block_exclusive(np);
     for (int i = i0; i < i1; ++i) {
         const uint32_t parts = totals[i] > cap ? (totals[i] + cap - 1) / cap : 1u;
