@@ -451,6 +451,7 @@ struct IweParams {
     int abs_p, grad;
     int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
     double vxb[2], vyb[2];           // MODE 2 (batch of 3 nearby flows): flows 1 and 2 (flow 0 is vx, vy)
+    double fx_scale, fx_inv;         // FIXED: LDS cells hold sum(value * 2^k) as int64 (2^k = fx_scale)
 };
 
 // Same per-event arithmetic as evk_scatter.hip's iwe_event (kept textually identical: parity depends on it).
@@ -476,7 +477,12 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
 
 // MODE 0: IWE.  MODE 1: IWE + dIWE (gradient).  MODE 2: three IWEs for three nearby flows in one pass over the events
 // (forward-difference numeric gradient: f(v), f(v + eps e1), f(v + eps e2) share every event load).
-template <int MODE>
+// FIXED: the LDS cells are 64-bit FIXED-POINT sums (ds_add_u64 sustains 4.6 lane-ops/clk/CU vs 3.0 for ds_add_f64,
+// tools/lds_probe2.hip, and this kernel is LDS-atomic bound).  Every float32 contribution is scaled by 2^k, k chosen by
+// the host so that n * max|contribution| < 2^61 cannot overflow (k >= 26, typically 30-36): quantisation <= 2^-(k+1) per
+// event, orders of magnitude below the float32 rounding of the result, and integer adds commute, so the window sums
+// are bit-reproducible from run to run.
+template <int MODE, bool FIXED>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
                                                          const uint32_t *__restrict__ index, TileGrid g,
                                                          IweParams q, float *__restrict__ staging,
@@ -521,6 +527,14 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     }
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
+    auto lds_acc = [&](acc_t *cell, float v) {
+        if constexpr (FIXED)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(cell),
+                                   (unsigned long long)__double2ll_rn((double)v * q.fx_scale), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            lds_add(cell, v);
+    };
     // one flow, one IWE plane (`wp` in LDS, `gp` in the image); GRAD adds the derivative planes behind it
     auto splat = [&](const float4 &r, double vx, double vy, acc_t *wp, float *gp) {
         int px, py;
@@ -531,20 +545,20 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
             acc_t *c = wp + ly * q.win_w + lx;
-            lds_add(c, mp * ax * ay);
-            lds_add(c + 1, mp * dx * ay);
-            lds_add(c + q.win_w, mp * ax * dy);
-            lds_add(c + q.win_w + 1, mp * dx * dy);
+            lds_acc(c, mp * ax * ay);
+            lds_acc(c + 1, mp * dx * ay);
+            lds_acc(c + q.win_w, mp * ax * dy);
+            lds_acc(c + q.win_w + 1, mp * dx * dy);
             if constexpr (GRAD) {
                 // The reference's 8 derivative contributions come in +/- pairs on neighbouring pixels
                 // (image.py:132-135): d0[y][x] gets -a*ay from px == x and +a*ay from px == x-1, etc.  Accumulate
                 // the 4 magnitudes (E0: a*ay, a*dy; E1: a*ax, a*dx) and take the finite difference at the flush:
                 // d0[y][x] = E0[y][x-1] - E0[y][x],  d1[y][x] = E1[y-1][x] - E1[y][x]   (8 LDS atomics, not 12).
                 acc_t *e0 = c + wcells, *e1 = e0 + wcells;
-                lds_add(e0, a * ay);
-                lds_add(e0 + q.win_w, a * dy);
-                lds_add(e1, a * ax);
-                lds_add(e1 + 1, a * dx);
+                lds_acc(e0, a * ay);
+                lds_acc(e0 + q.win_w, a * dy);
+                lds_acc(e1, a * ax);
+                lds_acc(e1 + 1, a * dx);
             }
         } else {  // outside the window (flow larger than the halo, clamped outlier): straight to the image
             float *c = gp + (int64_t)py * q.cw + px;
@@ -575,17 +589,30 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     stream_records(rec, lo, hi, one);
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
+    // cell value / difference of two cells as float (exact integer difference on the fixed-point path)
+    auto cell = [&](const acc_t *a) -> float {
+        if constexpr (FIXED) return (float)((double)*reinterpret_cast<const long long *>(a) * q.fx_inv);
+        else return (float)*a;
+    };
+    auto diff = [&](const acc_t *a, const acc_t *b) -> float {  // a - b; a == nullptr means 0
+        if constexpr (FIXED) {
+            const long long va = a ? *reinterpret_cast<const long long *>(a) : 0ll;
+            return (float)((double)(va - *reinterpret_cast<const long long *>(b)) * q.fx_inv);
+        } else {
+            return (float)((a ? *a : 0.0) - *b);
+        }
+    };
     for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
-        st[c] = (float)win[c];
+        st[c] = cell(win + c);
         if constexpr (GRAD) {
             const int lx = c % q.win_w, ly = c / q.win_w;
             const acc_t *e0 = win + wcells, *e1 = e0 + wcells;
-            st[wcells + c] = (float)((lx > 0 ? e0[c - 1] : 0.0) - e0[c]);
-            st[2 * wcells + c] = (float)((ly > 0 ? e1[c - q.win_w] : 0.0) - e1[c]);
+            st[wcells + c] = diff(lx > 0 ? e0 + c - 1 : nullptr, e0 + c);
+            st[2 * wcells + c] = diff(ly > 0 ? e1 + c - q.win_w : nullptr, e1 + c);
         }
         if constexpr (MODE == 2) {
-            st[wcells + c] = (float)win[wcells + c];
-            st[2 * wcells + c] = (float)win[2 * wcells + c];
+            st[wcells + c] = cell(win + wcells + c);
+            st[2 * wcells + c] = cell(win + 2 * wcells + c);
         }
     }
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
@@ -760,8 +787,8 @@ extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices
 static int launch_iwe_tiled(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                             int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
                             const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h,
-                            int canvas_w, uint32_t flags, double p_scale, void *staging, int64_t staging_bytes,
-                            float *iwe, float *diwe, void *stream) {
+                            int canvas_w, uint32_t flags, double p_scale, double acc_bound, void *staging,
+                            int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_index || !iwe || !staging)
         return EVK_EINVAL;
@@ -789,22 +816,39 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     }
     q.sx_lo = (int)floor(dx_lo) - 1, q.sx_hi = (int)floor(dx_hi) - 1;
     q.sy_lo = (int)floor(dy_lo) - 1, q.sy_hi = (int)floor(dy_hi) - 1;
+    // fixed-point LDS accumulation when the caller can bound every cell sum (acc_bound >= n * max|contribution|)
+    int k = 0;
+    if (acc_bound > 0.0 && acc_bound < 1e300) {
+        int e;
+        (void)frexp(acc_bound, &e);  // acc_bound < 2^e
+        k = 61 - e;
+        if (k > 40) k = 40;
+    }
+    const bool fixed = k >= 26;
+    q.fx_scale = fixed ? ldexp(1.0, k) : 0.0;
+    q.fx_inv = fixed ? ldexp(1.0, -k) : 0.0;
     const int nwin = bucket_max_items(n, ntiles) * slices;
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;
     const int ggrid = stream_grid((int64_t)canvas_h * canvas_w);
     const float4 *rec = (const float4 *)records;
+#define EVK_IWE_LAUNCH(M)                                                                                          \
+    do {                                                                                                           \
+        if (fixed) k_iwe_tiled<M, true><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
+        else k_iwe_tiled<M, false><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
+    } while (0)
     if (mode == 0) {
-        k_iwe_tiled<0><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
+        EVK_IWE_LAUNCH(0);
         k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
                                                        canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
     } else {
-        if (mode == 1) k_iwe_tiled<1><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
-        else k_iwe_tiled<2><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);
+        if (mode == 1) EVK_IWE_LAUNCH(1);
+        else EVK_IWE_LAUNCH(2);
         k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
     }
+#undef EVK_IWE_LAUNCH
     return launch_status();
 }
 
@@ -812,20 +856,21 @@ extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bu
                                         int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
                                         double t_first, double t_ref, double vx, double vy, double bounds_w,
                                         double bounds_h, int canvas_h, int canvas_w, uint32_t flags, double p_scale,
-                                        void *staging, int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
+                                        double acc_bound, void *staging, int64_t staging_bytes, float *iwe,
+                                        float *diwe, void *stream) {
     return launch_iwe_tiled((flags & EVK_IWE_GRADIENT) ? 1 : 0, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2,
                             slices, win_w, win_h, t_first, t_ref, &vx, &vy, bounds_w, bounds_h, canvas_h, canvas_w,
-                            flags, p_scale, staging, staging_bytes, iwe, diwe, stream);
+                            flags, p_scale, acc_bound, staging, staging_bytes, iwe, diwe, stream);
 }
 
 extern "C" int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
                                                int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
                                                double t_first, double t_ref, const double *host_vx,
                                                const double *host_vy, double bounds_w, double bounds_h, int canvas_h,
-                                               int canvas_w, uint32_t flags, double p_scale, void *staging,
-                                               int64_t staging_bytes, float *iwe3, void *stream) {
+                                               int canvas_w, uint32_t flags, double p_scale, double acc_bound,
+                                               void *staging, int64_t staging_bytes, float *iwe3, void *stream) {
     if (!host_vx || !host_vy || !iwe3 || (flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
     return launch_iwe_tiled(2, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
-                            t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, staging,
-                            staging_bytes, iwe3, iwe3 + (size_t)canvas_h * canvas_w, stream);
+                            t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, acc_bound,
+                            staging, staging_bytes, iwe3, iwe3 + (size_t)canvas_h * canvas_w, stream);
 }

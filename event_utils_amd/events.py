@@ -24,6 +24,7 @@ class DeviceEvents:
         self._t_host = t_host          # optional host copy of t (float64) for cheap ts[k] / searchsorted
         self.p_scale = 1.0             # adaptive lifespan multiplies ps by 100 (objectives.py:225), folded here
         self._buckets = {}             # cache of tile-bucketed layouts (see tiled.py)
+        self._p_absmax = None
 
     # -- construction --------------------------------------------------------------------------------------
     @classmethod
@@ -62,6 +63,12 @@ class DeviceEvents:
             self._t_host = self.t.double().cpu().numpy()
         return self._t_host
 
+    def p_absmax(self):
+        """max |p| (one device reduction, cached): bounds the accumulator sums for fixed-point LDS accumulation."""
+        if self._p_absmax is None:
+            self._p_absmax = float(self.p.abs().max().item()) if len(self) else 0.0
+        return self._p_absmax
+
     def slice(self, start, stop):
         """View of events [start:stop) (python slice semantics, no copy)."""
         sl = slice(start, stop)
@@ -74,4 +81,5 @@ class DeviceEvents:
         ev = DeviceEvents(self.x, self.y, self.t, self.p, t_host=self._t_host)
         ev.p_scale = self.p_scale * factor
         ev._buckets = self._buckets
+        ev._p_absmax = self._p_absmax
         return ev

@@ -174,8 +174,13 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
         import numpy as np
         keep = (np.ascontiguousarray(vxs, dtype=np.float64), np.ascontiguousarray(vys, dtype=np.float64))
         flow = (D.host_ptr(keep[0]), D.host_ptr(keep[1]))
+    # bound of any accumulator cell: every event in one pixel, weight |p| * p_scale (* |dt| for the derivative planes);
+    # lets the kernel accumulate in 64-bit fixed point (EVK_IWE_FIXED=0 keeps float64 accumulation)
+    acc_bound = 0.0
+    if os.environ.get("EVK_IWE_FIXED", "1") != "0":
+        acc_bound = float(len(ev)) * ev.p_absmax() * abs(float(ev.p_scale)) * max(1.0, span)
     head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
-        flow + (bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale))
+        flow + (bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale), acc_bound)
     return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk, "keep": keep}
 
 
