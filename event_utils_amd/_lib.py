@@ -27,6 +27,7 @@ SIGNATURES = {
     "evk_voxel_segments_f32": [P, P, P, P, P, c_int, c_int64, c_int, c_int, c_int, P, P, P],
     "evk_voxel_f64": [P, P, P, P, c_int64, c_double, c_double, c_int, c_int, c_int, P, P, P],
     "evk_warp_linvel_f64": [P, P, P, c_int64, c_double, c_double, c_double, P, P, P, P, P],
+    "evk_warp_flow_field_f32": [P, P, P, c_int64, P, c_int, c_int, c_float, P, P, P],
     "evk_bounds_mask_f64": [P, P, c_int64, c_double, c_double, c_double, c_double, P, P],
     "evk_iwe_linvel_f32": [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, c_int,
                            c_uint32, c_double, P, P, P],

@@ -289,6 +289,44 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_timestamp_images_f32(const float 
     }
 }
 
+// warp_events_flow_torch (lib/transforms/optic_flow.py:5-46): bilinear sample of a dense (2, h, wd) flow field at the
+// event position (F.grid_sample semantics: align_corners=True, zero padding; the coordinate is normalised to [-1, 1] and
+// un-normalised again, both in float32, :38-39), then x' = x + flow_x * (t - t0), y' = y + flow_y * (t - t0).
+__global__ void __launch_bounds__(EVK_BLOCK) k_warp_flow_field_f32(const float *__restrict__ x,
+                                                                   const float *__restrict__ y,
+                                                                   const float *__restrict__ t, int64_t n,
+                                                                   const float *__restrict__ flow, int h, int wd,
+                                                                   float t0, float *__restrict__ xo,
+                                                                   float *__restrict__ yo) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = (int64_t)h * wd;
+    const float wm1 = (float)(wd - 1), hm1 = (float)(h - 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xv = x[i], yv = y[i];
+        const float gx = xv / wm1 * 2.0f - 1.0f, gy = yv / hm1 * 2.0f - 1.0f;
+        const float ix = (gx + 1.0f) / 2.0f * wm1, iy = (gy + 1.0f) / 2.0f * hm1;
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float w = ix - xw, e = 1.0f - w, nn = iy - yn, ss = 1.0f - nn;
+        const int x0 = (int)xw, y0 = (int)yn;
+        float f[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float *fl = flow + c * plane;
+            auto at = [&](int yy, int xx) -> float {
+                return (xx >= 0 && xx < wd && yy >= 0 && yy < h) ? fl[(int64_t)yy * wd + xx] : 0.0f;
+            };
+            float acc = at(y0, x0) * (e * ss);
+            acc = acc + at(y0, x0 + 1) * (w * ss);
+            acc = acc + at(y0 + 1, x0) * (e * nn);
+            acc = acc + at(y0 + 1, x0 + 1) * (w * nn);
+            f[c] = acc;
+        }
+        const float dt = t[i] - t0;
+        xo[i] = xv + f[0] * dt;
+        yo[i] = yv + f[1] * dt;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // voxel grid: single pass, <= 2 bins per event
 // ---------------------------------------------------------------------------------------------------------
@@ -618,6 +656,14 @@ extern "C" int evk_timestamp_images_f32(const float *x, const float *y, const fl
     if (n == 0) return EVK_OK;
     k_timestamp_images_f32<<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, n, h, wd, clipx, clipy, mode,
                                                                               ta, td, out4, oob);
+    return launch_status();
+}
+
+extern "C" int evk_warp_flow_field_f32(const float *x, const float *y, const float *t, int64_t n, const float *flow,
+                                       int h, int wd, float t0, float *xo, float *yo, void *stream) {
+    if (n < 0 || h <= 1 || wd <= 1 || !flow || (n > 0 && (!x || !y || !t || !xo || !yo))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_warp_flow_field_f32<<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, n, flow, h, wd, t0, xo, yo);
     return launch_status();
 }
 

@@ -135,6 +135,11 @@ int evk_voxel_f64(const int32_t *x, const int32_t *y, const double *t, const dou
 int evk_warp_linvel_f64(const double *x, const double *y, const double *t, int64_t n, double t0, double vx,
                         double vy, double *xo, double *yo, double *jx, double *jy, void *stream);
 
+/* warp_events_flow_torch (lib/transforms/optic_flow.py:5-46): per-pixel flow field (2, h, wd) float32 sampled bilinearly
+ * at every event (grid_sample, align_corners=True, zero padding), xo = x + flow_x(x, y) * (t - t0), same for y. */
+int evk_warp_flow_field_f32(const float *x, const float *y, const float *t, int64_t n, const float *flow, int h, int wd,
+                            float t0, float *xo, float *yo, void *stream);
+
 /* events_bounds_mask (event_util.py:15-28): mask = !(x<=xmin || x>xmax) * !(y<=ymin || y>ymax) as 0.0/1.0. */
 int evk_bounds_mask_f64(const double *x, const double *y, int64_t n, double xmin, double xmax, double ymin,
                         double ymax, double *mask, void *stream);

@@ -215,6 +215,19 @@ def main():
         out["ti_t_pos_rev%d" % rev], out["ti_t_neg_rev%d" % rev] = a.numpy(), b.numpy()
     save("f11_gather_timestamp", **out)
 
+    # ---- F13 dense-flow warp (lib/transforms/optic_flow.py) ---------------------------------------------
+    H, Wd, n = 60, 80, 5000
+    rng = np.random.default_rng(130)
+    fx_, fy_, ft_ = (rng.uniform(-3, Wd + 2, n).astype(np.float32), rng.uniform(-3, H + 2, n).astype(np.float32),
+                     np.sort(rng.uniform(0, 0.1, n)).astype(np.float32))
+    flow = rng.normal(0, 30, size=(2, H, Wd)).astype(np.float32)
+    xw, yw = ref.optic_flow.warp_events_flow_torch(torch.from_numpy(fx_), torch.from_numpy(fy_), torch.from_numpy(ft_),
+                                                   torch.ones(n), torch.from_numpy(flow))
+    xw2, yw2 = ref.optic_flow.warp_events_flow_torch(torch.from_numpy(fx_), torch.from_numpy(fy_), torch.from_numpy(ft_),
+                                                     torch.ones(n), torch.from_numpy(flow), t0=0.02)
+    save("f13_flow_warp", xs=fx_, ys=fy_, ts=ft_, flow=flow, xw=xw.numpy(), yw=yw.numpy(), xw_t0=xw2.numpy(),
+         yw_t0=yw2.numpy(), versions=versions)
+
     # ---- F10 gaussian_filter (2-D and 3-D two-channel) ----------------------------------------------
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(100)

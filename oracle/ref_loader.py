@@ -127,8 +127,9 @@ def load():
         events_cmax = None
         _cache["events_cmax_error"] = repr(e)
 
+    optic_flow = importlib.import_module("lib.transforms.optic_flow")
     ns = types.SimpleNamespace(image=image, voxel_grid=voxel_grid, event_util=event_util,
-                               warps=warps, objectives=objectives, events_cmax=events_cmax)
+                               warps=warps, objectives=objectives, events_cmax=events_cmax, optic_flow=optic_flow)
     _cache["ns"] = ns
     return ns
 

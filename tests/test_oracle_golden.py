@@ -207,3 +207,14 @@ def test_f12_other_objectives(golden):
     P = g["params"]
     vals = [np.float64(r1.evaluate_function(q, x, y, t, p, w, (180, 240))) for q in (P[0], P[1], P[1], P[2])]
     assert np.array_equal(np.array(vals), g["r1_f"])
+
+
+def test_f13_dense_flow_warp(golden):
+    """torch's vectorised grid_sample contracts multiplies and adds differently from a plain float32 evaluation, so this
+    row is pinned to 1 ulp of the coordinates (2e-7 relative), not bit-exactly."""
+    g = golden("f13_flow_warp")
+    xw, yw = R.warp_events_flow_torch(g["xs"], g["ys"], g["ts"], None, g["flow"])
+    assert np.max(np.abs(xw - g["xw"])) <= 2e-7 * np.max(np.abs(g["xw"]))
+    assert np.max(np.abs(yw - g["yw"])) <= 2e-7 * np.max(np.abs(g["yw"]))
+    xw, yw = R.warp_events_flow_torch(g["xs"], g["ys"], g["ts"], None, g["flow"], t0=0.02)
+    assert np.max(np.abs(xw - g["xw_t0"])) <= 2e-7 * np.max(np.abs(g["xw_t0"]))
