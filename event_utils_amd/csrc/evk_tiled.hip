@@ -528,11 +528,14 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
     auto lds_acc = [&](acc_t *cell, float v) {
-        if constexpr (FIXED)
-            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(cell),
-                                   (unsigned long long)__double2ll_rn((double)v * q.fx_scale), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-        else
+        if constexpr (FIXED) {
+            // round-to-nearest double -> int64 with one add: for |x| < 2^51 the low mantissa bits of x + 1.5*2^52 hold
+            // x as a two's-complement integer (the host caps k so that every contribution satisfies |x| < 2^50)
+            const double magic = 6755399441055744.0;
+            const long long fx = __double_as_longlong((double)v * q.fx_scale + magic) - __double_as_longlong(magic);
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)fx,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else
             lds_add(cell, v);
     };
     // one flow, one IWE plane (`wp` in LDS, `gp` in the image); GRAD adds the derivative planes behind it
@@ -823,6 +826,10 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
         (void)frexp(acc_bound, &e);  // acc_bound < 2^e
         k = 61 - e;
         if (k > 40) k = 40;
+        // one contribution is at most acc_bound / n: keep |contribution * 2^k| < 2^50 for the one-add conversion
+        int e1;
+        (void)frexp(acc_bound / (double)(n > 0 ? n : 1), &e1);
+        if (k > 50 - e1) k = 50 - e1;
     }
     const bool fixed = k >= 26;
     q.fx_scale = fixed ? ldexp(1.0, k) : 0.0;
