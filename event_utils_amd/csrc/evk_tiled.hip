@@ -621,8 +621,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
 }
 
-// Gather: every canvas pixel sums the staged windows that cover it (candidates: tiles whose window, shifted by at
-// most max_shift, can reach the pixel) and ADDS the sum to the image (which already holds the rare direct atomics).
+// Gather: every canvas pixel sums the staged windows that cover it and ADDS the sum to the image (which already holds
+// the rare direct atomics).  One workgroup per 32x8 pixel patch: the windows that can reach the patch (tiles whose
+// window, shifted by at most [s_lo, s_hi], intersects it; all their work items and time slices) are listed once in LDS
+// (sorted by window id, so the float32 summation order is fixed), then every pixel walks that short list.
+#define EVK_GATHER_PX 32
+#define EVK_GATHER_PY 8
+#define EVK_GATHER_CAP 128
 template <bool GRAD>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restrict__ staging,
                                                           const int4 *__restrict__ origins,
@@ -631,21 +636,61 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
                                                           int sy_lo, int sy_hi, float *__restrict__ iwe,
                                                           float *__restrict__ diwe) {
     constexpr int PLANES = GRAD ? 3 : 1;
+    __shared__ int list_w[EVK_GATHER_CAP], list_x[EVK_GATHER_CAP], list_y[EVK_GATHER_CAP];
+    __shared__ int count;
     const int wcells = win_w * win_h;
     const int64_t plane = (int64_t)ch * cw;
     const uint32_t *part_start = index + IDX_PART(g.tiles_x * g.tiles_y);
-    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < plane;
-         pix += (int64_t)gridDim.x * blockDim.x) {
-        const int X = (int)(pix % cw), Y = (int)(pix / cw);
-        // a window starts at tile_origin + shift, shift in [s_lo, s_hi] (clamped by k_iwe_tiled): tile tx can cover X
-        // iff tx*tw + s_lo <= X < tx*tw + s_hi + win_w
-        const int tx_a = (X - sx_hi - win_w + 1) >> g.tw_log2, tx_b = (X - sx_lo) >> g.tw_log2;
-        const int ty_a = (Y - sy_hi - win_h + 1) >> g.th_log2, ty_b = (Y - sy_lo) >> g.th_log2;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        for (int ty = ty_a; ty <= ty_b; ++ty) {
-            if (ty < 0 || ty >= g.tiles_y) continue;
+    const int patches_x = (cw + EVK_GATHER_PX - 1) / EVK_GATHER_PX;
+    const int X0 = (blockIdx.x % patches_x) * EVK_GATHER_PX, Y0 = (blockIdx.x / patches_x) * EVK_GATHER_PY;
+    const int X1 = min(X0 + EVK_GATHER_PX, cw) - 1, Y1 = min(Y0 + EVK_GATHER_PY, ch) - 1;  // inclusive
+    // a window starts at tile_origin + shift, shift in [s_lo, s_hi] (clamped by k_iwe_tiled): tile tx can reach the
+    // patch columns [X0, X1] iff tx*tw + s_lo <= X1 and X0 < tx*tw + s_hi + win_w
+    const int tx_a = max((X0 - sx_hi - win_w + 1) >> g.tw_log2, 0), tx_b = min((X1 - sx_lo) >> g.tw_log2, g.tiles_x - 1);
+    const int ty_a = max((Y0 - sy_hi - win_h + 1) >> g.th_log2, 0), ty_b = min((Y1 - sy_lo) >> g.th_log2, g.tiles_y - 1);
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    const int ntx = tx_b - tx_a + 1, nty = ty_b - ty_a + 1;
+    for (int c = threadIdx.x; c < ntx * nty; c += EVK_BLOCK) {
+        const int tile = (ty_a + c / ntx) * g.tiles_x + tx_a + c % ntx;
+        const int w0 = (int)part_start[tile] * slices, w1 = (int)part_start[tile + 1] * slices;
+        for (int w = w0; w < w1; ++w) {
+            const int4 o = origins[w];
+            if (!o.z || o.x > X1 || o.x + win_w <= X0 || o.y > Y1 || o.y + win_h <= Y0) continue;
+            const int k = atomicAdd(&count, 1);
+            if (k < EVK_GATHER_CAP) list_w[k] = w, list_x[k] = o.x, list_y[k] = o.y;
+        }
+    }
+    __syncthreads();
+    const int nlist = count;
+    const int X = X0 + (threadIdx.x & (EVK_GATHER_PX - 1)), Y = Y0 + threadIdx.x / EVK_GATHER_PX;
+    const bool inside = X < cw && Y < ch;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (nlist <= EVK_GATHER_CAP) {
+        if (threadIdx.x == 0) {  // insertion sort by window id: a fixed summation order (lists are a handful of entries)
+            for (int i = 1; i < nlist; ++i) {
+                const int w = list_w[i], x = list_x[i], y = list_y[i];
+                int j = i - 1;
+                for (; j >= 0 && list_w[j] > w; --j) list_w[j + 1] = list_w[j], list_x[j + 1] = list_x[j], list_y[j + 1] = list_y[j];
+                list_w[j + 1] = w, list_x[j + 1] = x, list_y[j + 1] = y;
+            }
+        }
+        __syncthreads();
+        if (inside) {
+            for (int k = 0; k < nlist; ++k) {
+                const int lx = X - list_x[k], ly = Y - list_y[k];
+                if (lx < 0 || ly < 0 || lx >= win_w || ly >= win_h) continue;
+                const float *st = staging + (int64_t)list_w[k] * PLANES * wcells + ly * win_w + lx;
+                s0 += st[0];
+                if constexpr (GRAD) {
+                    s1 += st[wcells];
+                    s2 += st[2 * wcells];
+                }
+            }
+        }
+    } else if (inside) {  // more candidate windows than the LDS list holds (huge flows / many slices): walk them all
+        for (int ty = ty_a; ty <= ty_b; ++ty)
             for (int tx = tx_a; tx <= tx_b; ++tx) {
-                if (tx < 0 || tx >= g.tiles_x) continue;
                 const int tile = ty * g.tiles_x + tx;
                 const int w0 = (int)part_start[tile] * slices, w1 = (int)part_start[tile + 1] * slices;
                 for (int w = w0; w < w1; ++w) {
@@ -661,7 +706,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
                     }
                 }
             }
-        }
+    }
+    if (inside) {
+        const int64_t pix = (int64_t)Y * cw + X;
         iwe[pix] += s0;
         if constexpr (GRAD) {
             diwe[pix] += s1;
@@ -838,7 +885,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;
-    const int ggrid = stream_grid((int64_t)canvas_h * canvas_w);
+    const int ggrid = ((canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX) * ((canvas_h + EVK_GATHER_PY - 1) / EVK_GATHER_PY);
     const float4 *rec = (const float4 *)records;
 #define EVK_IWE_LAUNCH(M)                                                                                          \
     do {                                                                                                           \
