@@ -16,8 +16,22 @@ def require_gpu():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+try:                                   # fast path to the current stream handle (what torch.compile / triton use)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                 # pragma: no cover
+    _raw_stream = None
+
+
+def stream_id(device=None):
+    """hipStream_t of torch's current stream on `device` (int)."""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(stream_id())
 
 
 def ptr(t):
@@ -73,7 +87,7 @@ _scratch = {}
 
 
 def reduce_scratch(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "reduce")
+    key = (device.index, stream_id(device), "reduce")
     if key not in _scratch:
         nbytes = int(_lib.lib().evk_reduce_scratch_bytes())
         _scratch[key] = (torch.empty(nbytes // 8, dtype=torch.float64, device=device), nbytes)
@@ -82,7 +96,7 @@ def reduce_scratch(device):
 
 def out4(device, n=4):
     """Persistent n-double device result slot (objective evaluations return a few scalars)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "out%d" % n)
+    key = (device.index, stream_id(device), "out%d" % n)
     if key not in _scratch:
         _scratch[key] = torch.empty(n, dtype=torch.float64, device=device)
     return _scratch[key]

@@ -19,12 +19,13 @@ TILED_MIN_EVENTS = 350_000
 TILED_MIN_EVENTS_IWE = 150_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
+_staging_bytes = {}
 
 
 def _buf(key, nbytes, device):
     """Grow-only persistent device scratch (avoids re-allocating tens of MB per objective evaluation)."""
     import torch
-    k = (key, device.index, torch.cuda.current_stream(device).cuda_stream)   # per stream: calls are stream-ordered
+    k = (key, device.index, D.stream_id(device))   # per stream: calls are stream-ordered
     b = _persist.get(k)
     if b is None or b.numel() < nbytes:
         b = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
@@ -163,7 +164,10 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     if bk is None:
         bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
         ev._buckets[key] = bk
-    nbytes = int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, bk.n, S, planes, win_w, win_h))
+    skey = (bk.ntiles, bk.n, S, planes, win_w, win_h)
+    nbytes = _staging_bytes.get(skey)
+    if nbytes is None:
+        nbytes = _staging_bytes[skey] = int(_lib.lib().evk_iwe_tiled_staging_bytes(*skey))
     staging = _buf("iwe_staging", nbytes, ev.x.device)
     # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32 (the batch entry points take
     # two host arrays instead of the scalars vx, vy)
