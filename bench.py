@@ -60,7 +60,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # EVK_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1) drives the N > 1 code path -- process group, async
+    # all-reduce, barriers -- on a single GPU: a smoke test of the scaling harness where only one GPU is available
+    use_dist = world > 1 or os.environ.get("EVK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -76,7 +79,7 @@ def main():
     x, y, t, p = synth(1 + rank, n, rank * span, (rank + 1) * span)
     xd, yd, td, pd = (torch.from_numpy(a).to(dev) for a in (x, y, t, p))
     t_first, t_last = 0.0, 0.1
-    if world > 1:   # global ts[0] / ts[-1]: two scalars, agreed once outside the timed region
+    if use_dist:   # global ts[0] / ts[-1]: two scalars, agreed once outside the timed region
         lo = torch.tensor([float(t[0])], device=dev)
         hi = torch.tensor([float(t[-1])], device=dev)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -88,7 +91,7 @@ def main():
     impl = args.impl or tiled.default_impl()
     # N > 1: the all-reduce of step i (RCCL, its own stream) overlaps the kernels of step i+1 (double-buffered grids);
     # every grid is fully reduced before the clock stops.  EVK_BENCH_SYNC_ALLREDUCE=1 serialises them instead.
-    overlap = world > 1 and os.environ.get("EVK_BENCH_SYNC_ALLREDUCE", "0") != "1"
+    overlap = use_dist and os.environ.get("EVK_BENCH_SYNC_ALLREDUCE", "0") != "1"
     outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2 if overlap else 1)]
     works = [None] * len(outs)
     out = outs[0]
@@ -101,7 +104,7 @@ def main():
             works[k].wait()          # stream-level: this buffer's previous all-reduce has finished
             works[k] = None
         _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=outs[k], check=False, impl=impl, fresh=True)
-        if world > 1:
+        if use_dist:
             if overlap:
                 works[k] = dist.all_reduce(outs[k], op=dist.ReduceOp.SUM, async_op=True)
             else:
@@ -116,7 +119,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -128,10 +131,10 @@ def main():
         ev1[i].record()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -162,7 +165,7 @@ def main():
                    "events_per_gpu": n, "sensor": [H, W], "bins": B, "impl": kinfo["impl"],
                    "parallelism": ("event-sharded x%d, RCCL all-reduce of the (B,H,W) grid per step%s"
                                    % (world, ", overlapped with the next step's kernels" if overlap else ""))
-                   if world > 1 else "single GPU"},
+                   if use_dist else "single GPU"},
         "device_ms_per_step": round(dev_ms, 4),
         "roofline": roofline,
     }
@@ -173,7 +176,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(x, y, t, p)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,92 @@
+"""GPU (-m gpu): the event-sharded code paths on a real device with a 1-rank RCCL group (the box has one GPU): the
+all-reduce is then the identity, but everything else -- global time range, shard objective at a global t_ref, IWE+dIWE
+all-reduced in one buffer before the replicated blur / reductions -- runs exactly as with N ranks.  Shard additivity
+(the property that makes N > 1 legal) is checked by emulating two ranks sequentially."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+
+pytestmark = pytest.mark.gpu
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _events(seed, n, H, W):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    return x, y, t, p
+
+
+def test_sharded_voxel_and_objective_with_rccl_group(pg):
+    import event_utils_amd as E
+    from event_utils_amd import distributed as DD
+    from event_utils_amd.events import DeviceEvents
+    H, W, B, n = 120, 160, 5, 400_000
+    x, y, t, p = _events(0, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (np.floor(x), np.floor(y), t, p)]
+    vox = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
+    ref = R.events_to_voxel_torch(np.floor(x), np.floor(y), t, p, B, sensor_size=(H, W), accum="f64")
+    assert np.abs(vox.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    # objective configured for event sharding: global t_ref, all-reduce of the (3, H+1, W+1) buffer before blur
+    obj = DD.shard_objective(E.variance_objective(), float(t[-1]))
+    obj.sensor_size = (H, W)
+    ev = DeviceEvents.from_arrays(x, y, t, p)
+    w, prm = E.linvel_warp(), np.array([30., -20.])
+    f = float(obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0))
+    g = f64(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0))
+    robj = R.variance_objective(); robj.sensor_size = (H, W); robj.accum = "f64"
+    d = [f64(a) for a in (x, y, t, p)]
+    fr = float(robj.evaluate_function(prm, *d, R.linvel_warp(), (H, W), 1.0))
+    gr = f64(robj.evaluate_gradient(prm, *d, R.linvel_warp(), (H, W), 1.0))
+    assert abs(f - fr) <= 1e-5 * abs(fr) and np.abs(g - gr).max() <= 1e-5 * np.abs(gr).max() + 1e-9
+
+
+def test_two_emulated_ranks_are_additive():
+    """rank 0 and rank 1 evaluated one after the other on the same GPU: summing their IWE / dIWE / voxel grids gives the
+    single-rank result (what the all-reduce computes), with every rank warping to the GLOBAL reference time."""
+    import event_utils_amd as E
+    from event_utils_amd import distributed as DD
+    from event_utils_amd.contrast_max.objectives import iwe_device
+    from event_utils_amd.events import DeviceEvents
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    H, W, B, n = 120, 160, 5, 500_000
+    x, y, t, p = _events(1, n, H, W)
+    prm = np.array([-45., 25.])
+    full_ev = DeviceEvents.from_arrays(x, y, t, p)
+    iwe_full, d_full = iwe_device(prm, full_ev, (H, W), True, True, (H, W))
+    parts = []
+    for rank in range(2):
+        lo, hi = DD.shard_bounds(n, rank, 2)
+        ev = DeviceEvents.from_arrays(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi])
+        parts.append(iwe_device(prm, ev, (H, W), True, True, (H, W), t_ref=float(t[-1])))
+    iwe = parts[0][0] + parts[1][0]
+    diwe = parts[0][1] + parts[1][1]
+    assert (iwe - iwe_full).abs().max().item() <= 1e-5 * iwe_full.abs().max().item()
+    assert (diwe - d_full).abs().max().item() <= 1e-5 * d_full.abs().max().item()
+    cols = [torch.from_numpy(a).cuda() for a in (np.floor(x), np.floor(y), t, p)]
+    full = _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]))
+    acc = torch.zeros_like(full)
+    for rank in range(2):
+        lo, hi = DD.shard_bounds(n, rank, 2)
+        acc += _voxel_f32_device(*(c[lo:hi] for c in cols), B, (H, W), float(t[0]), float(t[-1]))
+    assert (acc - full).abs().max().item() <= 1e-5 * full.abs().max().item()
