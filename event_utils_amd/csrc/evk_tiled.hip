@@ -261,11 +261,14 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const fl
     extern __shared__ __attribute__((aligned(16))) float4 ring[];  // [ntiles][R]
     uint32_t *cursor = reinterpret_cast<uint32_t *>(ring + (size_t)ntiles * R);
     uint32_t *vstart = cursor + ntiles;
+    uint32_t *work_count = vstart + ntiles;
+    unsigned short *work = reinterpret_cast<unsigned short *>(work_count + 1);  // queue of tiles to flush (ids < 8192)
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
         const uint32_t c = bucket_start[i] + table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x];
         cursor[i] = c;
         vstart[i] = c;
     }
+    if (threadIdx.x == 0) *work_count = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     int64_t hi = lo + chunk;
@@ -306,20 +309,32 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const fl
             }
         }
         __syncthreads();
-        // flush: R consecutive lanes serve one tile; the last pass (ph == nphase) drains everything
+        // Flush in two steps (the kernel is instruction-bound: scanning all tiles with R lanes each cost more
+        // wave-instructions than placing the events).  Step 1: one LANE per tile decides whether the tile has a
+        // complete aligned granule (or, on the last pass, anything left) and queues it.  Step 2: R consecutive lanes
+        // per queued tile copy its records out as one contiguous piece.
         const bool last = (ph == nphase);
-        const int sub = threadIdx.x & (R - 1);
-        for (int k = threadIdx.x / R; k < ntiles; k += blockDim.x / R) {
-            const uint32_t vs = vstart[k], c = cursor[k];
-            uint32_t end;  // flush positions [vs, end)
-            if (c - vs >= (uint32_t)R) end = vs + R;          // window full (overflow went direct): drain it
-            else if (last) end = c;
-            else end = (c / G) * G;                           // complete aligned granules only
-            const uint32_t pos = vs + sub;
-            if (end > vs && pos < end) rec[pos] = ring[(size_t)k * R + (pos & (R - 1))];
-            if (sub == 0 && end > vs) vstart[k] = (c - vs >= (uint32_t)R) ? c : end;
+        auto flush_end = [&](uint32_t vs, uint32_t c) -> uint32_t {  // flush positions [vs, end)
+            if (c - vs >= (uint32_t)R) return vs + R;               // window full (overflow went direct): drain it
+            if (last) return c;
+            return (c / G) * G;                                     // complete aligned granules only
+        };
+        for (int k = threadIdx.x; k < ntiles; k += blockDim.x) {
+            const uint32_t vs = vstart[k];
+            if (flush_end(vs, cursor[k]) > vs) work[atomicAdd(work_count, 1u)] = (unsigned short)k;
         }
         __syncthreads();
+        const uint32_t nwork = *work_count;
+        const int sub = threadIdx.x & (R - 1);
+        for (uint32_t w = threadIdx.x / R; w < nwork; w += blockDim.x / R) {
+            const int k = work[w];
+            const uint32_t vs = vstart[k], c = cursor[k], end = flush_end(vs, c);
+            const uint32_t pos = vs + sub;
+            if (pos < end) rec[pos] = ring[(size_t)k * R + (pos & (R - 1))];
+            if (sub == 0) vstart[k] = (c - vs >= (uint32_t)R) ? c : end;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *work_count = 0;  // visible to step 1 of the next phase through its append barrier
     }
 }
 
@@ -783,10 +798,10 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     const size_t lds_budget = (160 * 1024) / (EVK_BUCKET_BLOCKS / 256) - 256;  // all partition blocks co-resident
     int R = 0;
     for (int r : {16, 8, 4})
-        if (!R && (size_t)ntiles * (r * 16 + 8) <= lds_budget) R = r;
+        if (!R && (size_t)ntiles * (r * 16 + 10) + 8 <= lds_budget) R = r;
     if (variant == 0) R = 0;
-    if (variant > 0 && (size_t)ntiles * (variant * 16 + 8) <= lds_budget) R = variant;
-    const size_t lds_wc = (size_t)ntiles * (R * 16 + 8);
+    if (variant > 0 && (size_t)ntiles * (variant * 16 + 10) + 8 <= lds_budget) R = variant;
+    const size_t lds_wc = (size_t)ntiles * (R * 16 + 10) + 8;  // rings + cursor + vstart + flush queue
 #define EVK_SCATTER_WC(RR)                                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
