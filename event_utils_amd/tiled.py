@@ -105,6 +105,12 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     impl = impl or default_impl()
     if can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
+        if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:     # sensors beyond 8192 tiles: enlarge the tiles
+            tw, th = next(((a, b) for a, b in ((5, 5), (6, 5), (6, 6))
+                           if _lib.lib().evk_bucket_num_tiles(H, W, a, b) > 0 and B * 8 << (a + b) <= 65536), (0, 0))
+    else:
+        tw = 0
+    if tw:
         bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
         voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh)
         return out
@@ -150,6 +156,8 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     dom_h = max(int(bounds_h) + 1, ch)
     dom_w = max(int(bounds_w) + 1, cw)
     tw, th = iwe_tile_shape(dom_h, dom_w)
+    if _lib.lib().evk_bucket_num_tiles(dom_h, dom_w, tw, th) <= 0:   # more than 8192 tiles: direct kernel
+        return None
     t_first = ev.t_at(0)
     planes = 3 if (flags & _lib.EVK_IWE_GRADIENT or batch is not None) else 1
     span = abs(t_first - t_ref)

@@ -91,6 +91,27 @@ def test_voxel_tiled_errors_and_wrap(E):
     close(v.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("shape", [(2200, 3900, 2), (3000, 4100, 9)])
+def test_voxel_sensors_beyond_the_tile_limit(E, shape):
+    """More than 8192 tiles at the preferred shape: the tiles are enlarged (first case) or, when the enlarged tile's
+    accumulators no longer fit the LDS, the direct kernel takes over (second case) -- never an error."""
+    H, W, B = shape
+    n = 200_000
+    x, y, t, p = _events(3, n, H, W)
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W))
+    close(v.cpu().numpy(), ref)
+
+
+def test_iwe_sensor_beyond_the_tile_limit(E):
+    H, W, n = 3000, 4100, 100_000
+    x, y, t, p = _events(4, n, H, W, real=True)
+    prm = np.array([40., -30.])
+    ref = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), sensor_size=(H, W), accum="f64")[0]
+    iwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), (H, W), sensor_size=(H, W))[0]
+    close(iwe, ref)
+
+
 def test_voxel_tiled_equals_direct_at_full_size(E, monkeypatch):
     """configs[1] at full size: 10M events, 640x480x5; tiled vs direct (both HIP) and mass conservation."""
     H, W, B, n = 480, 640, 5, 10_000_000
