@@ -1,18 +1,175 @@
 """
 Contrast-maximisation drivers.  Reference: lib/contrast_max/events_cmax.py (optimize_contrast :313-346, optimize
-:348-368).  The BFGS loop stays on the host (scipy.optimize.fmin_bfgs, as upstream); the events are uploaded ONCE and
-stay in HBM, every f / f' evaluation is a streaming pass of the fused kernel.
+:348-368, optimize_r2 :370-388, grid_search_initial :241-311, grid_search_optimisation :186-237, find_new_range
+:162-184, draw_objective_function :103-160, grid_cmax :28-76, segmentation_mask_from_d_iwe :78-101).  The search loops
+stay on the host (scipy.optimize.fmin_bfgs / the grid samplers, as upstream); the events are uploaded ONCE and stay in
+HBM, every evaluation is a streaming pass of the fused kernels, and samplers that evaluate many flows on the same
+events go through objective.evaluate_function_batch (three nearby flows per pass, one readback for all of them).
 
-Not provided: grid_search_initial / grid_search_optimisation / optimize_contrast(grid_search_init=True) call an
-undefined `recursive_search` upstream (events_cmax.py:233,336) and cannot run there either; plotting helpers are out of
-scope.
+Upstream these samplers cannot run as shipped: grid_search_optimisation / optimize_contrast(grid_search_init=True)
+call an undefined `recursive_search` (events_cmax.py:233,336), grid_search_initial needs numpy < 1.16
+(np.vstack(map(...)) :294) and draw_objective_function uses `plt` without importing it.  Here `recursive_search` IS
+grid_search_optimisation (the only reading consistent with its docstring); the golden vectors
+(tests/golden/f14_search.npz) were produced by the reference with exactly those three names supplied.
 """
+import copy
+
 import numpy as np
 import scipy.optimize as opt
 
 from ..events import DeviceEvents
-from .objectives import objective_function, variance_objective  # noqa: F401
+from .objectives import get_iwe, objective_function, soe_objective, variance_objective  # noqa: F401
 from .warps import linvel_warp, warp_function  # noqa: F401
+
+
+def _resident(xs, ys, ts, ps, warp_function, objective):
+    """Upload the events once for the fused linear-flow path; plugin warps keep their host arrays."""
+    if getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function):
+        ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
+        return ev, None, None, None
+    return xs, ys, ts, ps
+
+
+def _evaluate_many(objective, params_list, xs, ys, ts, ps, warp_function, img_size, blur_sigma):
+    batch = getattr(objective, "evaluate_function_batch", None)
+    if batch is not None:
+        return batch(params_list, xs, ys, ts, ps, warp_function, img_size, blur_sigma)
+    return [objective.evaluate_function(params=q, xs=xs, ys=ys, ts=ts, ps=ps, warpfunc=warp_function,
+                                        img_size=img_size, blur_sigma=blur_sigma) for q in params_list]
+
+
+def find_new_range(search_axes, param):
+    """New search range on one axis once the best sample `param` is known: from the previous to the next sample
+    position around it, so that all the unsearched domain around it is covered (reference: events_cmax.py:162-184)."""
+    i = np.searchsorted(search_axes, param)
+    if i >= len(search_axes) - 1:
+        below = above = np.abs(search_axes[-1] - search_axes[-2])
+    elif i == 0:
+        below = np.abs(search_axes[0] - search_axes[-1])
+        above = np.abs(search_axes[0] - search_axes[1])
+    else:
+        below = np.abs(search_axes[i] - search_axes[i - 1])
+        above = np.abs(search_axes[i] - search_axes[i + 1])
+    return [param - below, param + above]
+
+
+def grid_search_initial(xs, ys, ts, ps, warp_function, objective_function, img_size, param_ranges=None,
+                        log_scale=True, num_samples_per_param=5):
+    """
+    One level of the SOFAS grid search (reference: events_cmax.py:241-311): sample every parameter axis at
+    num_samples_per_param positions (evenly, or log-spaced = denser near the middle of the range), evaluate the
+    objective (blur_sigma=1.0) at all num_samples_per_param^dims combinations and keep the best one.  Returns the
+    upstream dict: 'params' (sample coordinates, parameter 0 varying fastest), 'eval', 'search_axes', 'min_params',
+    'min_func_eval' (min_params stays None when no evaluation is below 0, as upstream).
+    xs may also be a DeviceEvents (ys, ts, ps are then ignored).
+    """
+    assert num_samples_per_param % 2 == 1
+    half = int(num_samples_per_param / 2.0) + 1
+    if log_scale:
+        steps = np.logspace(0, 2.0, half)[1:]
+        steps = steps / steps[-1]
+    else:
+        steps = np.linspace(0, 1.0, half)[1:]
+    if param_ranges is None:
+        param_ranges = [[-150, 150] for _ in range(warp_function.dims)]
+    axes = []
+    for lo, hi in param_ranges:
+        half_width = (hi - lo) / 2.0
+        mid = lo + half_width
+        axes.append(np.concatenate(((mid - steps * half_width)[::-1], np.array([mid]), mid + steps * half_width)))
+    samples = list(zip(*(np.ravel(g) for g in np.meshgrid(*axes))))
+    xs, ys, ts, ps = _resident(xs, ys, ts, ps, warp_function, objective_function)
+    evals = _evaluate_many(objective_function, samples, xs, ys, ts, ps, warp_function, img_size, 1.0)
+    best_eval, best_params = 0, None
+    for q, f in zip(samples, evals):
+        if f < best_eval:
+            best_eval, best_params = f, q
+    return {"params": samples, "eval": list(evals), "search_axes": axes, "min_params": best_params,
+            "min_func_eval": best_eval}
+
+
+def grid_search_optimisation(xs, ys, ts, ps, warp_function, objective_function, img_size, param_ranges=None,
+                             log_scale=True, num_samples_per_param=5, depth=0, th0=1, max_iters=20):
+    """
+    Recursive grid search as per SOFAS (reference: events_cmax.py:186-237): grid_search_initial on the current ranges,
+    then re-sample the neighbourhood of the best point (find_new_range) until the largest range is below th0 or depth
+    reaches max_iters.  Returns the dict of the last level.  (Like upstream's recursive call, deeper levels use the
+    default th0 / max_iters.)
+    """
+    assert num_samples_per_param % 2 == 1 and num_samples_per_param >= 5
+    xs, ys, ts, ps = _resident(xs, ys, ts, ps, warp_function, objective_function)
+    optimal = grid_search_initial(xs, ys, ts, ps, warp_function, copy.deepcopy(objective_function), img_size,
+                                  param_ranges=param_ranges, log_scale=log_scale,
+                                  num_samples_per_param=num_samples_per_param)
+    new_ranges, widest = [], 0
+    for axis, param in zip(optimal["search_axes"], optimal["min_params"]):
+        r = find_new_range(axis, param)
+        new_ranges.append(r)
+        widest = max(widest, np.abs(r[1] - r[0]))
+    if widest >= th0 and depth < max_iters:
+        return recursive_search(xs, ys, ts, ps, warp_function, objective_function, img_size, param_ranges=new_ranges,
+                                log_scale=log_scale, num_samples_per_param=num_samples_per_param, depth=depth + 1)
+    return optimal
+
+
+recursive_search = grid_search_optimisation      # the name upstream calls (events_cmax.py:233,336)
+
+
+def objective_landscape(xs, ys, ts, ps, objective=None, warpfunc=None, x_range=(-200, 200), y_range=(-200, 200),
+                        resolution=20, img_size=(180, 240), norm_min=None, norm_max=None):
+    """The sampled, normalised image draw_objective_function shows (reference: events_cmax.py:122-133):
+    img[y, x] = -f(x*resolution + x_range[0], y*resolution + y_range[0]) at blur_sigma=0, scaled to [0, 1]."""
+    objective = variance_objective(minimum_events=1) if objective is None else objective
+    warpfunc = linvel_warp() if warpfunc is None else warpfunc
+    width, height = x_range[1] - x_range[0], y_range[1] - y_range[0]
+    shape = (int(height / resolution + 0.5), int(width / resolution + 0.5))
+    samples = [np.array([x * resolution + x_range[0], y * resolution + y_range[0]])
+               for x in range(shape[1]) for y in range(shape[0])]
+    xs, ys, ts, ps = _resident(xs, ys, ts, ps, warpfunc, objective)
+    evals = _evaluate_many(objective, samples, xs, ys, ts, ps, warpfunc, img_size, 0)
+    img = -np.array(evals, dtype=np.float64).reshape(shape[1], shape[0]).T
+    norm_min = np.min(img) if norm_min is None else norm_min
+    norm_max = np.max(img) if norm_max is None else norm_max
+    return (img - norm_min) / ((norm_max - norm_min) + 1e-6)
+
+
+def draw_objective_function(xs, ys, ts, ps, objective=None, warpfunc=None, x_range=(-200, 200), y_range=(-200, 200),
+                            gt=(0, 0), show_gt=True, resolution=20, img_size=(180, 240), show_axes=True, norm_min=None,
+                            norm_max=None, show=True):
+    """Sample the objective over a range of flows and draw it with matplotlib (reference: events_cmax.py:103-160;
+    objective defaults to variance_objective(minimum_events=1), warpfunc to linvel_warp()).  Returns the image
+    (upstream returns None)."""
+    import matplotlib.pyplot as plt
+    img = objective_landscape(xs, ys, ts, ps, objective, warpfunc, x_range, y_range, resolution, img_size, norm_min,
+                              norm_max)
+    width, height = x_range[1] - x_range[0], y_range[1] - y_range[0]
+    plt.imshow(img, interpolation='bilinear', cmap='viridis')
+    if not show_axes:
+        plt.xticks([])
+        plt.yticks([])
+    else:
+        for ticks, rng in ((plt.xticks, x_range), (plt.yticks, y_range)):
+            pos = ticks()[0][1:-1]
+            ticks(ticks=pos, labels=["{}".format(int(v)) for v in np.linspace(rng[0], rng[1], len(pos))])
+        plt.xlabel("$v_x$")
+        plt.ylabel("$v_y$")
+    if show_gt:
+        plt.axhline(y=((gt[1] - y_range[0]) / height) * img.shape[0], color='r', linestyle='--')
+        plt.axvline(x=((gt[0] - x_range[0]) / width) * img.shape[1], color='r', linestyle='--')
+    if show:
+        plt.show()
+    return img
+
+
+def segmentation_mask_from_d_iwe(d_iwe, th=None):
+    """Binary mask of the pixels whose IWE derivative is large in either parameter (reference: events_cmax.py:78-101;
+    thresholds default to the 95th percentile of the values above the 90th percentile of |d_iwe|).  Host-side
+    post-processing of the (2, H+1, W+1) image get_iwe returned, as upstream."""
+    d_iwe = np.asarray(d_iwe)
+    floor = np.percentile(np.abs(d_iwe), 90)
+    th = [np.percentile(c[np.abs(c) > floor], 95) if th is None else th for c in (d_iwe[0].ravel(), d_iwe[1].ravel())]
+    hit = [(d_iwe[k] > th[k]).astype(int) + (d_iwe[k] < -th[k]).astype(int) for k in range(2)]
+    return np.clip(hit[0] + hit[1], 0, 1)
 
 
 def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fmin_bfgs, x0=None, numeric_grads=False,
@@ -22,17 +179,18 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
     x0 = [0, 0], objective.iter_update(x0), then fmin_bfgs(f, x0, fprime | epsilon=1, args, callback=iter_update).
     xs may also be a DeviceEvents (ys, ts, ps are then ignored).
     """
+    fused = getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function)
+    xs, ys, ts, ps = _resident(xs, ys, ts, ps, warp_function, objective)         # resident events, uploaded once
     if grid_search_init and x0 is None:
-        raise NotImplementedError("grid_search_init calls an undefined function upstream (events_cmax.py:336)")
+        # events_cmax.py:333-337: coarse-to-fine grid search on a copy of the objective without adaptive lifespan
+        init_obj = copy.deepcopy(objective)
+        init_obj.adaptive_lifespan = False
+        minv = recursive_search(xs, ys, ts, ps, warp_function, init_obj, img_size, log_scale=False)
+        x0 = minv["min_params"]
     elif x0 is None:
         x0 = np.array([0, 0])
     objective.iter_update(x0)
-    fused = getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function)
-    if fused:
-        ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
-        args = (ev, None, None, None, warp_function, img_size, blur_sigma)      # resident events, uploaded once
-    else:
-        args = (xs, ys, ts, ps, warp_function, img_size, blur_sigma)
+    args = (xs, ys, ts, ps, warp_function, img_size, blur_sigma)
     if numeric_grads and hasattr(objective, "evaluate_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
         # same forward differences (epsilon = 1) scipy would take internally, but the three evaluations of one
         # gradient estimate share a single pass over the events
@@ -54,3 +212,51 @@ def optimize(xs, ys, ts, ps, warp, obj, numeric_grads=True, img_size=(180, 240))
     argmax_an = optimize_contrast(xs, ys, ts, ps, warp, obj, numeric_grads=numeric_grads, blur_sigma=1.0,
                                   img_size=img_size)
     return argmax_an
+
+
+def optimize_r2(xs, ys, ts, ps, warp, obj, numeric_grads=True, img_size=(180, 240)):
+    """Optimise `obj` with its default blur, then refine from that optimum with the sum-of-exponentials objective at
+    blur_sigma=1.0 (reference: events_cmax.py:370-388; like upstream, img_size is NOT forwarded to optimize_contrast,
+    whose default (180, 240) applies)."""
+    numeric_grads = numeric_grads if obj.has_derivative else True
+    xs, ys, ts, ps = _resident(xs, ys, ts, ps, warp, obj)
+    argmax_an = optimize_contrast(xs, ys, ts, ps, warp, obj, numeric_grads=numeric_grads, blur_sigma=None)
+    argmax_an = optimize_contrast(xs, ys, ts, ps, warp, soe_objective(), x0=argmax_an, numeric_grads=numeric_grads,
+                                  blur_sigma=1.0)
+    return argmax_an
+
+
+def grid_cmax(xs, ys, ts, ps, roi_size=(20, 20), step=None, warp=None, obj=None, min_events=10):
+    """
+    Contrast maximisation per cell of a grid over the sensor (reference: events_cmax.py:28-76): for every
+    step-sized region of interest holding more than min_events events, grid-search-initialised BFGS at blur 2.0, a
+    refinement at blur 1.0, then the objective of the IWE of ALL events at the cell's flow.  Returns (params, rois as
+    [y, x, step_y, step_x], function values).  Like upstream, `obj` is replaced per cell by
+    variance_objective(adaptive_lifespan=True, minimum_events=105) and the resolution is inferred from the events
+    (max + 1, lib/util/event_util.py:5-13), so xs / ys must be integer-valued.
+    """
+    warp = linvel_warp() if warp is None else warp
+    step = roi_size if step is None else step
+    xs, ys, ts, ps = (np.asarray(a) for a in (xs, ys, ts, ps))
+    resolution = [int(np.max(ys)) + 1, int(np.max(xs)) + 1]
+    everything = DeviceEvents.from_arrays(xs, ys, ts, ps) if getattr(warp, "fused_kernel", None) == "linvel" else None
+    results_params, results_rois, results_f_evals = [], [], []
+    for xc in range(0, resolution[1], step[1]):
+        in_cols = np.flatnonzero((xs >= xc) & (xs < xc + step[1]))
+        for yc in range(0, resolution[0], step[0]):
+            sel = in_cols[(ys[in_cols] >= yc) & (ys[in_cols] < yc + step[0])]
+            if len(sel) <= min_events:
+                continue
+            roi = (xs[sel], ys[sel], ts[sel], ps[sel])
+            obj = variance_objective(adaptive_lifespan=True, minimum_events=105)
+            params = optimize_contrast(*roi, warp, obj, numeric_grads=False, blur_sigma=2.0, img_size=resolution,
+                                       grid_search_init=True)
+            params = optimize_contrast(*roi, warp, obj, numeric_grads=False, blur_sigma=1.0, img_size=resolution,
+                                       x0=params)
+            whole = (everything, None, None, None) if everything is not None else (xs, ys, ts, ps)
+            iwe, _ = get_iwe(params, *whole, warp, resolution, use_polarity=True, compute_gradient=False,
+                             return_events=False)
+            results_params.append(params)
+            results_rois.append([yc, xc, step[0], step[1]])
+            results_f_evals.append(obj.evaluate_function(iwe=iwe))
+    return results_params, results_rois, results_f_evals

@@ -89,6 +89,16 @@ def iwe_device(params, ev, img_size, compute_gradient=False, use_polarity=True, 
     return iwe, diwe
 
 
+def cut_events_to_lifespan(xs, ys, ts, ps, params, pixel_crossings, minimum_events=10000):
+    """Cut the events down to the lifespan pixel_crossings / |params| before the last timestamp, keeping at least
+    minimum_events; the last event is dropped (reference: objectives.py:143-163; host-side slicing, no print)."""
+    dt = pixel_crossings / np.linalg.norm(params)
+    s_idx = np.searchsorted(ts, ts[-1] - dt)
+    if len(xs) - s_idx < minimum_events:
+        s_idx = len(xs) - minimum_events
+    return xs[s_idx:-1], ys[s_idx:-1], ts[s_idx:-1], ps[s_idx:-1]
+
+
 def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, use_polarity=True,
             return_events=False, return_per_event_contrast=False, sensor_size=None):
     """
@@ -164,6 +174,13 @@ class objective_function(ABC):
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
         pass
+
+    def evaluate_function_batch(self, params_list, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                                blur_sigma=None):
+        """evaluate_function at K parameter vectors on the same events (grid search / objective landscapes,
+        events_cmax.py:127-130,297-305) -> list of K values.  Generic version: K separate evaluations on the resident
+        events; variance_objective evaluates three nearby flows per pass over the events."""
+        return [self.evaluate_function(q, xs, ys, ts, ps, warpfunc, img_size, blur_sigma) for q in params_list]
 
     def iter_update(self, params, pixel_crossings=None):
         """Callback at each optimisation step: lifespan = pixel_crossings / |params| (5 if 0) (objectives.py:113-127)."""
@@ -261,6 +278,29 @@ class variance_objective(objective_function):
         loss = out[1].item()
         return np.float32(-loss)
 
+    def _batch3_setup(self, xs, ys, ts, ps, warpfunc, blur_sigma):
+        """Device state shared by the three-flows-per-pass launches, or None when that kernel does not apply (plugin
+        warp, event-sharded run, no events)."""
+        if (getattr(warpfunc, "fused_kernel", None) != "linvel" or self.distributed or self.process_group is not None):
+            return None
+        ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
+        if len(ev) == 0:
+            return None
+        dev = ev.x.device
+        ss = (180, 240) if self.sensor_size is None else self.sensor_size
+        ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
+        flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        w, radius = _blur_kernel(blur_sigma)
+        buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
+        scratch, nbytes = D.reduce_scratch(dev)
+
+        def launch(trio, out12, img_size):
+            return tiled.cmax_variance_batch3(ev, float(t_ref), [float(q[0]) for q in trio], [float(q[1]) for q in trio],
+                                              float(img_size[1]), float(img_size[0]), ch, cw, flags, w, radius, buf,
+                                              out12, scratch, nbytes, impl=self.impl)
+        return ev, float(t_ref), launch
+
     def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                                   blur_sigma=None, epsilon=1.0):
         """Forward-difference gradient of evaluate_function with absolute step `epsilon` -- exactly what
@@ -276,29 +316,54 @@ class variance_objective(objective_function):
             pts.append(x1)
         blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         fs = None
-        if (len(x0) == 2 and getattr(warpfunc, "fused_kernel", None) == "linvel" and not self.distributed
-                and self.process_group is None):
-            ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
-            if len(ev):
-                dev = ev.x.device
-                ss = (180, 240) if self.sensor_size is None else self.sensor_size
-                ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
-                flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
-                t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
-                w, radius = _blur_kernel(blur_sigma)
-                buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
-                out, (scratch, nbytes) = D.out4(dev, 12), D.reduce_scratch(dev)
-                if tiled.cmax_variance_batch3(ev, float(t_ref), [float(q[0]) for q in pts], [float(q[1]) for q in pts],
-                                              float(img_size[1]), float(img_size[0]), ch, cw, flags, w, radius, buf,
-                                              out, scratch, nbytes, impl=self.impl):
-                    res = out.cpu().numpy().reshape(3, 4)
-                    fs = [np.float32(-res[k, 1]) for k in range(3)]
+        setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur_sigma) if len(x0) == 2 else None
+        if setup is not None:
+            out = D.out4(setup[0].x.device, 12)
+            if setup[2](pts, out, img_size):
+                res = out.cpu().numpy().reshape(3, 4)
+                fs = [np.float32(-res[k, 1]) for k in range(3)]
         if fs is None:
             fs = [self.evaluate_function(q, xs, ys, ts, ps, warpfunc, img_size, blur_sigma) for q in pts]
         grad = np.empty(len(x0), dtype=np.float64)
         for i in range(len(x0)):
             grad[i] = (np.float64(fs[i + 1]) - np.float64(fs[0])) / (pts[i + 1][i] - x0[i])
         return grad
+
+    # flows of one three-flow pass may differ by at most this many pixels of displacement over the stream (the LDS
+    # windows are shared and grow by the spread)
+    BATCH_MAX_SPREAD_PX = 6.0
+
+    def evaluate_function_batch(self, params_list, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                                blur_sigma=None):
+        """f at K flows on the same resident events: consecutive flows are grouped in threes and each group whose
+        flows are close enough costs ONE pass over the events (evk_cmax_variance_batch3_tiled_f32); all passes are
+        enqueued back to back and the K results come back in a single readback.  Groups the batched kernel cannot
+        take (far-apart flows, direct-kernel regime) are evaluated one flow at a time."""
+        pts = [np.asarray(q, dtype=np.float64) for q in params_list]
+        K = len(pts)
+        vals = [None] * K
+        blur = self.default_blur if blur_sigma is None else blur_sigma
+        setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur) if K and all(len(q) == 2 for q in pts) else None
+        if setup is not None:
+            ev, t_ref, launch = setup
+            span = abs(ev.t_at(0) - t_ref)
+            out = torch.empty(4 * 3 * ((K + 2) // 3), dtype=torch.float64, device=ev.x.device)
+            done = []
+            for c in range(0, K, 3):
+                idx = [min(c + k, K - 1) for k in range(3)]
+                trio = [pts[i] for i in idx]
+                spread = max(max(q[d] for q in trio) - min(q[d] for q in trio) for d in range(2)) * span
+                if spread <= self.BATCH_MAX_SPREAD_PX and launch(trio, out[4 * c:4 * c + 12], img_size):
+                    done.append((c, idx))
+            if done:
+                res = out.cpu().numpy().reshape(-1, 4)
+                for c, idx in done:
+                    for k, i in enumerate(idx):
+                        vals[i] = np.float32(-res[c + k, 1])
+        for i in range(K):
+            if vals[i] is None:
+                vals[i] = self.evaluate_function(pts[i], xs, ys, ts, ps, warpfunc, img_size, blur_sigma)
+        return vals
 
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
@@ -330,8 +395,7 @@ class variance_objective(objective_function):
 # The other objectives of the reference (objectives.py:266-596): same IWE, a different scalar reduction.
 # Upstream these classes skip objective_function.__init__ (so e.g. soe has no pixel_crossings and cannot go through
 # optimize()); here they all inherit the full base state, which is a superset of the upstream behaviour.
-# Not provided: rms_objective (upstream takes np.linalg.norm(iwe, 2) of a MATRIX, i.e. its largest singular value, :282)
-# and zhu_timestamp_objective (calls the undefined events_to_zhu_timestamp_image, :545).
+# Not provided: zhu_timestamp_objective (calls the undefined events_to_zhu_timestamp_image, :545).
 # ---------------------------------------------------------------------------------------------------------------
 class _reduction_objective(objective_function):
     def _stats(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, p=0.0, thresh=0.0):
@@ -388,6 +452,34 @@ class sos_objective(_reduction_objective):
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
         g, n = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 0, 0.0, False)
         return -(2.0 * g / n / (self.div * self.div)).astype(np.float32)
+
+
+class rms_objective(_reduction_objective):
+    """"Root mean squared" objective (reference: objectives.py:266-306).  As written upstream the loss is
+    -norm(blur(iwe), 2)^2 / pixels with np.linalg.norm(., 2) of a MATRIX, i.e. its largest singular value (:282), not
+    the Frobenius norm; reproduced as is.  The blurred IWE stays on the device and its spectral norm comes from the
+    device SVD (torch.linalg.matrix_norm -> rocSOLVER).  Gradient: -2 mean(iwe * blur3d(d_iwe)[i]), un-blurred IWE."""
+
+    def __init__(self):
+        super().__init__(name="rms", use_polarity=True, has_derivative=True, default_blur=1.0)
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        dev = D.require_gpu()
+        if iwe is None:
+            iwe, _ = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, False)
+        else:
+            iwe = D.to_device(iwe, torch.float32, dev)
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        if blur_sigma > 0:
+            iwe = gaussian_filter_device(iwe.contiguous(), blur_sigma)
+        norm = torch.linalg.matrix_norm(iwe.double(), ord=2).item()   # float64: the device f32 SVD is only good to ~1e-5
+        return np.float32(-(norm * norm) / (iwe.shape[0] * iwe.shape[1]))
+
+    def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
+        g, n = self._gradsums(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, iwe, d_iwe, 0, 0.0, False)
+        return -(2.0 * g / n)
 
 
 class soe_objective(_reduction_objective):

@@ -147,3 +147,69 @@ def test_numeric_gradient_formula_equals_scipy_internal_forward_differences(gold
 
 def g_numeric_argmax(golden):
     return golden("f9_optimize_trace")["numeric_argmax"]
+
+
+class _QuadraticObjective:
+    """Duck-typed plugin objective (no GPU): f(v) = |v - v*|^2 - 1e4, minimum at v* = (40, -25)."""
+    has_derivative = False
+
+    def evaluate_function(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
+                          blur_sigma=None, showimg=False, iwe=None):
+        return float((params[0] - 40.0) ** 2 + (params[1] + 25.0) ** 2 - 1e4)
+
+
+class _PluginWarp:
+    name, dims = "plugin", 2
+
+
+def test_parameter_space_samplers_host_logic(golden):
+    """grid_search_initial / find_new_range / grid_search_optimisation / objective_landscape / cut_events_to_lifespan /
+    segmentation_mask_from_d_iwe: sample positions, orders and selections pinned to what the reference produced
+    (tests/golden/f14_search.npz); objective values come from a plugin objective so no GPU is needed."""
+    import inspect
+    from event_utils_amd.contrast_max import events_cmax as C
+    from event_utils_amd.contrast_max.objectives import cut_events_to_lifespan
+    g, g8 = golden("f14_search"), golden("f8_objective")
+    obj, w = _QuadraticObjective(), _PluginWarp()
+    r = C.grid_search_initial(None, None, None, None, w, obj, (180, 240))
+    assert np.array_equal(np.array(r["search_axes"]), g["gsi_log5_axes"])
+    assert np.array_equal(np.array(r["params"]), g["gsi_log5_params"])
+    assert r["min_params"] == (15.0, -15.0) and r["min_func_eval"] == obj.evaluate_function((15.0, -15.0))
+    r = C.grid_search_initial(None, None, None, None, w, obj, (180, 240), log_scale=False, num_samples_per_param=7,
+                              param_ranges=[[-60, 60], [-90, 30]])
+    assert np.array_equal(np.array(r["search_axes"]), g["gsi_lin7_axes"])
+    assert np.array_equal(np.array(r["params"]), g["gsi_lin7_params"])
+    for q, rng in zip(g["fnr_params"], g["fnr_ranges"]):
+        assert np.array_equal(np.array(C.find_new_range(g["fnr_axes"], q)), rng)
+    r = C.grid_search_optimisation(None, None, None, None, w, obj, (180, 240), log_scale=False)
+    assert np.allclose(r["min_params"], (40.0, -25.0), atol=0.5)
+    assert C.recursive_search is C.grid_search_optimisation
+
+    class NoMinimum(_QuadraticObjective):
+        def evaluate_function(self, params=None, **k):
+            return 1.0
+    assert C.grid_search_initial(None, None, None, None, w, NoMinimum(), (180, 240))["min_params"] is None
+
+    a = g["landscape_args"]
+    img = C.objective_landscape(None, None, None, None, obj, w, x_range=(a[0], a[1]), y_range=(a[2], a[3]),
+                                resolution=a[4])
+    assert img.shape == g["landscape"].shape and img.min() == 0.0 and abs(img.max() - 1.0) < 1e-6
+    raw = np.array([[-obj.evaluate_function((x * 20 - 100, y * 20 - 80)) for x in range(10)] for y in range(7)])
+    assert np.allclose(img, (raw - raw.min()) / (raw.max() - raw.min() + 1e-6), rtol=0, atol=1e-12)
+
+    x, y, t, p = (np.asarray(g8[k], dtype=np.float64) for k in ("xs", "ys", "ts", "ps"))
+    for i, prm in enumerate(([400., -250.], [4000., -2500.])):
+        cut = cut_events_to_lifespan(x, y, t, p, np.array(prm), 5, minimum_events=5000)
+        assert len(cut[0]) == g["cut_len"][i] and cut[2][0] == g["cut_first_t"][i]
+    assert np.array_equal(C.segmentation_mask_from_d_iwe(g["seg_d_iwe"]), g["seg_mask"])
+    assert np.array_equal(C.segmentation_mask_from_d_iwe(g["seg_d_iwe"], th=0.05), g["seg_mask_th"])
+
+    names = lambda f: list(inspect.signature(f).parameters)
+    assert names(C.grid_search_initial) == ["xs", "ys", "ts", "ps", "warp_function", "objective_function", "img_size",
+                                            "param_ranges", "log_scale", "num_samples_per_param"]
+    assert names(C.grid_search_optimisation) == names(C.grid_search_initial) + ["depth", "th0", "max_iters"]
+    assert names(C.draw_objective_function) == ["xs", "ys", "ts", "ps", "objective", "warpfunc", "x_range", "y_range",
+                                                "gt", "show_gt", "resolution", "img_size", "show_axes", "norm_min",
+                                                "norm_max", "show"]
+    assert names(C.optimize_r2) == names(C.optimize)
+    assert names(C.grid_cmax) == ["xs", "ys", "ts", "ps", "roi_size", "step", "warp", "obj", "min_events"]

@@ -218,3 +218,51 @@ def test_f13_dense_flow_warp(golden):
     assert np.max(np.abs(yw - g["yw"])) <= 2e-7 * np.max(np.abs(g["yw"]))
     xw, yw = R.warp_events_flow_torch(g["xs"], g["ys"], g["ts"], None, g["flow"], t0=0.02)
     assert np.max(np.abs(xw - g["xw_t0"])) <= 2e-7 * np.max(np.abs(g["xw_t0"]))
+
+
+def _f8_events(golden):
+    g8 = golden("f8_objective")
+    return f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"]), tuple(int(v) for v in g8["img_size"])
+
+
+def test_f14_grid_search_and_landscape(golden):
+    """grid_search_initial / grid_search_optimisation / find_new_range / draw_objective_function's image
+    (events_cmax.py:103-311) -- the parameter-space samplers of SURVEY 8(f) rank 1."""
+    g = golden("f14_search")
+    x, y, t, p, img_size = _f8_events(golden)
+    w = R.linvel_warp()
+    for tag, kw in (("log5", dict(log_scale=True, num_samples_per_param=5)),
+                    ("lin7", dict(log_scale=False, num_samples_per_param=7, param_ranges=[[-60, 60], [-90, 30]]))):
+        r = R.grid_search_initial(x, y, t, p, w, R.variance_objective(), img_size, **kw)
+        assert np.array_equal(np.array(r["search_axes"]), g["gsi_%s_axes" % tag])
+        assert np.array_equal(np.array(r["params"]), g["gsi_%s_params" % tag])
+        assert np.array_equal(np.array(r["eval"], dtype=np.float64), g["gsi_%s_eval" % tag])
+        assert np.array_equal(np.array(r["min_params"]), g["gsi_%s_min_params" % tag])
+    for q, rng in zip(g["fnr_params"], g["fnr_ranges"]):
+        assert np.array_equal(np.array(R.find_new_range(g["fnr_axes"], q)), rng)
+    r = R.grid_search_optimisation(x, y, t, p, w, R.variance_objective(), img_size, log_scale=False)
+    assert np.array_equal(np.array(r["min_params"]), g["gso_min_params"])
+    a = g["landscape_args"]
+    obj = R.variance_objective(minimum_events=1)
+    img = R.objective_landscape(x, y, t, p, obj, w, x_range=(a[0], a[1]), y_range=(a[2], a[3]), resolution=a[4],
+                                img_size=img_size)
+    assert img.shape == g["landscape"].shape
+    assert np.array_equal(img, g["landscape"])
+
+
+def test_f14_rms_lifespan_cut_segmentation(golden):
+    g = golden("f14_search")
+    x, y, t, p, img_size = _f8_events(golden)
+    w = R.linvel_warp()
+    rms = R.rms_objective()
+    k = 0
+    for q in g["rms_params"]:
+        for s in (None, 0.0):
+            assert np.float64(rms.evaluate_function(q, x, y, t, p, w, img_size, blur_sigma=s)) == g["rms_f"][k]
+            assert np.array_equal(f64(rms.evaluate_gradient(q, x, y, t, p, w, img_size, blur_sigma=s)), g["rms_g"][k])
+            k += 1
+    for i, prm in enumerate(([400., -250.], [4000., -2500.])):
+        cut = R.cut_events_to_lifespan(x, y, t, p, np.array(prm), 5, minimum_events=5000)
+        assert len(cut[0]) == g["cut_len"][i] and cut[2][0] == g["cut_first_t"][i]
+    assert np.array_equal(R.segmentation_mask_from_d_iwe(g["seg_d_iwe"]), g["seg_mask"])
+    assert np.array_equal(R.segmentation_mask_from_d_iwe(g["seg_d_iwe"], th=0.05), g["seg_mask_th"])
