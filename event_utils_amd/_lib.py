@@ -52,6 +52,9 @@ SIGNATURES = {
     "evk_objective_gradsums_f32": [P, P, c_int, c_int, P, c_int, c_uint32, c_int, c_double, P, P, c_int64, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
     "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P],
+    "evk_bucket_events_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                     P, P, P, c_int64, P, c_int, P],
+    "evk_native_to_columns_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, P, P, P, P, P],
     "evk_voxel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, c_int64, P],
     "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, P, c_int64, P, P, P],

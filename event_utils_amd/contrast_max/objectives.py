@@ -72,7 +72,7 @@ def iwe_device(params, ev, img_size, compute_gradient=False, use_polarity=True, 
     """Fused linear-flow get_iwe on device-resident events -> (iwe, d_iwe | None) float32 device tensors of shape
     (H+1, W+1) / (2, H+1, W+1).  t_ref defaults to ts[-1] of `ev` (objectives.py:186); an event-sharded caller passes
     the GLOBAL ts[-1]."""
-    dev = ev.x.device
+    dev = ev.device
     ss = (180, 240) if sensor_size is None else sensor_size       # Q1
     ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
     buf = torch.zeros((3 if compute_gradient else 1, ch, cw), dtype=torch.float32, device=dev)
@@ -219,7 +219,7 @@ class objective_function(ABC):
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
         if len(ev) == 0:
             return None
-        dev = ev.x.device
+        dev = ev.device
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
         ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
         flags = (0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if grad else 0)
@@ -286,7 +286,7 @@ class variance_objective(objective_function):
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
         if len(ev) == 0:
             return None
-        dev = ev.x.device
+        dev = ev.device
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
         ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
         flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
@@ -318,7 +318,7 @@ class variance_objective(objective_function):
         fs = None
         setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur_sigma) if len(x0) == 2 else None
         if setup is not None:
-            out = D.out4(setup[0].x.device, 12)
+            out = D.out4(setup[0].device, 12)
             if setup[2](pts, out, img_size):
                 res = out.cpu().numpy().reshape(3, 4)
                 fs = [np.float32(-res[k, 1]) for k in range(3)]
@@ -347,7 +347,7 @@ class variance_objective(objective_function):
         if setup is not None:
             ev, t_ref, launch = setup
             span = abs(ev.t_at(0) - t_ref)
-            out = torch.empty(4 * 3 * ((K + 2) // 3), dtype=torch.float64, device=ev.x.device)
+            out = torch.empty(4 * 3 * ((K + 2) // 3), dtype=torch.float64, device=ev.device)
             done = []
             for c in range(0, K, 3):
                 idx = [min(c + k, K - 1) for k in range(3)]

@@ -43,6 +43,76 @@ __device__ __forceinline__ int tile_key(float x, float y, const TileGrid &g, int
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// column sources of the bucketing kernels: quads of 4 consecutive events (base index lo % 4 == 0) and single events
+// ---------------------------------------------------------------------------------------------------------
+struct ColsF32 {  // four float32 SoA columns, 16 B / event
+    const float *x, *y, *t, *p;
+    __device__ __forceinline__ void xy4(int64_t lo, int64_t q, Vec4<float> &xv, Vec4<float> &yv) const {
+        xv = load4(x + lo, q), yv = load4(y + lo, q);
+    }
+    __device__ __forceinline__ void tp4(int64_t lo, int64_t q, Vec4<float> &tv, Vec4<float> &pv) const {
+        tv = load4(t + lo, q), pv = load4(p + lo, q);
+    }
+    __device__ __forceinline__ float x1(int64_t i) const { return x[i]; }
+    __device__ __forceinline__ float y1(int64_t i) const { return y[i]; }
+    __device__ __forceinline__ float t1(int64_t i) const { return t[i]; }
+    __device__ __forceinline__ float p1(int64_t i) const { return p[i]; }
+};
+
+// The on-disk dtypes of the reference's event files (event_packagers.py:90-93: xs, ys int16, ts float64, ps bool;
+// h5_to_memmap.py:119-121: xy int16 (N, 2), t float64, p uint8): 13 B / event, converted in registers.
+// xy_stride 1: separate x / y columns; 2: one interleaved (N, 2) array (y = x + 1).
+// t: float64 or float32; the record holds (float)(t - t_offset), the subtraction in float64.
+// p: EVK_P_U8_PM1 uint8/bool {0,1} -> 2p - 1 (what the loaders' get_events does, hdf5_dataset.py:22,
+// memmap_dataset.py:23), EVK_P_U8 uint8 as is, EVK_P_I8 int8 as is.
+struct ColsNative {
+    const int16_t *x, *y;
+    const void *t;
+    const uint8_t *p;
+    double t_offset;
+    int xy_stride, t_f64, p_kind;
+    __device__ __forceinline__ float pol(uint32_t b) const {
+        return p_kind == EVK_P_U8_PM1 ? (float)(2 * (int)b - 1) : (p_kind == EVK_P_I8 ? (float)(int8_t)b : (float)b);
+    }
+    __device__ __forceinline__ void xy4(int64_t lo, int64_t q, Vec4<float> &xv, Vec4<float> &yv) const {
+        if (xy_stride == 2) {
+            const uint4 w = reinterpret_cast<const uint4 *>(x + 2 * lo)[q];  // x0 y0 | x1 y1 | x2 y2 | x3 y3
+            const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv.v[k] = (float)(int16_t)(u[k] & 0xffffu), yv.v[k] = (float)(int16_t)(u[k] >> 16);
+        } else {
+            const uint2 a = reinterpret_cast<const uint2 *>(x + lo)[q], b = reinterpret_cast<const uint2 *>(y + lo)[q];
+            const uint32_t ua[2] = {a.x, a.y}, ub[2] = {b.x, b.y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                xv.v[2 * k] = (float)(int16_t)(ua[k] & 0xffffu), xv.v[2 * k + 1] = (float)(int16_t)(ua[k] >> 16);
+                yv.v[2 * k] = (float)(int16_t)(ub[k] & 0xffffu), yv.v[2 * k + 1] = (float)(int16_t)(ub[k] >> 16);
+            }
+        }
+    }
+    __device__ __forceinline__ void tp4(int64_t lo, int64_t q, Vec4<float> &tv, Vec4<float> &pv) const {
+        if (t_f64) {
+            const Vec4<double> d = load4(static_cast<const double *>(t) + lo, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv.v[k] = (float)(d.v[k] - t_offset);
+        } else {
+            const Vec4<float> f = load4(static_cast<const float *>(t) + lo, q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv.v[k] = (float)((double)f.v[k] - t_offset);
+        }
+        const uint32_t w = reinterpret_cast<const uint32_t *>(p + lo)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv.v[k] = pol((w >> (8 * k)) & 0xffu);
+    }
+    __device__ __forceinline__ float x1(int64_t i) const { return (float)x[i * xy_stride]; }
+    __device__ __forceinline__ float y1(int64_t i) const { return (float)y[i * xy_stride]; }
+    __device__ __forceinline__ float t1(int64_t i) const {
+        return (float)((t_f64 ? static_cast<const double *>(t)[i] : (double)static_cast<const float *>(t)[i]) - t_offset);
+    }
+    __device__ __forceinline__ float p1(int64_t i) const { return pol(p[i]); }
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // bucketing: histogram -> scan -> scatter
 // ---------------------------------------------------------------------------------------------------------
 #ifndef EVK_BUCKET_THREADS
@@ -53,10 +123,10 @@ __device__ __forceinline__ int tile_key(float x, float y, const TileGrid &g, int
 #endif
 
 // Block b owns the contiguous event range [b*chunk, (b+1)*chunk) (chunk % 4 == 0); table[b][tile] = its count.
-__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *__restrict__ x,
-                                                                  const float *__restrict__ y, int64_t n,
-                                                                  int64_t chunk, TileGrid g, int mode, int ntiles,
-                                                                  uint32_t *__restrict__ table, uint32_t *oob) {
+template <typename C>
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const C c, int64_t n, int64_t chunk, TileGrid g,
+                                                                  int mode, int ntiles, uint32_t *__restrict__ table,
+                                                                  uint32_t *oob) {
     extern __shared__ uint32_t hist[];
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) hist[i] = 0;
     __syncthreads();
@@ -76,15 +146,19 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const float *_
         }
     };
     int64_t q = threadIdx.x;
+    Vec4<float> xa, ya, xb, yb;
     for (; q + blockDim.x < nq; q += 2 * blockDim.x) {  // 4 independent 16-byte loads in flight per lane
-        const Vec4<float> xa = load4(x + lo, q), ya = load4(y + lo, q);
-        const Vec4<float> xb = load4(x + lo, q + blockDim.x), yb = load4(y + lo, q + blockDim.x);
+        c.xy4(lo, q, xa, ya);
+        c.xy4(lo, q + blockDim.x, xb, yb);
         count4(xa, ya);
         count4(xb, yb);
     }
-    for (; q < nq; q += blockDim.x) count4(load4(x + lo, q), load4(y + lo, q));
+    for (; q < nq; q += blockDim.x) {
+        c.xy4(lo, q, xa, ya);
+        count4(xa, ya);
+    }
     for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {  // ragged tail of the last block
-        const int key = tile_key(x[i], y[i], g, mode);
+        const int key = tile_key(c.x1(i), c.y1(i), g, mode);
         if (key >= 0)
             atomicAdd(&hist[key], 1u);
         else
@@ -205,11 +279,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__res
 // Scatter: LDS cursors start at bucket_start[tile] + (this block's exclusive prefix); an LDS returning atomic hands
 // every event its final slot; the 16-byte record is written there.  Events keep their time order across blocks and
 // (up to the interleaving of one block's waves) within a block.
-__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float *__restrict__ x,
-                                                                     const float *__restrict__ y,
-                                                                     const float *__restrict__ t,
-                                                                     const float *__restrict__ p, int64_t n,
-                                                                     int64_t chunk, TileGrid g, int mode, int ntiles,
+template <typename C>
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const C c, int64_t n, int64_t chunk, TileGrid g,
+                                                                     int mode, int ntiles,
                                                                      const uint32_t *__restrict__ table,
                                                                      const uint32_t *__restrict__ bucket_start,
                                                                      float4 *__restrict__ rec) {
@@ -222,7 +294,9 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float
     if (hi > n) hi = n;
     const int64_t nq = (hi > lo) ? ((hi - lo) >> 2) : 0;
     for (int64_t q = threadIdx.x; q < nq; q += blockDim.x) {
-        const Vec4<float> xv = load4(x + lo, q), yv = load4(y + lo, q), tv = load4(t + lo, q), pv = load4(p + lo, q);
+        Vec4<float> xv, yv, tv, pv;
+        c.xy4(lo, q, xv, yv);
+        c.tp4(lo, q, tv, pv);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int key = tile_key(xv.v[k], yv.v[k], g, mode);
@@ -233,10 +307,11 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float
         }
     }
     for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {
-        const int key = tile_key(x[i], y[i], g, mode);
+        const float xs = c.x1(i), ys = c.y1(i);
+        const int key = tile_key(xs, ys, g, mode);
         if (key >= 0) {
             const uint32_t pos = atomicAdd(&cursor[key], 1u);
-            rec[pos] = make_float4(x[i], y[i], t[i], p[i]);
+            rec[pos] = make_float4(xs, ys, c.t1(i), c.p1(i));
         }
     }
 }
@@ -247,13 +322,9 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter(const float
 // events the complete, G = R/2-aligned granules (G*16 bytes: 64 B for R = 8, 128 B for R = 16) are written out by
 // G consecutive lanes as one contiguous, aligned piece.  A record that does not fit the window (a hot tile) is stored
 // directly -- such stores are consecutive in memory anyway.
-template <int R>
-__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const float *__restrict__ x,
-                                                                        const float *__restrict__ y,
-                                                                        const float *__restrict__ t,
-                                                                        const float *__restrict__ p, int64_t n,
-                                                                        int64_t chunk, TileGrid g, int mode,
-                                                                        int ntiles,
+template <int R, typename C>
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const C c, int64_t n, int64_t chunk,
+                                                                        TileGrid g, int mode, int ntiles,
                                                                         const uint32_t *__restrict__ table,
                                                                         const uint32_t *__restrict__ bucket_start,
                                                                         float4 *__restrict__ rec) {
@@ -291,7 +362,8 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const fl
     auto fetch = [&](int64_t ph) {
         const int64_t q = ph * blockDim.x + threadIdx.x;
         if (ph < nphase && q < nq && lo + (q << 2) + 4 <= hi) {
-            xn = load4(x + lo, q), yn = load4(y + lo, q), tn = load4(t + lo, q), pn = load4(p + lo, q);
+            c.xy4(lo, q, xn, yn);
+            c.tp4(lo, q, tn, pn);
         }
     };
     fetch(0);
@@ -305,7 +377,7 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const fl
 #pragma unroll
                 for (int k = 0; k < 4; ++k) place(xv.v[k], yv.v[k], tv.v[k], pv.v[k]);
             } else {
-                for (int64_t i = base; i < hi; ++i) place(x[i], y[i], t[i], p[i]);
+                for (int64_t i = base; i < hi; ++i) place(c.x1(i), c.y1(i), c.t1(i), c.p1(i));
             }
         }
         __syncthreads();
@@ -768,17 +840,31 @@ extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
     return ((int64_t)EVK_BUCKET_BLOCKS * ntiles + ntiles) * (int64_t)sizeof(uint32_t);
 }
 
-extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n,
-                                     int key_mode, int dom_h, int dom_w, int tw_log2, int th_log2, float *records,
-                                     uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
-                                     int stages, void *stream) {
+template <int RR, typename C>
+static void launch_scatter_wc(const C &c, int64_t n, int64_t chunk, const TileGrid &g, int key_mode, int ntiles,
+                              const uint32_t *table, const uint32_t *bucket_start, float *records, size_t lds_wc,
+                              hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_tile_scatter_wc<RR, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    k_tile_scatter_wc<RR, C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds_wc, s>>>(c, n, chunk, g, key_mode, ntiles, table,
+                                                                                bucket_start, (float4 *)records);
+}
+
+template <typename C>
+static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom_w, int tw_log2, int th_log2,
+                         float *records, uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                         int stages, void *stream) {
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (ntiles > EVK_MAX_TILES || n < 0 || n > (int64_t)4000000000LL || (key_mode != 0 && key_mode != 1)) return EVK_EINVAL;
-    if (!bucket_start || !scratch || (n > 0 && (!x || !y || !t || !p || !records))) return EVK_EINVAL;
+    if (!bucket_start || !scratch || (n > 0 && !records)) return EVK_EINVAL;
     if (scratch_bytes < evk_bucket_scratch_bytes(ntiles)) return EVK_ESCRATCH;
-    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p) && aligned16(records))) return EVK_EALIGN;
+    if (!aligned16(records)) return EVK_EALIGN;
     hipStream_t s = (hipStream_t)stream;
     uint32_t *table = (uint32_t *)scratch;
     uint32_t *totals = table + (int64_t)EVK_BUCKET_BLOCKS * ntiles;
@@ -787,7 +873,7 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     if (chunk == 0) chunk = 4;
     const size_t lds = (size_t)ntiles * sizeof(uint32_t);
     if (stages & EVK_STAGE_HIST)
-        k_tile_hist<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, n, chunk, g, key_mode, ntiles, table, oob);
+        k_tile_hist<C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob);
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
         k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles), bucket_start);
@@ -802,24 +888,68 @@ extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float
     if (variant == 0) R = 0;
     if (variant > 0 && (size_t)ntiles * (variant * 16 + 10) + 8 <= lds_budget) R = variant;
     const size_t lds_wc = (size_t)ntiles * (R * 16 + 10) + 8;  // rings + cursor + vstart + flush queue
-#define EVK_SCATTER_WC(RR)                                                                                        \
-    do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute((const void *)k_tile_scatter_wc<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
-        k_tile_scatter_wc<RR><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds_wc, s>>>(                               \
-            x, y, t, p, n, chunk, g, key_mode, ntiles, table, bucket_start, (float4 *)records);                   \
-    } while (0)
-    if (R == 16) EVK_SCATTER_WC(16);
-    else if (R == 8) EVK_SCATTER_WC(8);
-    else if (R == 4) EVK_SCATTER_WC(4);
+    if (R == 16) launch_scatter_wc<16>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, lds_wc, s);
+    else if (R == 8) launch_scatter_wc<8>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, lds_wc, s);
+    else if (R == 4) launch_scatter_wc<4>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, lds_wc, s);
     else
-        k_tile_scatter<<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(x, y, t, p, n, chunk, g, key_mode, ntiles,
-                                                                       table, bucket_start, (float4 *)records);
-#undef EVK_SCATTER_WC
+        k_tile_scatter<C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table,
+                                                                          bucket_start, (float4 *)records);
+    return launch_status();
+}
+
+extern "C" int evk_bucket_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n,
+                                     int key_mode, int dom_h, int dom_w, int tw_log2, int th_log2, float *records,
+                                     uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                     int stages, void *stream) {
+    if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    const ColsF32 c{x, y, t, p};
+    return bucket_events(c, n, key_mode, dom_h, dom_w, tw_log2, th_log2, records, bucket_start, scratch, scratch_bytes, oob,
+                         stages, stream);
+}
+
+static int native_cols(ColsNative &c, const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                       double t_offset, const void *p, int p_kind, int64_t n) {
+    if ((xy_stride != 1 && xy_stride != 2) || (t_kind != EVK_T_F32 && t_kind != EVK_T_F64) ||
+        (p_kind != EVK_P_U8_PM1 && p_kind != EVK_P_U8 && p_kind != EVK_P_I8) || !(t_offset == t_offset))
+        return EVK_EINVAL;
+    if (n > 0 && (!x || !t || !p || (xy_stride == 1 && !y))) return EVK_EINVAL;
+    c.x = x, c.y = xy_stride == 2 ? x + 1 : y, c.t = t, c.p = static_cast<const uint8_t *>(p);
+    c.t_offset = t_offset, c.xy_stride = xy_stride, c.t_f64 = t_kind == EVK_T_F64, c.p_kind = p_kind;
+    return EVK_OK;
+}
+
+extern "C" int evk_bucket_events_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                                            double t_offset, const void *p, int p_kind, int64_t n, int key_mode,
+                                            int dom_h, int dom_w, int tw_log2, int th_log2, float *records,
+                                            uint32_t *bucket_start, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                            int stages, void *stream) {
+    ColsNative c;
+    const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
+    if (rc != EVK_OK) return rc;
+    if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    return bucket_events(c, n, key_mode, dom_h, dom_w, tw_log2, th_log2, records, bucket_start, scratch, scratch_bytes, oob,
+                         stages, stream);
+}
+
+// native columns -> four float32 SoA columns (any alignment): the direct kernels' input, 13 B read + 16 B written
+__global__ void __launch_bounds__(EVK_BLOCK) k_native_to_columns(const ColsNative c, int64_t n, float *__restrict__ x,
+                                                                 float *__restrict__ y, float *__restrict__ t,
+                                                                 float *__restrict__ p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = c.x1(i), y[i] = c.y1(i), t[i] = c.t1(i), p[i] = c.p1(i);
+}
+
+extern "C" int evk_native_to_columns_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                                         double t_offset, const void *p, int p_kind, int64_t n, float *out_x,
+                                         float *out_y, float *out_t, float *out_p, void *stream) {
+    ColsNative c;
+    const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
+    if (rc != EVK_OK || n < 0) return rc != EVK_OK ? rc : EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    if (!out_x || !out_y || !out_t || !out_p) return EVK_EINVAL;
+    k_native_to_columns<<<stream_grid(n), EVK_BLOCK, 0, (hipStream_t)stream>>>(c, n, out_x, out_y, out_t, out_p);
     return launch_status();
 }
 

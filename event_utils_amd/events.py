@@ -1,4 +1,5 @@
-"""Device-resident event stream: four SoA columns x, y, t, p in HBM (float32: 16 B/event; float64: 32 B/event).
+"""Device-resident event stream: four SoA columns x, y, t, p in HBM (float32: 16 B/event; float64: 32 B/event), or the
+reference's on-disk dtypes as they are (NativeColumns: int16 x, y, float64 / float32 t, uint8 p; 13 / 9 B/event).
 Created once per optimisation / window so that every objective evaluation is a pure streaming pass with only the
 motion parameters and a few scalars crossing PCIe."""
 import numpy as np
@@ -16,15 +17,62 @@ def _f32_lossless(a):
     return bool(np.array_equal(a.astype(np.float32).astype(np.float64), a.astype(np.float64)))
 
 
+class NativeColumns:
+    """Device-resident events in the dtypes the reference's files store them in (lib/data_formats/event_packagers.py:
+    90-93: xs, ys int16, ts float64, ps bool; h5_to_memmap.py:119-121: xy int16 (N, 2), t float64, p uint8) -- 13 B /
+    event, or 9 B with float32 t.  The kernels widen them in registers (include/evk.h, "native on-disk dtypes"):
+    x, y -> float, t -> (float)(t - t_offset) with the subtraction in float64, p per p_kind."""
+    P_KINDS = {"pm1": 0, "u8": 1, "i8": 2}        # EVK_P_U8_PM1, EVK_P_U8, EVK_P_I8
+
+    def __init__(self, x, y, t, p, xy_stride, t_offset, p_kind):
+        self.x, self.y, self.t, self.p = x, y, t, p          # y is None for an interleaved (N, 2) xy array
+        self.xy_stride, self.t_offset, self.p_kind = int(xy_stride), float(t_offset), int(p_kind)
+        self.n = int(t.shape[0])
+        self.t_kind = 1 if t.dtype == torch.float64 else 0   # EVK_T_F64 / EVK_T_F32
+
+    def head(self):
+        """The argument prefix shared by evk_bucket_events_native_f32 and evk_native_to_columns_f32."""
+        return (D.ptr(self.x), D.ptr(self.y) if self.y is not None else None, self.xy_stride, D.ptr(self.t), self.t_kind,
+                self.t_offset, D.ptr(self.p), self.p_kind, self.n)
+
+    def aligned(self):
+        return all(a is None or a.data_ptr() % 16 == 0 for a in (self.x, self.y, self.t, self.p))
+
+    def widen(self):
+        """-> four float32 SoA columns (evk_native_to_columns_f32)."""
+        from . import _lib
+        dev = self.t.device
+        out = [torch.empty(self.n, dtype=torch.float32, device=dev) for _ in range(4)]
+        _lib.call("evk_native_to_columns_f32", *self.head(), *(D.ptr(o) for o in out), D.stream())
+        return out
+
+
 class DeviceEvents:
-    def __init__(self, x, y, t, p, t_host=None):
-        assert x.shape == y.shape == t.shape == p.shape and x.dim() == 1
-        assert x.dtype == y.dtype == t.dtype == p.dtype and x.dtype in (torch.float32, torch.float64)
-        self.x, self.y, self.t, self.p = x, y, t, p
+    def __init__(self, x, y, t, p, t_host=None, native=None):
+        if native is None:
+            assert x.shape == y.shape == t.shape == p.shape and x.dim() == 1
+            assert x.dtype == y.dtype == t.dtype == p.dtype and x.dtype in (torch.float32, torch.float64)
+        self._cols = None if native is not None else (x, y, t, p)
+        self.native = native           # NativeColumns: the float32 columns are then widened on first use only
         self._t_host = t_host          # optional host copy of t (float64) for cheap ts[k] / searchsorted
         self.p_scale = 1.0             # adaptive lifespan multiplies ps by 100 (objectives.py:225), folded here
         self._buckets = {}             # cache of tile-bucketed layouts (see tiled.py)
         self._p_absmax = None
+        self._t_ends = None            # (ts[0], ts[-1]) when known without touching the column
+
+    def _columns(self):
+        if self._cols is None:
+            self._cols = tuple(self.native.widen())
+        return self._cols
+
+    x = property(lambda self: self._columns()[0])
+    y = property(lambda self: self._columns()[1])
+    t = property(lambda self: self._columns()[2])
+    p = property(lambda self: self._columns()[3])
+
+    @property
+    def device(self):
+        return self.native.t.device if self._cols is None else self._cols[0].device
 
     # -- construction --------------------------------------------------------------------------------------
     @classmethod
@@ -44,18 +92,67 @@ class DeviceEvents:
         t_host = cols[2].astype(np.float64) if dt == torch.float64 else cols[2].astype(np.float32).astype(np.float64)
         return cls(*(D.to_device(c, dt, device) for c in cols), t_host=t_host)
 
+    @classmethod
+    def from_native(cls, xs, ys, ts, ps, polarity="pm1", t_offset=None, device=None):
+        """Events in their on-disk dtypes -> device, WITHOUT host-side casts (13 B/event over PCIe and in HBM instead
+        of 16; replaces the widening of lib/data_loaders/memmap_dataset.py:19-24 / hdf5_dataset.py:18-23).
+          xs, ys   int16 columns, or xs = an (N, 2) int16 xy array and ys = None            (numpy or torch)
+          ts       float64 or float32; the kernels use (float)(ts - t_offset), t_offset defaults to ts[0]
+          ps       bool / uint8 {0, 1} with polarity='pm1' (-> 2p - 1, what the loaders' get_events returns),
+                   polarity='literal' to use the stored values as they are (uint8 / bool / int8)."""
+        device = device or D.require_gpu()
+
+        def up(a, dtypes, what):
+            if isinstance(a, torch.Tensor):
+                a = a.view(torch.uint8) if a.dtype == torch.bool else a
+                if a.dtype not in dtypes:
+                    raise TypeError("%s must be one of %s, got %s" % (what, dtypes, a.dtype))
+                return a.contiguous().to(device)
+            a = np.asarray(a)
+            a = a.view(np.uint8) if a.dtype == np.bool_ else a
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if t.dtype not in dtypes:
+                raise TypeError("%s must be one of %s, got %s" % (what, dtypes, t.dtype))
+            return t.to(device)
+        if ys is None:
+            xy = up(xs, (torch.int16,), "xy")
+            if xy.dim() != 2 or xy.shape[1] != 2:
+                raise ValueError("an interleaved coordinate array must have shape (N, 2)")
+            x, y, stride, n = xy, None, 2, xy.shape[0]
+        else:
+            x, y = up(xs, (torch.int16,), "xs").reshape(-1), up(ys, (torch.int16,), "ys").reshape(-1)
+            stride, n = 1, x.shape[0]
+        t = up(ts, (torch.float64, torch.float32), "ts").reshape(-1)
+        p = up(ps, (torch.uint8, torch.int8), "ps").reshape(-1)
+        if not (t.shape[0] == n and p.shape[0] == n and (y is None or y.shape[0] == n)):
+            raise ValueError("event columns differ in length")
+        if polarity not in ("pm1", "literal"):
+            raise ValueError("polarity must be 'pm1' or 'literal'")
+        if polarity == "pm1" and p.dtype != torch.uint8:
+            raise TypeError("polarity='pm1' maps uint8 / bool {0, 1} to -1 / +1; int8 columns are used literally")
+        p_kind = NativeColumns.P_KINDS["pm1" if polarity == "pm1" else ("i8" if p.dtype == torch.int8 else "u8")]
+        if t_offset is None:
+            t_offset = float(t[0].item()) if n else 0.0
+        ev = cls(None, None, None, None, native=NativeColumns(x, y, t, p, stride, t_offset, p_kind))
+        if n:   # ts[0], ts[-1] as the kernels see them, without a host pass over the column
+            ends = (ts[0], ts[-1]) if not isinstance(ts, torch.Tensor) else (t[0].item(), t[-1].item())
+            ev._t_ends = tuple(float(np.float32(np.float64(e) - t_offset)) for e in ends)
+        return ev
+
     # -- array-ish protocol used by the objective code -------------------------------------------------------
     def __len__(self):
-        return self.x.shape[0]
+        return self.native.n if self._cols is None else self._cols[0].shape[0]
 
     @property
     def dtype(self):
-        return self.x.dtype
+        return torch.float32 if self._cols is None else self._cols[0].dtype
 
     def t_at(self, k):
         """ts[k] as a python float (float64 value of the stored column)."""
         if self._t_host is not None:
             return float(self._t_host[k])
+        if self._t_ends is not None and k in (0, -1):
+            return self._t_ends[k]
         return float(self.t[k].item())
 
     def t_host(self):
@@ -66,7 +163,10 @@ class DeviceEvents:
     def p_absmax(self):
         """max |p| (one device reduction, cached): bounds the accumulator sums for fixed-point LDS accumulation."""
         if self._p_absmax is None:
-            self._p_absmax = float(self.p.abs().max().item()) if len(self) else 0.0
+            if self._cols is None and self.native.p_kind == 0:
+                self._p_absmax = 1.0 if len(self) else 0.0          # {0, 1} -> -1 / +1
+            else:
+                self._p_absmax = float(self.p.abs().max().item()) if len(self) else 0.0
         return self._p_absmax
 
     def slice(self, start, stop):
@@ -78,7 +178,8 @@ class DeviceEvents:
         return ev
 
     def scaled(self, factor):
-        ev = DeviceEvents(self.x, self.y, self.t, self.p, t_host=self._t_host)
+        ev = DeviceEvents(*(self._cols or (None,) * 4), t_host=self._t_host, native=self.native)
+        ev._cols, ev._t_ends = self._cols, self._t_ends
         ev.p_scale = self.p_scale * factor
         ev._buckets = self._buckets
         ev._p_absmax = self._p_absmax

@@ -10,17 +10,20 @@ from .. import _device as D
 from .. import _lib
 
 
-def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None, fresh=None):
+def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None, fresh=None,
+                      native=None):
     """Device-resident core of events_to_voxel_torch.  out=None: a new (B, H, W) float32 grid is returned; else the
-    events are accumulated into `out` (fresh=True: `out` is overwritten instead, no memset needed)."""
-    dev = xd.device
+    events are accumulated into `out` (fresh=True: `out` is overwritten instead, no memset needed).
+    native = events.NativeColumns replaces the four float32 columns (on-disk dtypes, widened in the kernels)."""
+    dev = xd.device if native is None else native.t.device
     H, W = int(sensor_size[0]), int(sensor_size[1])
     if out is None:
         out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         fresh = True
     oob = D.OobCounter(dev) if check else None
     from .. import tiled
-    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl, fresh=bool(fresh))
+    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl, fresh=bool(fresh),
+                    native=native)
     if check:
         oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
     return out
@@ -34,12 +37,31 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     out-of-range coordinates raising IndexError (:140-142 -> image.py:87-99, clip_out_of_range=False).
     Like the reference the float path needs float32 ts / ps (float64 raises RuntimeError).
     """
-    if device is None:
-        device = xs.device
-    assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
     if not temporal_bilinear:
         raise NotImplementedError("temporal_bilinear=False is dead code upstream (undefined names, "
                                   "voxel_grid.py:144-147)")
+    from ..events import DeviceEvents
+    if isinstance(xs, DeviceEvents):
+        # resident events (ys, ts, ps ignored), e.g. DeviceEvents.from_native(...) holding the on-disk dtypes
+        ev = xs
+        if len(ev) == 0:
+            raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
+        if ev.dtype != torch.float32:
+            raise RuntimeError("events_to_voxel_torch needs float32 event columns (voxel_grid.py:138-142)")
+        native = ev.native if ev._cols is None else None
+        cols = (None,) * 4 if native is not None else (ev.x, ev.y, ev.t, ev.p)
+        out = _voxel_f32_device(*cols, B, sensor_size, ev.t_at(0), ev.t_at(-1), native=native)
+        return out if device is None else out.to(device)
+    if device is None:
+        device = xs.device
+    assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
+    if (xs.dtype == torch.int16 and ys.dtype == torch.int16 and ts.dtype == torch.float32 and len(xs)
+            and ps.dtype in (torch.uint8, torch.int8, torch.bool)):
+        # int16 coordinates / 8-bit polarities as stored on disk: valid upstream too (xs.long(), ps * weights promotes
+        # to float32); here they are read as they are (9 B/event) instead of being widened to four float32 columns
+        ev = DeviceEvents.from_native(xs, ys, ts, ps, polarity="literal", t_offset=0.0)
+        out = _voxel_f32_device(None, None, None, None, B, sensor_size, ev.t_at(0), ev.t_at(-1), native=ev.native)
+        return out.to(device)
     if ts.dtype == torch.float64 or ps.dtype == torch.float64:
         raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
                            "destination and Double for the source.")

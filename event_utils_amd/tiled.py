@@ -54,15 +54,17 @@ def can_tile(cols, impl, min_events=None):
     return impl == "tiled" or n >= (TILED_MIN_EVENTS if min_events is None else min_events)
 
 
-def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None):
-    """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass)."""
+def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None, native=None):
+    """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass).
+    native = events.NativeColumns: the same sort reading the on-disk dtypes (evk_bucket_events_native_f32; the four
+    column arguments are then ignored)."""
     import torch
     L = _lib.lib()
     ntiles = L.evk_bucket_num_tiles(dom_h, dom_w, tw_log2, th_log2)
     if ntiles <= 0:
         raise _lib.EvkError("unsupported tiling %s of domain %s" % ((tw_log2, th_log2), (dom_h, dom_w)))
-    n = xd.shape[0]
-    dev = xd.device
+    n = xd.shape[0] if native is None else native.n
+    dev = xd.device if native is None else native.t.device
     if into is not None:
         records, bucket_start = into.records, into.bucket_start
     else:
@@ -70,9 +72,12 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
         bucket_start = torch.empty(int(L.evk_bucket_index_len(ntiles, n)), dtype=torch.int32, device=dev)
     nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
     scratch = _buf("bucket", nbytes, dev)
-    _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, key_mode, dom_h, dom_w, tw_log2,
-              th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
-              oob.ptr if oob is not None else None, stages, D.stream())
+    tail = (key_mode, dom_h, dom_w, tw_log2, th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
+            oob.ptr if oob is not None else None, stages, D.stream())
+    if native is None:
+        _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, *tail)
+    else:
+        _lib.call("evk_bucket_events_native_f32", *native.head(), *tail)
     return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n)
 
 
@@ -99,11 +104,17 @@ def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh):
               t_first, t_last, B, 1 if fresh else 0, D.ptr(out), D.ptr(staging), nbytes, D.stream())
 
 
-def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None, fresh=False):
+def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None, fresh=False, native=None):
     """events_to_voxel_torch core on device columns; accumulates into `out` (B, H, W).  fresh=True: `out` is
-    uninitialised memory and is fully (over)written -- the tiled path then needs no memset at all."""
+    uninitialised memory and is fully (over)written -- the tiled path then needs no memset at all.
+    native = events.NativeColumns: the tiled path buckets the on-disk dtypes directly (xd..pd may then be callables
+    producing the widened float32 columns, only called when the direct kernel has to take over)."""
     impl = impl or default_impl()
-    if can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536:
+    if native is not None:
+        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
+    else:
+        tileable = can_tile((xd, yd, td, pd), impl)
+    if tileable and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:     # sensors beyond 8192 tiles: enlarge the tiles
             tw, th = next(((a, b) for a, b in ((5, 5), (6, 5), (6, 6))
@@ -111,9 +122,11 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     else:
         tw = 0
     if tw:
-        bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
+        bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob, native=native)
         voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh)
         return out
+    if native is not None:
+        xd, yd, td, pd = native.widen()
     if fresh:
         out.zero_()
     _lib.call("evk_voxel_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], t_first, t_last, B, H, W,
@@ -151,7 +164,12 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     import math
     impl = impl or default_impl()
     vxs, vys = ((vx,), (vy,)) if batch is None else batch
-    if not (can_tile((ev.x, ev.y, ev.t, ev.p), impl, TILED_MIN_EVENTS_IWE) and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
+    native = ev.native if ev._cols is None else None     # on-disk dtypes not widened yet: bucket them as they are
+    if native is not None:
+        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS_IWE)
+    else:
+        tileable = can_tile((ev.x, ev.y, ev.t, ev.p), impl, TILED_MIN_EVENTS_IWE)
+    if not (tileable and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
         return None
     dom_h = max(int(bounds_h) + 1, ch)
     dom_w = max(int(bounds_w) + 1, cw)
@@ -176,13 +194,16 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     key = (1, dom_h, dom_w, tw, th)
     bk = ev._buckets.get(key)
     if bk is None:
-        bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
+        if native is not None:
+            bk = bucket_events(None, None, None, None, 1, dom_h, dom_w, tw, th, native=native)
+        else:
+            bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
         ev._buckets[key] = bk
     skey = (bk.ntiles, bk.n, S, planes, win_w, win_h)
     nbytes = _staging_bytes.get(skey)
     if nbytes is None:
         nbytes = _staging_bytes[skey] = int(_lib.lib().evk_iwe_tiled_staging_bytes(*skey))
-    staging = _buf("iwe_staging", nbytes, ev.x.device)
+    staging = _buf("iwe_staging", nbytes, ev.device)
     # argument prefix shared by evk_iwe_linvel_tiled_f32 and evk_cmax_variance_tiled_f32 (the batch entry points take
     # two host arrays instead of the scalars vx, vy)
     if batch is None:

@@ -243,6 +243,34 @@ int evk_bucket_events_f32(const float *x, const float *y, const float *t, const 
                           int dom_h, int dom_w, int tw_log2, int th_log2, float *records, uint32_t *bucket_index,
                           void *scratch, int64_t scratch_bytes, uint32_t *oob, int stages, void *stream);
 
+/* ---- native on-disk dtypes --------------------------------------------------------------
+ * The reference's event files hold xs, ys int16, ts float64, ps bool (HDF5, lib/data_formats/event_packagers.py:90-93)
+ * or xy int16 (N, 2), t float64, p uint8 (memmap, lib/data_formats/h5_to_memmap.py:119-121); its loaders widen them on
+ * the host (lib/data_loaders/memmap_dataset.py:19-24, hdf5_dataset.py:18-23: float32 coordinates, p * 2.0 - 1.0).
+ * These two entry points take the columns as stored -- 13 B/event instead of 16 -- and widen in registers:
+ *   x, y      int16; xy_stride 1 = two separate columns, 2 = one interleaved (N, 2) array passed as `x` (y ignored)
+ *   t         EVK_T_F64 / EVK_T_F32; the value used is (float)((double)t - t_offset): pass t_offset = ts[0] so that
+ *             epoch-scale float64 timestamps survive the narrowing ("t pre-offset by t[0] in f64")
+ *   p         EVK_P_U8_PM1: uint8 / bool {0, 1} -> 2p - 1;  EVK_P_U8: uint8 as is;  EVK_P_I8: int8 as is
+ * Everything downstream (records, tile kernels) is identical to the float32 path on the widened columns. */
+#define EVK_T_F32 0
+#define EVK_T_F64 1
+#define EVK_P_U8_PM1 0
+#define EVK_P_U8 1
+#define EVK_P_I8 2
+
+/* evk_bucket_events_f32 reading native columns (each 16-byte aligned, EVK_EALIGN otherwise). */
+int evk_bucket_events_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                                 double t_offset, const void *p, int p_kind, int64_t n, int key_mode, int dom_h,
+                                 int dom_w, int tw_log2, int th_log2, float *records, uint32_t *bucket_index,
+                                 void *scratch, int64_t scratch_bytes, uint32_t *oob, int stages, void *stream);
+
+/* Native columns -> the four float32 SoA columns every other entry point takes (any alignment); replaces the host
+ * casts of memmap_dataset.py:21-23 / hdf5_dataset.py:19-22. */
+int evk_native_to_columns_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                              double t_offset, const void *p, int p_kind, int64_t n, float *out_x, float *out_y,
+                              float *out_t, float *out_p, void *stream);
+
 /* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image; n = the event count that was
  * bucketed): one workgroup per work item, LDS accumulators (B x tile, float64), exclusive plain-store flush: vox += tile,
  * or vox = tile when `overwrite` (the caller then needs no memset: every cell is written).  The parts of a split tile

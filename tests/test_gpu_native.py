@@ -1,0 +1,151 @@
+"""GPU (-m gpu): events in the reference's ON-DISK dtypes (int16 x / y or interleaved xy, float64 / float32 t,
+bool / uint8 / int8 p) read by the kernels as they are -- against the golden vectors of the real
+reference (tests/golden/f15_native_dtypes.npz), the oracle's restatement of the loaders' widening, and the float32
+column path of the same library."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+def close(a, ref, tol=TOL):
+    a, ref = f64(a), f64(ref)
+    assert a.shape == ref.shape
+    assert np.max(np.abs(a - ref)) <= tol * max(np.max(np.abs(ref)), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def E():
+    import event_utils_amd as E
+    from event_utils_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return E
+
+
+def _native(seed, n, H, W, t0=1.6e9, span=0.5):
+    rng = np.random.default_rng(seed)
+    xs = rng.integers(0, W, n).astype(np.int16); ys = rng.integers(0, H, n).astype(np.int16)
+    ts = t0 + np.sort(rng.uniform(0.0, span, n))
+    ps = rng.integers(0, 2, n).astype(bool)
+    return xs, ys, ts, ps
+
+
+@pytest.mark.parametrize("n", [1, 7, 4099, 100_003])
+def test_widening_kernel_equals_the_loaders_casts(E, n):
+    xs, ys, ts, ps = _native(n, n, 180, 240)
+    ref = R.widen_native_events(xs, ys, ts, ps)
+    ev = E.DeviceEvents.from_native(xs, ys, ts, ps)
+    assert ev.native is not None and ev._cols is None and len(ev) == n and ev.dtype == torch.float32
+    assert ev.t_at(0) == 0.0 and ev.t_at(-1) == float(ref[2][-1])
+    for got, want in zip((ev.x, ev.y, ev.t, ev.p), ref):
+        assert np.array_equal(got.cpu().numpy(), want)
+    xy = np.stack((xs, ys), axis=1)
+    ev2 = E.DeviceEvents.from_native(xy, None, ts.astype(np.float32), ps.astype(np.uint8), t_offset=0.0)
+    ref2 = R.widen_native_events(xy, None, ts.astype(np.float32), ps, t_offset=0.0)
+    for got, want in zip((ev2.x, ev2.y, ev2.t, ev2.p), ref2):
+        assert np.array_equal(got.cpu().numpy(), want)
+    signed = (ps.astype(np.int8) * 3 - 1).astype(np.int8)                      # {-1, 2}: int8 is used literally
+    ev3 = E.DeviceEvents.from_native(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
+                                     torch.from_numpy(signed), polarity="literal")
+    assert np.array_equal(ev3.p.cpu().numpy(), signed.astype(np.float32))
+    assert np.array_equal(ev3.t.cpu().numpy(), ref[2])
+    with pytest.raises(TypeError):
+        E.DeviceEvents.from_native(xs.astype(np.int32), ys, ts, ps)
+    with pytest.raises(TypeError):
+        E.DeviceEvents.from_native(xs, ys, ts, signed)                          # 'pm1' needs {0, 1} uint8 / bool
+    with pytest.raises(ValueError):
+        E.DeviceEvents.from_native(xs, ys[:-1] if n > 1 else np.zeros(2, np.int16), ts, ps)
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("key_mode", [0, 1])
+def test_bucketing_native_equals_bucketing_widened(E, interleaved, key_mode):
+    from event_utils_amd import tiled
+    n, H, W = 300_001, 200, 320
+    xs, ys, ts, ps = _native(3, n, H, W)
+    ev = (E.DeviceEvents.from_native(np.stack((xs, ys), axis=1), None, ts, ps) if interleaved
+          else E.DeviceEvents.from_native(xs, ys, ts, ps))
+    bn = tiled.bucket_events(None, None, None, None, key_mode, H, W, 4, 3, native=ev.native)
+    assert ev._cols is None                                       # bucketed without widening
+    bw = tiled.bucket_events(ev.x, ev.y, ev.t, ev.p, key_mode, H, W, 4, 3)
+    T = bn.ntiles
+    assert np.array_equal(bn.bucket_start[:T + 1].cpu().numpy(), bw.bucket_start[:T + 1].cpu().numpy())
+    a, b = bn.records.cpu().numpy(), bw.records.cpu().numpy()
+    bs = bn.bucket_start[:T + 1].cpu().numpy().astype(np.int64)
+    seg = np.searchsorted(bs, np.arange(n), side="right") - 1     # same multiset of records inside every tile
+    order = lambda r: np.lexsort((r[:, 3], r[:, 1], r[:, 0], r[:, 2], seg))
+    assert np.array_equal(a[order(a)], b[order(b)])
+
+
+@pytest.mark.parametrize("impl", ["tiled", "direct", "auto"])
+def test_voxel_from_on_disk_dtypes_matches_reference(E, golden, monkeypatch, impl):
+    monkeypatch.setenv("EVK_IMPL", impl)
+    g = golden("f15_native_dtypes")
+    ss, B = tuple(int(v) for v in g["sensor_size"]), int(g["B"])
+    ev = E.DeviceEvents.from_native(g["xs"], g["ys"], g["ts"], g["ps"])
+    v = E.events_to_voxel_torch(ev, None, None, None, B, sensor_size=ss)
+    assert v.is_cuda and v.dtype == torch.float32
+    close(v.cpu().numpy(), g["voxel_torch_widened"])
+    close(v.cpu().numpy(), g["voxel_numpy_f64"])                  # epoch-scale float64 timestamps survive
+    xy = np.stack((g["xs"], g["ys"]), axis=1)
+    v2 = E.events_to_voxel_torch(E.DeviceEvents.from_native(xy, None, g["ts"], g["ps"].astype(np.uint8)), None, None,
+                                 None, B, sensor_size=ss)
+    close(v2.cpu().numpy(), g["voxel_torch_widened"])
+    # the reference signature fed narrow torch dtypes (valid upstream): int16 / int16 / float32 / uint8 used literally
+    t32 = torch.from_numpy((g["ts"] - g["ts"][0]).astype(np.float32))
+    for p8 in (torch.from_numpy(g["ps"].astype(np.uint8)), torch.from_numpy(g["ps"])):
+        v3 = E.events_to_voxel_torch(torch.from_numpy(g["xs"]), torch.from_numpy(g["ys"]), t32, p8, B, sensor_size=ss)
+        assert v3.device.type == "cpu"
+        close(v3.numpy(), g["voxel_torch_narrow_literal"])
+    with pytest.raises(RuntimeError):                             # float64 ts: dtype error, as upstream
+        E.events_to_voxel_torch(torch.from_numpy(g["xs"]), torch.from_numpy(g["ys"]), torch.from_numpy(g["ts"]),
+                                torch.from_numpy(g["ps"].astype(np.uint8)), B, sensor_size=ss)
+    bad = g["xs"].copy(); bad[17] = ss[1] + 3
+    with pytest.raises(IndexError):
+        E.events_to_voxel_torch(E.DeviceEvents.from_native(bad, g["ys"], g["ts"], g["ps"]), None, None, None, B,
+                                sensor_size=ss)
+
+
+def test_voxel_native_at_scale_equals_float_columns(E, monkeypatch):
+    H, W, B, n = 480, 640, 5, 4_000_000
+    xs, ys, ts, ps = _native(8, n, H, W, span=0.1)
+    ev = E.DeviceEvents.from_native(xs, ys, ts, ps)
+    vn = E.events_to_voxel_torch(ev, None, None, None, B, sensor_size=(H, W))
+    assert ev._cols is None                                       # the tiled path never widened the columns
+    cols = [torch.from_numpy(c).cuda() for c in R.widen_native_events(xs, ys, ts, ps)]
+    vf = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    close(vn.cpu().numpy(), vf.cpu().numpy(), 1e-6)
+    ref = R.events_to_voxel_torch(*R.widen_native_events(xs[:300_000], ys[:300_000], ts[:300_000], ps[:300_000]), B,
+                                  sensor_size=(H, W), accum="f64")
+    sub = E.DeviceEvents.from_native(xs[:300_000], ys[:300_000], ts[:300_000], ps[:300_000])
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    close(E.events_to_voxel_torch(sub, None, None, None, B, sensor_size=(H, W)).cpu().numpy(), ref)
+    assert abs(vn.double().sum().item() - float(np.sum(ps * 2.0 - 1.0))) <= 1e-3 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("impl", ["tiled", "direct"])
+def test_contrast_maximisation_on_native_events(E, golden, monkeypatch, impl):
+    monkeypatch.setenv("EVK_IMPL", impl)
+    g = golden("f15_native_dtypes")
+    ss = tuple(int(v) for v in g["sensor_size"])
+    ev = E.DeviceEvents.from_native(g["xs"], g["ys"], g["ts"], g["ps"])
+    obj, w = E.variance_objective(), E.linvel_warp()
+    for k, (q, f, gr) in enumerate(zip(g["cmax_params"], g["cmax_f"], g["cmax_g"])):
+        assert abs(obj.evaluate_function(q, ev, None, None, None, w, ss, 1.0) - f) <= TOL * abs(f)
+        got = obj.evaluate_gradient(q, ev, None, None, None, w, ss, 1.0)
+        assert np.max(np.abs(f64(got) - gr)) <= TOL * max(np.max(np.abs(gr)), 1e-3)
+        if impl == "tiled" and k == 1:
+            assert ev._cols is None        # bucketed from the on-disk dtypes (the third flow is large enough for the
+                                           # direct kernel to take over, which widens the columns once)
+    iwe, _ = E.get_iwe(g["cmax_params"][1], ev, None, None, None, w, ss)
+    xf, yf, tf, pf = f64(g["xs"]), f64(g["ys"]), g["ts"] - g["ts"][0], g["ps"] * 2.0 - 1.0
+    close(iwe, R.get_iwe(g["cmax_params"][1], xf, yf, tf, pf, R.linvel_warp(), ss, accum="f64")[0])

@@ -266,3 +266,30 @@ def test_f14_rms_lifespan_cut_segmentation(golden):
         assert len(cut[0]) == g["cut_len"][i] and cut[2][0] == g["cut_first_t"][i]
     assert np.array_equal(R.segmentation_mask_from_d_iwe(g["seg_d_iwe"]), g["seg_mask"])
     assert np.array_equal(R.segmentation_mask_from_d_iwe(g["seg_d_iwe"], th=0.05), g["seg_mask_th"])
+
+
+def test_f15_native_dtypes(golden):
+    """Events in the reference's on-disk dtypes (int16 / float64 epoch seconds / bool): the loaders' widening restated
+    (widen_native_events) + the torch path == what the reference computes; the numpy path takes them as stored."""
+    g = golden("f15_native_dtypes")
+    xs, ys, ts, ps = g["xs"], g["ys"], g["ts"], g["ps"]
+    ss, B = tuple(int(v) for v in g["sensor_size"]), int(g["B"])
+    assert xs.dtype == np.int16 and ts.dtype == np.float64 and ps.dtype == np.bool_
+    assert np.array_equal(R.events_to_voxel(xs, ys, ts, ps * 2.0 - 1.0, B, sensor_size=ss), g["voxel_numpy_f64"])
+    cols = R.widen_native_events(xs, ys, ts, ps)
+    assert all(c.dtype == np.float32 for c in cols) and set(np.unique(cols[3])) == {-1.0, 1.0} and cols[2][0] == 0
+    assert np.array_equal(R.events_to_voxel_torch(*cols, B, sensor_size=ss), g["voxel_torch_widened"])
+    xy = np.stack((xs, ys), axis=1)
+    assert all(np.array_equal(a, b) for a, b in zip(R.widen_native_events(xy, None, ts, ps), cols))
+    lit = R.widen_native_events(xs, ys, cols[2], ps.astype(np.uint8), t_offset=0.0, polarity="literal")
+    assert np.array_equal(lit[2], cols[2]) and set(np.unique(lit[3])) == {0.0, 1.0}
+    assert np.array_equal(R.events_to_voxel_torch(*lit, B, sensor_size=ss), g["voxel_torch_narrow_literal"])
+    # float32 of the ABSOLUTE epoch timestamps would be useless: every event collapses onto one value
+    assert len(np.unique(ts.astype(np.float32))) == 1
+    # the float32 torch grid agrees with the float64 numpy grid to float32 rounding of t_norm
+    assert np.max(np.abs(g["voxel_torch_widened"] - g["voxel_numpy_f64"])) <= 1e-5 * np.max(np.abs(g["voxel_numpy_f64"]))
+    obj, w = R.variance_objective(), R.linvel_warp()
+    xf, yf, tf, pf = xs.astype(np.float64), ys.astype(np.float64), ts - ts[0], ps * 2.0 - 1.0
+    for q, f, gr in zip(g["cmax_params"], g["cmax_f"], g["cmax_g"]):
+        assert np.float64(obj.evaluate_function(q, xf, yf, tf, pf, w, ss, blur_sigma=1.0)) == f
+        assert np.array_equal(f64(obj.evaluate_gradient(q, xf, yf, tf, pf, w, ss, blur_sigma=1.0)), gr)
