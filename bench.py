@@ -170,6 +170,9 @@ def main():
         "roofline": roofline,
     }
 
+    if rank == 0 and world == 1:
+        result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
+                                               max(5, args.steps))
     if rank == 0 and world == 1 and not args.no_cmax:
         result["cmax"] = bench_cmax(E, DeviceEvents, dev, impl)
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -178,6 +181,37 @@ def main():
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def bench_native(DeviceEvents, voxel, x, y, t, p, B, H, W, impl, reps):
+    """The same workload held in the reference's on-disk dtypes (int16 x, y; float64 epoch-second t; uint8 {0,1} p:
+    13 B/event): (a) bucketed straight from those columns, (b) widened to four float32 columns
+    by evk_native_to_columns_f32 first (what a loader's casts amount to, done on the device) and then voxelised."""
+    ev = DeviceEvents.from_native(x.astype(np.int16), y.astype(np.int16), 1.6e9 + t.astype(np.float64),
+                                  ((p + 1) / 2).astype(np.uint8))
+    nat = ev.native
+    out = torch.empty((B, H, W), dtype=torch.float32, device=nat.t.device)
+    t_first, t_last = ev.t_at(0), ev.t_at(-1)
+
+    def direct_from_native():
+        voxel(None, None, None, None, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True, native=nat)
+
+    def widen_then_voxel():
+        cols = nat.widen()
+        voxel(*cols, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True)
+    res = {"bytes_per_event": 13, "layout": "x,y int16 + t float64 + p uint8 columns"}
+    for name, fn in (("from_native_ms", direct_from_native), ("widen_then_f32_path_ms", widen_then_voxel)):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res[name] = round(a.elapsed_time(b) / reps, 4)
+    res["from_native_Mevents_s"] = round(len(x) / res["from_native_ms"] / 1e3, 1)
+    return res
 
 
 def pmc_traffic(kernel, n):
