@@ -170,6 +170,12 @@ def main():
         "roofline": roofline,
     }
 
+    if use_dist and not args.no_cmax:
+        try:   # extra information only: it must never cost the scaling run its JSON line
+            c5 = bench_c5(E, DeviceEvents, dist, rank, world, dev, impl)
+        except Exception as e:  # noqa: BLE001
+            c5 = {"error": repr(e)}
+        result["c5"] = c5
     if rank == 0 and world == 1:
         result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
                                                max(5, args.steps))
@@ -319,6 +325,59 @@ def bench_cmax(E, DeviceEvents, dev, impl):
                     "iters_per_s": round(iters / dt, 2), "evals_per_s": round((cnt["f"] + cnt["g"]) / dt, 2)}
     out["c4"] = c4
     return out
+
+
+def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
+    """configs[4]: 50 M events per GPU (400 M on 8), 1280x720, event-sharded: every rank holds one time slice of the
+    stream; voxel grid (5 bins) and IWE (+dIWE) are all-reduced over RCCL, the blur / variance / gradient run replicated.
+    Timed like the main metric: barrier + synchronize on both sides, max over ranks."""
+    from event_utils_amd.distributed import shard_objective
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    H5, W5, n5, B5 = 720, 1280, 50_000_000, 5
+    span = 0.1 / world
+    rng = np.random.default_rng(40 + rank)
+    x = rng.uniform(1, W5 - 1, n5).astype(np.float32)
+    y = rng.uniform(1, H5 - 1, n5).astype(np.float32)
+    t = np.sort(rng.uniform(rank * span, (rank + 1) * span, n5)).astype(np.float32)
+    p = (rng.integers(0, 2, n5) * 2 - 1).astype(np.float32)
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    lo = torch.tensor([float(t[0])], device=dev)
+    hi = torch.tensor([float(t[-1])], device=dev)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    t_first, t_last = float(lo.item()), float(hi.item())
+    del x, y, t, p
+    obj, w = shard_objective(E.variance_objective(), t_last), E.linvel_warp()
+    obj.sensor_size, obj.impl = (H5, W5), impl
+    prm = np.array([30.0, -20.0])
+    grid = torch.empty((B5, H5, W5), dtype=torch.float32, device=dev)
+    xi, yi = ev.x.floor(), ev.y.floor()           # voxelisation takes pixel coordinates
+
+    def voxel():
+        _voxel_f32_device(xi, yi, ev.t, ev.p, B5, (H5, W5), t_first, t_last, out=grid, check=False, impl=impl, fresh=True)
+        dist.all_reduce(grid, op=dist.ReduceOp.SUM)
+
+    res = {"workload": "configs[4]: %d x 50M events, 1280x720, event-sharded, RCCL all-reduce of the grids" % world}
+    for name, fn, reps in (("voxel", voxel, 10),
+                           ("f", lambda: obj.evaluate_function(prm, ev, None, None, None, w, (H5, W5), 1.0), 10),
+                           ("grad", lambda: obj.evaluate_gradient(prm, ev, None, None, None, w, (H5, W5), 1.0), 10)):
+        for _ in range(2):
+            fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        res[name + "_ms"] = round(dt * 1e3, 4)
+        res[name + "_Mevents_per_s"] = round(n5 * world / dt / 1e6, 1)
+        if name != "voxel":
+            res[name + "_evals_per_s"] = round(1.0 / dt, 2)
+    return res
 
 
 def cpu_baseline(x, y, t, p):
