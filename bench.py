@@ -335,23 +335,33 @@ def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
     from event_utils_amd.representations.voxel_grid import _voxel_f32_device
     H5, W5, n5, B5 = 720, 1280, 50_000_000, 5
     span = 0.1 / world
-    rng = np.random.default_rng(40 + rank)
-    x = rng.uniform(1, W5 - 1, n5).astype(np.float32)
-    y = rng.uniform(1, H5 - 1, n5).astype(np.float32)
-    t = np.sort(rng.uniform(rank * span, (rank + 1) * span, n5)).astype(np.float32)
-    p = (rng.integers(0, 2, n5) * 2 - 1).astype(np.float32)
-    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
-    lo = torch.tensor([float(t[0])], device=dev)
-    hi = torch.tensor([float(t[-1])], device=dev)
+    ok = torch.ones(1, device=dev)
+    try:    # the part that can fail on one rank only (memory): agree on it before any further collective
+        rng = np.random.default_rng(40 + rank)
+        x = rng.uniform(1, W5 - 1, n5).astype(np.float32)
+        y = rng.uniform(1, H5 - 1, n5).astype(np.float32)
+        t = np.sort(rng.uniform(rank * span, (rank + 1) * span, n5)).astype(np.float32)
+        p = (rng.integers(0, 2, n5) * 2 - 1).astype(np.float32)
+        ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+        grid = torch.empty((B5, H5, W5), dtype=torch.float32, device=dev)
+        xi, yi = ev.x.floor(), ev.y.floor()           # voxelisation takes pixel coordinates
+        ends = (float(t[0]), float(t[-1]))
+        del x, y, t, p
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        ok.zero_()
+        err = repr(e)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() == 0:
+        return {"error": "setup failed on at least one rank" + (": " + err if "err" in locals() else "")}
+    lo = torch.tensor([ends[0]], device=dev)
+    hi = torch.tensor([ends[1]], device=dev)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     t_first, t_last = float(lo.item()), float(hi.item())
-    del x, y, t, p
     obj, w = shard_objective(E.variance_objective(), t_last), E.linvel_warp()
     obj.sensor_size, obj.impl = (H5, W5), impl
     prm = np.array([30.0, -20.0])
-    grid = torch.empty((B5, H5, W5), dtype=torch.float32, device=dev)
-    xi, yi = ev.x.floor(), ev.y.floor()           # voxelisation takes pixel coordinates
 
     def voxel():
         _voxel_f32_device(xi, yi, ev.t, ev.p, B5, (H5, W5), t_first, t_last, out=grid, check=False, impl=impl, fresh=True)

@@ -4,7 +4,8 @@
 //   1. events are bucketed ONCE by output tile (counting sort: per-block tile histogram -> scan -> scatter into
 //      16-byte (x, y, t, p) records, contiguous per tile);
 //   2. one workgroup per tile streams its records with 16 B/lane coalesced loads and accumulates in an LDS tile
-//      (ds_add_f32, ~TB/s-class);
+//      (64-bit LDS atomics: ds_add_f64 for voxel grids, fixed-point ds_add_u64 for IWE windows; ds_add_f32 is ~10x
+//      slower on gfx950, tools/lds_probe.hip);
 //   3. the tile is flushed with plain, coalesced stores: voxel tiles are owned exclusively; IWE windows (tile + halo,
 //      shifted by the flow) go to a staging area and a gather kernel sums the (<= a few) windows covering each pixel.
 // No global atomics remain on the hot path (only the rare event that lands outside its block's window uses one).
