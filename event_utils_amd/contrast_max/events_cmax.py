@@ -233,29 +233,32 @@ def grid_cmax(xs, ys, ts, ps, roi_size=(20, 20), step=None, warp=None, obj=None,
     refinement at blur 1.0, then the objective of the IWE of ALL events at the cell's flow.  Returns (params, rois as
     [y, x, step_y, step_x], function values).  Like upstream, `obj` is replaced per cell by
     variance_objective(adaptive_lifespan=True, minimum_events=105) and the resolution is inferred from the events
-    (max + 1, lib/util/event_util.py:5-13), so xs / ys must be integer-valued.
+    (max + 1, lib/util/event_util.py:5-13), so xs / ys must be integer-valued.  The events are uploaded once; the cells
+    are selected from the resident columns on the device.
     """
     warp = linvel_warp() if warp is None else warp
     step = roi_size if step is None else step
-    xs, ys, ts, ps = (np.asarray(a) for a in (xs, ys, ts, ps))
-    resolution = [int(np.max(ys)) + 1, int(np.max(xs)) + 1]
-    everything = DeviceEvents.from_arrays(xs, ys, ts, ps) if getattr(warp, "fused_kernel", None) == "linvel" else None
+    if getattr(warp, "fused_kernel", None) != "linvel":
+        raise NotImplementedError("grid_cmax is provided for the fused linear-flow warp (upstream hard-wires it too, :47)")
+    # the events go to the device once; the cells are cut out of the resident columns there
+    everything = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
+    ex, ey = everything.x, everything.y
+    resolution = [int(ey.max().item()) + 1, int(ex.max().item()) + 1]
     results_params, results_rois, results_f_evals = [], [], []
     for xc in range(0, resolution[1], step[1]):
-        in_cols = np.flatnonzero((xs >= xc) & (xs < xc + step[1]))
+        in_cols = (ex >= xc) & (ex < xc + step[1])
         for yc in range(0, resolution[0], step[0]):
-            sel = in_cols[(ys[in_cols] >= yc) & (ys[in_cols] < yc + step[0])]
-            if len(sel) <= min_events:
+            sel = in_cols & (ey >= yc) & (ey < yc + step[0])
+            if int(sel.sum().item()) <= min_events:
                 continue
-            roi = (xs[sel], ys[sel], ts[sel], ps[sel])
+            roi = DeviceEvents(ex[sel], ey[sel], everything.t[sel], everything.p[sel])
             obj = variance_objective(adaptive_lifespan=True, minimum_events=105)
-            params = optimize_contrast(*roi, warp, obj, numeric_grads=False, blur_sigma=2.0, img_size=resolution,
-                                       grid_search_init=True)
-            params = optimize_contrast(*roi, warp, obj, numeric_grads=False, blur_sigma=1.0, img_size=resolution,
-                                       x0=params)
-            whole = (everything, None, None, None) if everything is not None else (xs, ys, ts, ps)
-            iwe, _ = get_iwe(params, *whole, warp, resolution, use_polarity=True, compute_gradient=False,
-                             return_events=False)
+            params = optimize_contrast(roi, None, None, None, warp, obj, numeric_grads=False, blur_sigma=2.0,
+                                       img_size=resolution, grid_search_init=True)
+            params = optimize_contrast(roi, None, None, None, warp, obj, numeric_grads=False, blur_sigma=1.0,
+                                       img_size=resolution, x0=params)
+            iwe, _ = get_iwe(params, everything, None, None, None, warp, resolution, use_polarity=True,
+                             compute_gradient=False, return_events=False)
             results_params.append(params)
             results_rois.append([yc, xc, step[0], step[1]])
             results_f_evals.append(obj.evaluate_function(iwe=iwe))

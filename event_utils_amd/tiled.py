@@ -265,18 +265,20 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
 
 
 def _time_ms(fn, reps):
+    """Average duration of fn's launches: `reps` back-to-back calls between ONE pair of HIP events on the launch
+    stream.  (An event pair around every single launch adds the ~7-10 us the command processor needs between the
+    event's timestamp write and the dispatch, which made a 62 us kernel read as 72 us against rocprofv3's
+    kernel-trace; back to back the GPU stays fed, the host enqueue being shorter than the kernels timed here.)"""
     import torch
     fn()
     torch.cuda.synchronize()
-    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    for i in range(reps):
-        e0[i].record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
         fn()
-        e1[i].record()
+    e1.record()
     torch.cuda.synchronize()
-    ts = [a.elapsed_time(b) for a, b in zip(e0, e1)]
-    return float(sum(ts) / len(ts))
+    return float(e0.elapsed_time(e1) / reps)
 
 
 def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps=10):
