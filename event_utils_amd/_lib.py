@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
+EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE = 1, 2, 4
 
 P = c_void_p  # every device / host pointer crosses as void*
 
@@ -49,6 +50,7 @@ SIGNATURES = {
                                            c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
                                            P, c_int, P, c_int64, P, P, P, c_int64, P],
     "evk_objective_stats_f32": [P, c_int, c_int, P, c_int, c_double, c_double, P, P, c_int64, P],
+    "evk_objective_variance_fg_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_objective_gradsums_f32": [P, P, c_int, c_int, P, c_int, c_uint32, c_int, c_double, P, P, c_int64, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
     "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P],

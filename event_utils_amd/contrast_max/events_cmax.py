@@ -199,6 +199,21 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
     elif numeric_grads:
         argmax = optimizer(objective.evaluate_function, x0, args=args, epsilon=1, disp=False,
                            callback=objective.iter_update)
+    elif hasattr(objective, "evaluate_function_and_gradient") and fused and optimizer is opt.fmin_bfgs:
+        # the line search asks for f and f' at the same trial point (phi, then derphi): one pass over the events
+        # yields both, the gradient is kept for the call that follows
+        last = {}
+
+        def f_and_keep(x, *a):
+            fv, gv = objective.evaluate_function_and_gradient(x, *a)
+            last["x"], last["g"] = np.array(x, dtype=np.float64, copy=True), gv
+            return fv
+
+        def g_from_last(x, *a):
+            if "x" in last and np.array_equal(last["x"], np.asarray(x, dtype=np.float64)):
+                return last["g"]
+            return objective.evaluate_gradient(x, *a)
+        argmax = optimizer(f_and_keep, x0, fprime=g_from_last, args=args, disp=False, callback=objective.iter_update)
     else:
         argmax = optimizer(objective.evaluate_function, x0, fprime=objective.evaluate_gradient, args=args, disp=False,
                            callback=objective.iter_update)

@@ -365,6 +365,26 @@ class variance_objective(objective_function):
                 vals[i] = self.evaluate_function(pts[i], xs, ys, ts, ps, warpfunc, img_size, blur_sigma)
         return vals
 
+    def evaluate_function_and_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None,
+                                       img_size=None, blur_sigma=None):
+        """(evaluate_function(params), evaluate_gradient(params)) from ONE pass over the events: both come from the
+        same IWE / dIWE, and a BFGS line search asks for both at every trial point (events_cmax.py:345; scipy's
+        phi / derphi).  Values identical to the two separate calls."""
+        dev = D.require_gpu()
+        blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
+        flags = _lib.EVK_POST_MIX if self.reference_exact else _lib.EVK_POST_BLUR_IWE
+        res = self._one_call(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, True, flags | _lib.EVK_POST_VALUE)
+        if res is None:
+            iwe, d_iwe = self._iwe(params, xs, ys, ts, ps, warpfunc, img_size, True)
+            w, radius = _blur_kernel(blur_sigma)
+            iwe, d_iwe = iwe.contiguous(), d_iwe.contiguous()
+            out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+            _lib.call("evk_objective_variance_fg_f32", D.ptr(iwe), D.ptr(d_iwe), iwe.shape[0], iwe.shape[1],
+                      D.host_ptr(w) if w is not None else None, radius, flags, D.ptr(out), D.ptr(scratch), nbytes,
+                      D.stream())
+            res = out.cpu().numpy()
+        return np.float32(-res[3]), -(res[:2].astype(np.float32))
+
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):
         """-mean(2 (iwe-mean(iwe)) * blur(d_iwe)[i]) (objectives.py:238-264).  reference_exact keeps Q4 (3-D blur mixes

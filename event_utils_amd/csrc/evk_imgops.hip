@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_blur_axis(const float *__restrict
 // ---------------------------------------------------------------------------------------------------------
 
 #define EVK_REDUCE_MAX_BLOCKS 4096
-#define EVK_REDUCE_K 5
+#define EVK_REDUCE_K 7
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -73,7 +73,7 @@ template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_partial(const float *__restrict__ a,
                                                               const float *__restrict__ d, int64_t n,
                                                               double *__restrict__ partials) {
-    double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
+    double acc[EVK_REDUCE_K] = {};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double v = (double)a[i];
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_partial(const float *__res
 template <int MODE, bool WIDE = false>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
                                                             int64_t n, double *__restrict__ out) {
-    double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
+    double acc[EVK_REDUCE_K] = {};
     partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
     out += (WIDE ? 8 : 4) * blockIdx.x;
     for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
@@ -118,6 +118,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
             out[1] = 2.0 * inv * (tot[4] - mean * tot[2]);
             out[2] = mean;
             out[3] = tot[0];
+            if constexpr (MODE == 3) {  // value + gradient: [g0, g1, mean v, var v] of the blurred image v
+                const double mv = tot[5] * inv;
+                out[2] = mv;
+                out[3] = tot[6] * inv - mv * mv;
+            }
         }
         if constexpr (WIDE && MODE == 0) {  // stats: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
             out[4] = tot[2], out[5] = tot[3], out[6] = tot[4], out[7] = 0.0;
@@ -195,6 +200,8 @@ __device__ __forceinline__ unsigned int float_order_bits(float f) {  // monotone
 
 // MODE 0: sum v, sum v^2 of the blurred image.  MODE 1: sum g(a), sum d0, sum d1, sum g(a) d0, sum g(a) d1.
 // MODE 2: sum v, sum v^2, sum exp(v), sum exp(-p v), count(v > thresh) and max v of the blurred image.
+// MODE 3: MODE 1 and MODE 0 together (function value AND gradient of one evaluation): the 5 sums of MODE 1, then
+//         sum v, sum v^2 of the blurred IWE.
 template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restrict__ iwe,
                                                           const float *__restrict__ diwe, int ch, int cw,
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     const int64_t plane = (int64_t)ch * cw;
     iwe += blockIdx.y * plane;                                         // MODE 0 batched over image planes
     partials += (int64_t)blockIdx.y * gridDim.x * EVK_REDUCE_K;
-    double acc[EVK_REDUCE_K] = {0, 0, 0, 0, 0};
+    double acc[EVK_REDUCE_K] = {};
     if constexpr (MODE == 0 || MODE == 2) {
         float v[4];
         blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
@@ -248,7 +255,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
             };
             blur_tile(patch, inter, bw, y0, x0, ch, cw, load_mixed, d[c]);
         }
-        if (flags & EVK_POST_BLUR_IWE) {
+        if (MODE == 3 || (flags & EVK_POST_BLUR_IWE)) {
             blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, a);
         }
 #pragma unroll
@@ -265,6 +272,10 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
                 acc[2] += (double)d[1][k];
                 acc[3] += av * (double)d[0][k];
                 acc[4] += av * (double)d[1][k];
+                if constexpr (MODE == 3) {
+                    acc[5] += (double)a[k];
+                    acc[6] += (double)a[k] * (double)a[k];
+                }
             }
         }
     }
@@ -334,6 +345,8 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     if (!iwe || h <= 0 || w <= 0 || !out || !scratch || (MODE == 1 && !diwe) || nplanes < 1 || nplanes > 8)
         return EVK_EINVAL;
     if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
+    static const double identity[1] = {1.0};
+    if (MODE == 3 && radius < 0) host_weights = identity, radius = 0, flags &= ~EVK_POST_MIX;  // no blur = 1-tap kernel
     if (radius < 0) {  // blur_sigma <= 0: plain reductions
         for (int k = 0; k < nplanes; ++k) {
             const int rc = launch_reduce<MODE>(iwe + (int64_t)k * h * w, diwe, (int64_t)h * w, out + 4 * k, scratch,
@@ -367,6 +380,12 @@ extern "C" int evk_objective_variance_grad_f32(const float *iwe, const float *di
                                                const double *host_weights, int radius, uint32_t flags, double *out,
                                                void *scratch, int64_t scratch_bytes, void *stream) {
     return launch_post<1>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream);
+}
+
+extern "C" int evk_objective_variance_fg_f32(const float *iwe, const float *diwe, int h, int w,
+                                             const double *host_weights, int radius, uint32_t flags, double *out,
+                                             void *scratch, int64_t scratch_bytes, void *stream) {
+    return launch_post<3>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream);
 }
 
 extern "C" int evk_objective_variance_planes_f32(const float *imgs, int nplanes, int h, int w,

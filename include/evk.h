@@ -185,10 +185,19 @@ int evk_objective_variance_f32(const float *iwe, int h, int w, const double *hos
 
 #define EVK_POST_MIX 1u      /* scipy's 3-D filter of the (2, H, W) dIWE also mixes the two channels (quirk Q4) */
 #define EVK_POST_BLUR_IWE 2u /* use the blurred IWE in the gradient (reference_exact=False); default raw (Q5)    */
+#define EVK_POST_VALUE 4u    /* evk_cmax_variance_tiled_f32 with EVK_IWE_GRADIENT: also the function value (out as
+                                evk_objective_variance_fg_f32)                                                   */
 /* evaluate_gradient (objectives.py:252-264): out as evk_variance_grad_f32 with diwe replaced by its blurred version. */
 int evk_objective_variance_grad_f32(const float *iwe, const float *diwe, int h, int w, const double *host_weights,
                                     int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes,
                                     void *stream);
+
+/* evaluate_function AND evaluate_gradient of one parameter vector from one IWE / dIWE (what a BFGS line search asks for
+ * at every trial point, events_cmax.py:345): out = [g0, g1, mean v, var v] with g as evk_objective_variance_grad_f32
+ * (same flags) and v = gaussian_filter(iwe) as evk_objective_variance_f32; values identical to the two separate calls. */
+int evk_objective_variance_fg_f32(const float *iwe, const float *diwe, int h, int w, const double *host_weights,
+                                  int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes,
+                                  void *stream);
 
 /* ---- generic objective reductions: the objectives of objectives.py:266-596 other than the variance one differ only in
  * the scalar they take from the (blurred) IWE -----------------------------------------------------------------------
@@ -302,7 +311,8 @@ int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index,
 /* variance_objective.evaluate_function / evaluate_gradient (objectives.py:211-264) in ONE call on bucketed records:
  * memset(iwe_buf) -> evk_iwe_linvel_tiled_f32 -> evk_objective_variance[_grad]_f32.  iwe_buf is (1, ch, cw) or, with
  * EVK_IWE_GRADIENT, (3, ch, cw) float32 = IWE followed by the two dIWE planes (left filled, un-blurred).
- * out: as evk_objective_variance_f32 / evk_objective_variance_grad_f32. */
+ * out: as evk_objective_variance_f32 / evk_objective_variance_grad_f32 / (post_flags & EVK_POST_VALUE)
+ * evk_objective_variance_fg_f32. */
 int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                                 int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
                                 double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,

@@ -380,6 +380,14 @@ def test_f9_optimize(E, golden, mode):
         trace.append(("g", np.array(prm, float), None, f64(v)))
         return v
     obj.evaluate_function, obj.evaluate_gradient = frec, grec
+    fg0 = obj.evaluate_function_and_gradient
+
+    def fgrec(prm, *a, **k):        # one pass yields the value and the gradient the line search asks for next
+        fv, gv = fg0(prm, *a, **k)
+        trace.append(("f", np.array(prm, float), float(fv), None))
+        trace.append(("g", np.array(prm, float), None, f64(gv)))
+        return fv, gv
+    obj.evaluate_function_and_gradient = fgrec
     ng0, ngrads = obj.evaluate_numeric_gradient, []
     obj.evaluate_numeric_gradient = lambda prm, *a, **k: (ngrads.append((np.array(prm, float), ng0(prm, *a, **k))), ngrads[-1][1])[1]
     import warnings
@@ -406,11 +414,42 @@ def test_f9_optimize(E, golden, mode):
             assert np.max(np.abs(gv - g[mode + "_g"][k])) <= TOL * np.max(np.abs(g[mode + "_g"][k])) + 1e-9
         k += 1
     if mode == "analytic":
+        assert len(trace) >= 4
         assert np.linalg.norm(np.asarray(argmax, float) - g[mode + "_argmax"]) < 1.5
         assert np.linalg.norm(np.asarray(argmax, float) - np.array([40., -25.])) < 2.0
     fa = f64(f0(np.asarray(argmax, float), x, y, t, p, E.linvel_warp(), tuple(g8["img_size"]), 1.0))
     fr = f64(f0(g[mode + "_argmax"], x, y, t, p, E.linvel_warp(), tuple(g8["img_size"]), 1.0))
     assert fa <= fr + 0.02 * abs(fr)        # at least as good an optimum as the reference found
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("n", [30_000, 400_000])
+def test_value_and_gradient_in_one_pass_equal_the_separate_calls(E, golden, exact, n):
+    """evaluate_function_and_gradient (evk_objective_variance_fg_f32 / EVK_POST_VALUE) == evaluate_function +
+    evaluate_gradient, on the direct-kernel regime (30 k events) and the tile-bucketed one (400 k), with and without
+    blur, reference-exact and consistent gradient; and the reference's own values on the golden scene."""
+    H, W = 180, 240
+    rng = np.random.default_rng(21)
+    x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p)
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.reference_exact = exact
+    for prm in ([0., 0.], [30., -20.], [-250., 400.]):
+        for s in (1.0, 0.0, 2.0):
+            fv, gv = obj.evaluate_function_and_gradient(np.array(prm), ev, None, None, None, w, (H, W), s)
+            f1 = obj.evaluate_function(np.array(prm), ev, None, None, None, w, (H, W), s)
+            g1 = obj.evaluate_gradient(np.array(prm), ev, None, None, None, w, (H, W), s)
+            assert abs(float(fv) - float(f1)) <= 2e-6 * abs(float(f1))
+            assert np.max(np.abs(f64(gv) - f64(g1))) <= 2e-6 * np.max(np.abs(f64(g1))) + 1e-12
+    if exact and n == 30_000:
+        g8 = golden("f8_objective")
+        xs, ys, ts, ps = f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"])
+        for i, prm in enumerate(g8["params"]):
+            for j, s in enumerate(g8["sigmas"]):
+                fv, gv = obj.evaluate_function_and_gradient(prm, xs, ys, ts, ps, w, tuple(g8["img_size"]), float(s))
+                assert abs(float(fv) - g8["f"][i, j]) <= TOL * abs(g8["f"][i, j])
+                assert np.max(np.abs(f64(gv) - g8["grad"][i, j])) <= TOL * np.max(np.abs(g8["grad"][i, j])) + 1e-9
 
 
 # ------------------------------------------------------------------------------------------------ windowed voxels
