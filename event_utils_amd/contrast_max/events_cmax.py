@@ -191,28 +191,36 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
         x0 = np.array([0, 0])
     objective.iter_update(x0)
     args = (xs, ys, ts, ps, warp_function, img_size, blur_sigma)
-    if numeric_grads and hasattr(objective, "evaluate_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
-        # same forward differences (epsilon = 1) scipy would take internally, but the three evaluations of one
-        # gradient estimate share a single pass over the events
-        argmax = optimizer(objective.evaluate_function, x0, fprime=objective.evaluate_numeric_gradient, args=args,
-                           disp=False, callback=objective.iter_update)
+    last = {}
+
+    def keep(x, fv, gv):
+        last["x"], last["g"] = np.array(x, dtype=np.float64, copy=True), gv
+        return fv
+
+    def kept(x):
+        return last["g"] if "x" in last and np.array_equal(last["x"], np.asarray(x, dtype=np.float64)) else None
+    if numeric_grads and hasattr(objective, "evaluate_function_and_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
+        # same forward differences (epsilon = 1) scipy would take internally, but f(x), f(x + e1), f(x + e2) share a
+        # single pass over the events, and that pass serves both the f and the f' request of a trial point
+        def f_num(x, *a):
+            return keep(x, *objective.evaluate_function_and_numeric_gradient(x, *a))
+
+        def g_num(x, *a):
+            g = kept(x)
+            return objective.evaluate_numeric_gradient(x, *a) if g is None else g
+        argmax = optimizer(f_num, x0, fprime=g_num, args=args, disp=False, callback=objective.iter_update)
     elif numeric_grads:
         argmax = optimizer(objective.evaluate_function, x0, args=args, epsilon=1, disp=False,
                            callback=objective.iter_update)
     elif hasattr(objective, "evaluate_function_and_gradient") and fused and optimizer is opt.fmin_bfgs:
         # the line search asks for f and f' at the same trial point (phi, then derphi): one pass over the events
         # yields both, the gradient is kept for the call that follows
-        last = {}
-
         def f_and_keep(x, *a):
-            fv, gv = objective.evaluate_function_and_gradient(x, *a)
-            last["x"], last["g"] = np.array(x, dtype=np.float64, copy=True), gv
-            return fv
+            return keep(x, *objective.evaluate_function_and_gradient(x, *a))
 
         def g_from_last(x, *a):
-            if "x" in last and np.array_equal(last["x"], np.asarray(x, dtype=np.float64)):
-                return last["g"]
-            return objective.evaluate_gradient(x, *a)
+            g = kept(x)
+            return objective.evaluate_gradient(x, *a) if g is None else g
         argmax = optimizer(f_and_keep, x0, fprime=g_from_last, args=args, disp=False, callback=objective.iter_update)
     else:
         argmax = optimizer(objective.evaluate_function, x0, fprime=objective.evaluate_gradient, args=args, disp=False,

@@ -302,7 +302,7 @@ class variance_objective(objective_function):
         return ev, float(t_ref), launch
 
     def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
-                                  blur_sigma=None, epsilon=1.0):
+                                  blur_sigma=None, epsilon=1.0, with_value=False):
         """Forward-difference gradient of evaluate_function with absolute step `epsilon` -- exactly what
         scipy.optimize.fmin_bfgs(..., epsilon=1) estimates internally on the reference's default path
         (events_cmax.py:343: x1 = x + eps*e_i, grad_i = (f(x1) - f(x)) / (x1_i - x_i)) -- but f(x), f(x + eps e1),
@@ -327,7 +327,14 @@ class variance_objective(objective_function):
         grad = np.empty(len(x0), dtype=np.float64)
         for i in range(len(x0)):
             grad[i] = (np.float64(fs[i + 1]) - np.float64(fs[0])) / (pts[i + 1][i] - x0[i])
-        return grad
+        return (fs[0], grad) if with_value else grad
+
+    def evaluate_function_and_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None,
+                                               img_size=None, blur_sigma=None, epsilon=1.0):
+        """(evaluate_function(params), evaluate_numeric_gradient(params)): f(x) is one of the three values the
+        forward differences need anyway, so a line-search trial point costs ONE pass over the events."""
+        return self.evaluate_numeric_gradient(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, epsilon,
+                                              with_value=True)
 
     # flows of one three-flow pass may differ by at most this many pixels of displacement over the stream (the LDS
     # windows are shared and grow by the spread)

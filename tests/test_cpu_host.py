@@ -143,6 +143,10 @@ def test_numeric_gradient_formula_equals_scipy_internal_forward_differences(gold
                           disp=False)
     assert np.allclose(a, g_numeric_argmax(golden), atol=1e-9)
     assert np.allclose(a, b, atol=1e-9)
+    # the value that comes with the gradient is f(x) itself (one of the three forward-difference evaluations)
+    x0 = np.array([12.0, -7.0])
+    fv, gv = obj.evaluate_function_and_numeric_gradient(x0, *args)
+    assert fv == obj.evaluate_function(x0, *args) and np.array_equal(gv, obj.evaluate_numeric_gradient(x0, *args))
 
 
 def g_numeric_argmax(golden):

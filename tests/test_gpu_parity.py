@@ -388,8 +388,14 @@ def test_f9_optimize(E, golden, mode):
         trace.append(("g", np.array(prm, float), None, f64(gv)))
         return fv, gv
     obj.evaluate_function_and_gradient = fgrec
-    ng0, ngrads = obj.evaluate_numeric_gradient, []
-    obj.evaluate_numeric_gradient = lambda prm, *a, **k: (ngrads.append((np.array(prm, float), ng0(prm, *a, **k))), ngrads[-1][1])[1]
+    ng0, ngrads = obj.evaluate_function_and_numeric_gradient, []
+
+    def ngrec(prm, *a, **k):        # f(x) and the forward-difference gradient at x from one batched pass
+        fv, gv = ng0(prm, *a, **k)
+        trace.append(("f", np.array(prm, float), float(fv), None))
+        ngrads.append((np.array(prm, float), f64(gv)))
+        return fv, gv
+    obj.evaluate_function_and_numeric_gradient = ngrec
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
