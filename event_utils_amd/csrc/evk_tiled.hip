@@ -882,7 +882,12 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
     static const int variant = getenv("EVK_SCATTER") ? atoi(getenv("EVK_SCATTER")) : -1;  // tuning: 0 plain, 4/8/16
-    const size_t lds_budget = (160 * 1024) / (EVK_BUCKET_BLOCKS / 256) - 256;  // all partition blocks co-resident
+    // all partition blocks co-resident, one per CU.  With EVK_STAGE_SHARE_CU the rings take at most 96 KB so that a
+    // workgroup of ANOTHER kernel (an overlapped RCCL collective) still fits on every CU: a scatter workgroup that
+    // owns all 160 KB cannot start on a CU where such a kernel is resident, and one late workgroup costs the call
+    // +27 % (tools/contention_probe.py); the smaller rings cost +3 % and are insensitive to it.
+    const size_t lds_budget = (stages & EVK_STAGE_SHARE_CU) ? (size_t)96 * 1024
+                                                            : (size_t)(160 * 1024) / (EVK_BUCKET_BLOCKS / 256) - 256;
     int R = 0;
     for (int r : {16, 8, 4})
         if (!R && (size_t)ntiles * (r * 16 + 10) + 8 <= lds_budget) R = r;

@@ -54,6 +54,16 @@ def can_tile(cols, impl, min_events=None):
     return impl == "tiled" or n >= (TILED_MIN_EVENTS if min_events is None else min_events)
 
 
+def share_cu():
+    """Whether the partition kernel should leave LDS for another kernel's workgroups (EVK_STAGE_SHARE_CU): yes when a
+    collective may overlap it, i.e. in a torch.distributed job of more than one rank; EVK_SHARE_CU=0/1 overrides."""
+    env = os.environ.get("EVK_SHARE_CU")
+    if env in ("0", "1"):
+        return env == "1"
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None, native=None):
     """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass).
     native = events.NativeColumns: the same sort reading the on-disk dtypes (evk_bucket_events_native_f32; the four
@@ -73,7 +83,7 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
     nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
     scratch = _buf("bucket", nbytes, dev)
     tail = (key_mode, dom_h, dom_w, tw_log2, th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
-            oob.ptr if oob is not None else None, stages, D.stream())
+            oob.ptr if oob is not None else None, stages | (8 if share_cu() else 0), D.stream())
     if native is None:
         _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, *tail)
     else:

@@ -243,6 +243,8 @@ int evk_bucket_max_items(int ntiles, int64_t n);
 #define EVK_STAGE_SCAN 2    /* prefix sums -> bucket index                                                       */
 #define EVK_STAGE_SCATTER 4 /* write-combining scatter into records (reads x, y, t, p; needs stages 1|2 done)    */
 #define EVK_STAGE_ALL 7
+#define EVK_STAGE_SHARE_CU 8 /* modifier of the scatter stage: keep its LDS rings <= 96 KB so that workgroups of another,
+                                concurrently running kernel (an overlapped RCCL collective) still fit on every CU    */
 
 /* Counting sort of the SoA columns by tile: records = n x (x, y, t, p) float4 (16 B, contiguous per tile, time order
  * preserved across the 256 partition blocks), bucket_index = evk_bucket_index_len(ntiles, n) uint32 (see above).
