@@ -80,3 +80,65 @@ def test_objective_values_are_reproducible_run_to_run():
     fs = {float(obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0)) for _ in range(5)}
     gs = {tuple(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0).tolist()) for _ in range(5)}
     assert len(fs) == 1 and len(gs) == 1
+
+
+@pytest.mark.parametrize("cfg", [("configs[2]", 10_000_000, 480, 640), ("configs[3]", 50_000_000, 720, 1280)])
+def test_full_size_iwe_properties(cfg, monkeypatch):
+    """BASELINE.json's contrast-maximisation sizes, where the oracle would take minutes: size-independent properties.
+    (1) mass: the four bilinear weights of an accepted event sum to 1, so sum(IWE) = sum of the accepted polarities
+    (here: all of them, the flow keeps every event inside), and sum(dIWE) = 0 (a derivative of weights that sum to a
+    constant); (2) additivity: IWE(first half) + IWE(second half) = IWE(all), each half warped to the global reference
+    time (what the multi-GPU all-reduce relies on); (3) the tile-bucketed and the direct global-atomic kernels agree."""
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.objectives import iwe_device
+    _, n, H, W = cfg
+    rng = np.random.default_rng(7)
+    x = rng.uniform(8, W - 8, n).astype(np.float32); y = rng.uniform(8, H - 8, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    prm = np.array([30., -20.])                         # at most 3 px of displacement: nothing leaves the sensor
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    iwe, diwe = iwe_device(prm, ev, (H, W), True, True, (H, W))
+    total = float(p.astype(np.float64).sum())
+    assert abs(iwe.double().sum().item() - total) <= 1e-6 * n ** 0.5 + 1e-3
+    assert abs(diwe[0].double().sum().item()) <= 1e-4 * n ** 0.5 and abs(diwe[1].double().sum().item()) <= 1e-4 * n ** 0.5
+    half = n // 2
+    parts = [iwe_device(prm, ev.slice(a, b), (H, W), True, True, (H, W), t_ref=ev.t_at(-1))
+             for a, b in ((0, half), (half, n))]
+    _close(parts[0][0] + parts[1][0], iwe)
+    _close(parts[0][1] + parts[1][1], diwe)
+    monkeypatch.setenv("EVK_IMPL", "direct")
+    iwe_d, diwe_d = iwe_device(prm, ev, (H, W), True, True, (H, W))
+    _close(iwe, iwe_d)
+    _close(diwe, diwe_d)
+    # the objective of the whole evaluation chain, tiled (one library call) vs direct kernels
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.sensor_size = (H, W)
+    fd, gd = obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0), obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0)
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    ft, gt = obj.evaluate_function_and_gradient(prm, ev, None, None, None, w, (H, W), 1.0)
+    assert abs(float(ft) - float(fd)) <= 1e-5 * abs(float(fd))
+    assert np.max(np.abs(np.asarray(gt, float) - np.asarray(gd, float))) <= 1e-5 * np.max(np.abs(np.asarray(gd, float))) + 1e-9
+
+
+def test_full_size_voxel_per_gpu_share_of_configs4(monkeypatch):
+    """One rank's share of configs[4]: 50 M events, 1280x720, 5 bins.  Mass conservation (the two temporal weights of
+    an event sum to 1: sum(grid) = sum(p)), tiled == direct, and additivity of two half streams voxelised against the
+    GLOBAL time range (the all-reduce identity)."""
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    H, W, B, n = 720, 1280, 5, 50_000_000
+    rng = np.random.default_rng(9)
+    cols = [torch.from_numpy(a).cuda() for a in (rng.integers(0, W, n).astype(np.float32),
+                                                rng.integers(0, H, n).astype(np.float32),
+                                                np.sort(rng.uniform(0, 0.1, n)).astype(np.float32),
+                                                (rng.integers(0, 2, n) * 2 - 1).astype(np.float32))]
+    t0, t1 = cols[2][0].item(), cols[2][-1].item()
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    vt = _voxel_f32_device(*cols, B, (H, W), t0, t1)
+    assert abs(vt.double().sum().item() - cols[3].double().sum().item()) <= 1e-3 * n ** 0.5
+    half = (n // 2) & ~3                                  # keeps the second half's columns 16-byte aligned
+    va = _voxel_f32_device(*(c[:half] for c in cols), B, (H, W), t0, t1)
+    vb = _voxel_f32_device(*(c[half:] for c in cols), B, (H, W), t0, t1)
+    _close(va + vb, vt)
+    monkeypatch.setenv("EVK_IMPL", "direct")
+    _close(vt, _voxel_f32_device(*cols, B, (H, W), t0, t1))
