@@ -34,7 +34,9 @@ def test_random_voxel_tiled_equals_direct(seed):
     cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
     a = _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), impl="tiled")
     b = _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), impl="direct")
-    _close(a, b)
+    # the direct kernel sums in float32 atomics: with 80 % of the events on ONE pixel its own rounding reaches ~1e-5 of
+    # the hot cell (the tiled path accumulates in float64), so the clustered scenes get a wider band
+    _close(a, b, 1e-4 if kind == 1 else 1e-5)
     assert abs(a.double().sum().item() - float(p.astype(np.float64).sum())) <= 1e-4 * max(1.0, np.abs(p).sum())
 
 
