@@ -32,3 +32,28 @@ err = (va + vb - v).abs().max().item() / v.abs().max().item()
 print("additivity of the two halves: rel. err %.2e" % err)
 assert err <= 1e-5
 print("ok")
+
+# ---- the IWE / objective path on the same stream (real-valued coordinates inside the sensor) ----------------------
+import numpy as np  # noqa: E402
+import event_utils_amd as E  # noqa: E402
+from event_utils_amd.contrast_max.objectives import iwe_device  # noqa: E402
+del v, va, vb
+x.add_(0.37).clamp_(4, W - 4)
+y.add_(0.61).clamp_(4, H - 4)
+ev = E.DeviceEvents(x, y, t, p)
+prm = np.array([25.0, -15.0])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+iwe, diwe = iwe_device(prm, ev, (H, W), True, True, (H, W), impl="tiled")
+torch.cuda.synchronize()
+print("IWE + dIWE of %d events: %.1f ms (bucketing included)" % (n, (time.perf_counter() - t0) * 1e3))
+print("mass: sum(iwe) = %.1f, sum(p) = %.1f, sum(diwe) = %.3f %.3f" % (iwe.double().sum().item(), psum,
+                                                                   diwe[0].double().sum().item(), diwe[1].double().sum().item()))
+assert abs(iwe.double().sum().item() - psum) <= 1e-3 * n ** 0.5 + 1.0
+h = (n // 2) & ~3
+a = iwe_device(prm, ev.slice(0, h), (H, W), False, True, (H, W), impl="tiled", t_ref=ev.t_at(-1))[0]
+b = iwe_device(prm, ev.slice(h, n), (H, W), False, True, (H, W), impl="tiled", t_ref=ev.t_at(-1))[0]
+err = (a + b - iwe).abs().max().item() / iwe.abs().max().item()
+print("additivity of the two halves: rel. err %.2e" % err)
+assert err <= 1e-5
+print("ok")
