@@ -122,13 +122,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev0[i].record()
         step(i)
-        ev1[i].record()
     drain()
     torch.cuda.synchronize()
     if use_dist:
@@ -140,7 +136,16 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world / (elapsed / args.steps) / 1e6
-    dev_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    # device-side time per step, outside the timed region (an event pair around every step of the timed loop would
+    # itself cost ~8 us per step): one pair of HIP events around K more steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    e1.record()
+    torch.cuda.synchronize()
+    dev_ms = e0.elapsed_time(e1) / args.steps
 
     # ---- roofline of the dominant kernel(s): HIP-event timing of the voxel call alone (no memset, no collective) ----
     kinfo = tiled.time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=impl, reps=max(5, args.steps))
