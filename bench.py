@@ -421,9 +421,25 @@ def cpu_baseline(x, y, t, p):
         R.events_to_voxel(xi, yi, t64, p64, B, sensor_size=(H, W))
         best.append(time.perf_counter() - t0)
     dt = float(np.median(best))
-    return {"value": round(len(x) / dt / 1e6, 2), "unit": "Mevents/s", "cores": 1, "kind": "port",
-            "sample": "oracle numpy events_to_voxel (reference numpy path), %d events, 640x480x5, median of %d runs, "
-                      "%.2f s each; host has %d logical cores" % (len(x), reps, dt, os.cpu_count())}
+    res = {"value": round(len(x) / dt / 1e6, 2), "unit": "Mevents/s", "cores": 1, "kind": "port",
+           "sample": "oracle numpy events_to_voxel (reference numpy path), %d events, 640x480x5, median of %d runs, "
+                     "%.2f s each; host has %d logical cores" % (len(x), reps, dt, os.cpu_count())}
+    try:    # best-effort CPU: the reference's torch path (B index_put_ passes) with every host thread torch will use
+        from oracle import reference_torch_cpu as T
+        cols = [torch.from_numpy(a) for a in (x, y, t, p)]
+        T.events_to_voxel_torch(*(c[:m] for c in cols), B, sensor_size=(H, W))
+        best = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            T.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+            best.append(time.perf_counter() - t0)
+        dtm = float(np.median(best))
+        res["multithreaded"] = {"value": round(len(x) / dtm / 1e6, 2), "unit": "Mevents/s", "cores": torch.get_num_threads(),
+                                "kind": "port", "sample": "oracle torch-CPU events_to_voxel_torch (reference torch path, "
+                                "index_put_ accumulate), same %d events, median of %d runs, %.2f s each" % (len(x), reps, dtm)}
+    except Exception as e:  # noqa: BLE001
+        res["multithreaded"] = {"error": repr(e)}
+    return res
 
 
 if __name__ == "__main__":

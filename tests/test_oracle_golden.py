@@ -293,3 +293,24 @@ def test_f15_native_dtypes(golden):
     for q, f, gr in zip(g["cmax_params"], g["cmax_f"], g["cmax_g"]):
         assert np.float64(obj.evaluate_function(q, xf, yf, tf, pf, w, ss, blur_sigma=1.0)) == f
         assert np.array_equal(f64(obj.evaluate_gradient(q, xf, yf, tf, pf, w, ss, blur_sigma=1.0)), gr)
+
+
+def test_torch_cpu_restatement_matches_f3(golden):
+    """oracle/reference_torch_cpu.py (the multi-threaded CPU baseline of bench.py) against the reference's own torch
+    output; one thread so that index_put_ accumulates in a fixed order."""
+    import torch
+    from oracle import reference_torch_cpu as T
+    g = golden("f3_voxel_torch")
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for tag, Bs in (("small", (1, 2, 5, 9)), ("dvs", (5,))):
+            cols = [torch.from_numpy(np.asarray(g[tag + k], dtype=np.float32)) for k in ("_xs", "_ys", "_ts", "_ps")]
+            for B in Bs:
+                if B == 1:
+                    continue                      # dt * 0: the reference's NaN grid is covered by the numpy oracle
+                v = T.events_to_voxel_torch(*cols, B, sensor_size=tuple(g[tag + "_sensor_size"]))
+                ref = g["%s_voxel_B%d" % (tag, B)]
+                assert np.max(np.abs(v.numpy() - ref)) <= 1e-6 * np.max(np.abs(ref))
+    finally:
+        torch.set_num_threads(nthreads)
