@@ -289,6 +289,10 @@ def bench_cmax(E, DeviceEvents, dev, impl):
     c3.update(_time_evals(obj, w, ev, np.array([30.0, -20.0]), (H, W)))
     out.update(c3)
     del ev
+    try:    # the same evaluation the way the reference composes it on the CPU, on a bounded sample
+        out["cpu_baseline"] = cmax_cpu_baseline(x, y, t, p)
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline"] = {"error": repr(e)}
     # ---- configs[3]: 50 M events, 1280x720, full optimize() ----
     H4, W4, n4 = 720, 1280, 50_000_000
     x, y, t, p = structured_scene(3, n4, H4, W4)
@@ -404,6 +408,26 @@ def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
         res[name + "_Mevents_per_s"] = round(n5 * world / dt / 1e6, 1)
         if name != "voxel":
             res[name + "_evals_per_s"] = round(1.0 / dt, 2)
+    return res
+
+
+def cmax_cpu_baseline(x, y, t, p, m=2_000_000):
+    """variance objective / gradient the way the reference composes them (numpy warp + mask, torch index_put_ splat,
+    scipy gaussian_filter; oracle/reference_torch_cpu.py, pinned to the golden vectors), all host threads, on the first
+    m events of the configs[2] stream."""
+    from oracle import reference_torch_cpu as T
+    xs, ys, ts, ps = (a[:m].astype(np.float64) for a in (x, y, t, p))
+    prm = np.array([30.0, -20.0])
+    res = {"unit": "Mevents/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "first %d events of the configs[2] stream, 640x480, median of 3 runs" % m}
+    for name, fn in (("f", T.variance_f), ("grad", T.variance_grad)):
+        fn(prm, xs, ys, ts, ps, (H, W), (H, W), 1.0)
+        ts_ = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn(prm, xs, ys, ts, ps, (H, W), (H, W), 1.0)
+            ts_.append(time.perf_counter() - t0)
+        res[name + "_Mevents_per_s"] = round(m / float(np.median(ts_)) / 1e6, 2)
     return res
 
 

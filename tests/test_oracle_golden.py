@@ -314,3 +314,22 @@ def test_torch_cpu_restatement_matches_f3(golden):
                 assert np.max(np.abs(v.numpy() - ref)) <= 1e-6 * np.max(np.abs(ref))
     finally:
         torch.set_num_threads(nthreads)
+
+
+def test_torch_cpu_restatement_of_the_objective_matches_f8(golden):
+    """The CPU baseline of bench.py's contrast-maximisation numbers (numpy warp + torch splat + scipy blur, as the
+    reference composes them) against the reference's own objective values and gradients."""
+    import torch
+    from oracle import reference_torch_cpu as T
+    g = golden("f8_objective")
+    x, y, t, p = (f64(g[k]) for k in ("xs", "ys", "ts", "ps"))
+    size = tuple(int(v) for v in g["img_size"])
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for i, prm in enumerate(g["params"]):
+            for j, s in enumerate(g["sigmas"]):
+                assert np.isclose(T.variance_f(prm, x, y, t, p, size, size, float(s)), g["f"][i, j], rtol=1e-6, atol=0)
+                assert np.allclose(T.variance_grad(prm, x, y, t, p, size, size, float(s)), g["grad"][i, j], rtol=1e-5, atol=1e-9)
+    finally:
+        torch.set_num_threads(nthreads)
