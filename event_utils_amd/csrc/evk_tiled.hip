@@ -451,10 +451,15 @@ __device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, 
     }
 }
 
+// flags: EVK_VOXEL_OVERWRITE; EVK_VOXEL_SPLIT_POLARITY: two grids in one pass, vox = (2, B, h, w): [0] counts the
+// events with p > 0, [1] those with p <= 0, each with weight 1 (events_to_neg_pos_voxel_torch, voxel_grid.py:172-180).
 __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec, uint32_t *__restrict__ index,
                                                            TileGrid g, float t_first, float dt, float bm1, int B,
-                                                           int overwrite, float *__restrict__ vox,
+                                                           int flags, float *__restrict__ vox,
                                                            float *__restrict__ staging) {
+    const int overwrite = flags & EVK_VOXEL_OVERWRITE;
+    const bool split = flags & EVK_VOXEL_SPLIT_POLARITY;
+    const int NB = split ? 2 * B : B;  // accumulator planes
     extern __shared__ __attribute__((aligned(16))) acc_t acc[];
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *item_tile = index + IDX_ITEM(ntiles);
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
     const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     const uint32_t part_id = blockIdx.x - first_item;
     const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
-    for (int i = threadIdx.x; i < B * tpix; i += EVK_BLOCK) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < NB * tpix; i += EVK_BLOCK) acc[i] = 0.0;
     __syncthreads();
     const uint32_t blo = bucket_start[tile], cnt = bucket_start[tile + 1] - blo;
     const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * part_id) / nparts);
@@ -475,13 +480,22 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
         if (yi < 0) yi += g.dom_h;
         const int local = ((yi - ty0) << g.tw_log2) + (xi - tx0);
         const float tn = (r.z - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
-        voxel_bins_lds(acc, tpix, local, B, tn, r.w);
+        if (!split) {
+            voxel_bins_lds(acc, tpix, local, B, tn, r.w);
+        } else if (tn != tn) {  // dt == 0: the reference's 0 * NaN poisons BOTH grids at this pixel
+            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+        } else if (r.w > 0.0f) {
+            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
+        } else if (r.w <= 0.0f) {  // a NaN polarity is in neither grid
+            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+        }
     };
     stream_records(rec, lo, hi, one);
     __syncthreads();
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
     auto flush = [&](auto value_of) {
-        for (int c = threadIdx.x; c < B * tpix; c += EVK_BLOCK) {
+        for (int c = threadIdx.x; c < NB * tpix; c += EVK_BLOCK) {
             const int b = c / tpix, l = c - b * tpix;
             const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
             if (X < g.dom_w && Y < g.dom_h) {
@@ -500,7 +514,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
     // Split (hot) tile: every part stores its partial tile, the LAST part to arrive sums them in part order
     // (deterministic) and writes the output.  Hand-off per cdna_hip_programming.md G16: drained plain stores ->
     // barrier -> one-lane agent release -> counter; last arriver: one-lane agent acquire -> barrier -> plain loads.
-    const int cells = B * tpix;
+    const int cells = NB * tpix;
     float *mine = staging + (int64_t)blockIdx.x * cells;
     for (int c = threadIdx.x; c < cells; c += EVK_BLOCK) mine[c] = (float)acc[c];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -964,19 +978,20 @@ extern "C" int64_t evk_voxel_tiled_staging_bytes(int ntiles, int64_t n, int B, i
 }
 
 extern "C" int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n, int h, int wd, int tw_log2,
-                                   int th_log2, float t_first, float t_last, int B, int overwrite, float *vox,
+                                   int th_log2, float t_first, float t_last, int B, int flags, float *vox,
                                    void *staging, int64_t staging_bytes, void *stream) {
     TileGrid g;
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !records || !bucket_index || !vox || !staging ||
-        n < 0)
+        n < 0 || (flags & ~(EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY)))
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
-    const size_t lds = (size_t)B * sizeof(acc_t) << (tw_log2 + th_log2);
+    const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
+    const size_t lds = (size_t)planes * sizeof(acc_t) << (tw_log2 + th_log2);
     if (lds > 64 * 1024) return EVK_EINVAL;
-    if (staging_bytes < evk_voxel_tiled_staging_bytes(ntiles, n, B, tw_log2, th_log2)) return EVK_ESCRATCH;
+    if (staging_bytes < evk_voxel_tiled_staging_bytes(ntiles, n, planes, tw_log2, th_log2)) return EVK_ESCRATCH;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
     k_voxel_tiled<<<bucket_max_items(n, ntiles), EVK_BLOCK, lds, (hipStream_t)stream>>>(
-        (const float4 *)records, bucket_index, g, t_first, dt, bm1, B, overwrite, vox, (float *)staging);
+        (const float4 *)records, bucket_index, g, t_first, dt, bm1, B, flags, vox, (float *)staging);
     return launch_status();
 }
 

@@ -99,7 +99,20 @@ def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear
 
 
 def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
-    """Separate voxel grids of positive / non-positive events (reference: voxel_grid.py:155-182)."""
+    """Separate voxel grids of positive / non-positive events (reference: voxel_grid.py:155-182).  Above the tiled
+    crossover both grids come from ONE pass over the events (EVK_VOXEL_SPLIT_POLARITY) instead of two voxelisations."""
+    if (temporal_bilinear and all(isinstance(a, torch.Tensor) for a in (xs, ys, ts, ps)) and len(xs)
+            and ts.dtype != torch.float64 and ps.dtype != torch.float64):
+        from .. import tiled
+        dev = D.require_gpu()
+        cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
+        H, W = int(sensor_size[0]), int(sensor_size[1])
+        oob = D.OobCounter(dev)
+        both = tiled.voxel_neg_pos_f32(*cols, float(cols[2][0].item()), float(cols[2][-1].item()), B, H, W, oob)
+        if both is not None:
+            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+            both = both.to(xs.device if device is None else device)
+            return both[0], both[1]
     pos_weights = torch.where(ps > 0, 1.0, 0.0).to(torch.float32)
     neg_weights = torch.where(ps <= 0, 1.0, 0.0).to(torch.float32)
     voxel_pos = events_to_voxel_torch(xs, ys, ts, pos_weights, B, device=device, sensor_size=sensor_size,

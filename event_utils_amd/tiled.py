@@ -108,12 +108,32 @@ def voxel_tile_shape(H, W, B):
     return 3, 3
 
 
-def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh):
-    """evk_voxel_tiled_f32 on bucketed events `bk` (staging for the parts of split hot tiles is persistent scratch)."""
-    nbytes = int(_lib.lib().evk_voxel_tiled_staging_bytes(bk.ntiles, bk.n, B, bk.tw_log2, bk.th_log2))
+def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
+    """evk_voxel_tiled_f32 on bucketed events `bk` (staging for the parts of split hot tiles is persistent scratch).
+    split_polarity: `out` is (2, B, H, W) -- the grids of the positive and of the non-positive events, weight 1 each."""
+    planes = 2 * B if split_polarity else B
+    nbytes = int(_lib.lib().evk_voxel_tiled_staging_bytes(bk.ntiles, bk.n, planes, bk.tw_log2, bk.th_log2))
     staging = _buf("voxel_staging", nbytes, out.device)
     _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, H, W, bk.tw_log2, bk.th_log2,
-              t_first, t_last, B, 1 if fresh else 0, D.ptr(out), D.ptr(staging), nbytes, D.stream())
+              t_first, t_last, B, (1 if fresh else 0) | (2 if split_polarity else 0), D.ptr(out), D.ptr(staging), nbytes,
+              D.stream())
+
+
+def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
+    """events_to_neg_pos_voxel_torch core: (2, B, H, W) float32 = [positive events, non-positive events] from ONE
+    bucketing pass and ONE tile-kernel pass, or None when the tiled path does not apply (the caller then voxelises the
+    two weight columns one after the other, as upstream)."""
+    import torch
+    impl = impl or default_impl()
+    if not (can_tile((xd, yd, td, pd), impl) and 2 * B * 8 * 64 <= 65536):
+        return None
+    tw, th = voxel_tile_shape(H, W, 2 * B)
+    if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:
+        return None
+    out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
+    bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
+    voxel_tiled(bk, t_first, t_last, B, H, W, out, True, split_polarity=True)
+    return out
 
 
 def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None, fresh=False, native=None):

@@ -284,12 +284,17 @@ int evk_native_to_columns_f32(const int16_t *x, const int16_t *y, int xy_stride,
 
 /* events_to_voxel_torch on bucketed records (EVK_KEY_NEAREST over the (h, wd) image; n = the event count that was
  * bucketed): one workgroup per work item, LDS accumulators (B x tile, float64), exclusive plain-store flush: vox += tile,
- * or vox = tile when `overwrite` (the caller then needs no memset: every cell is written).  The parts of a split tile
- * meet in `staging` (evk_voxel_tiled_staging_bytes) and the last one to arrive sums them in part order.
- * Same per-event arithmetic as evk_voxel_f32. */
+ * or vox = tile with EVK_VOXEL_OVERWRITE (the caller then needs no memset: every cell is written).  The parts of a
+ * split tile meet in `staging` (evk_voxel_tiled_staging_bytes) and the last one to arrive sums them in part order.
+ * Same per-event arithmetic as evk_voxel_f32.
+ * EVK_VOXEL_SPLIT_POLARITY: events_to_neg_pos_voxel_torch (voxel_grid.py:155-182) in ONE pass instead of two:
+ * vox = (2, B, h, wd), [0] = grid of the events with p > 0, [1] = of those with p <= 0, each event with weight 1
+ * (2B accumulator planes: pass 2B to evk_voxel_tiled_staging_bytes). */
+#define EVK_VOXEL_OVERWRITE 1
+#define EVK_VOXEL_SPLIT_POLARITY 2
 int64_t evk_voxel_tiled_staging_bytes(int ntiles, int64_t n, int B, int tw_log2, int th_log2);
 int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n, int h, int wd, int tw_log2, int th_log2,
-                        float t_first, float t_last, int B, int overwrite, float *vox, void *staging,
+                        float t_first, float t_last, int B, int flags, float *vox, void *staging,
                         int64_t staging_bytes, void *stream);
 
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):

@@ -263,3 +263,37 @@ def test_optimize_numeric_uses_batched_gradient(E, golden):
     fa = f64(obj.evaluate_function(np.asarray(argmax, float), x, y, t, p, E.linvel_warp(), (180, 240), 1.0))
     fr = f64(obj.evaluate_function(g["numeric_argmax"], x, y, t, p, E.linvel_warp(), (180, 240), 1.0))
     assert fa <= fr + 0.02 * abs(fr)
+
+
+@pytest.mark.parametrize("n,shape", [(400_003, (480, 640, 5)), (70_000, (50, 70, 3)), (2_000_000, (720, 1280, 5))])
+def test_neg_pos_voxel_grids_in_one_pass(E, n, shape):
+    """events_to_neg_pos_voxel_torch (voxel_grid.py:155-182): both grids from one bucketing + one tile-kernel pass
+    (EVK_VOXEL_SPLIT_POLARITY) == the oracle's two voxelisations with where(ps > 0) / where(ps <= 0) weights.
+    Polarities are general reals with zeros (-> negative grid) and a NaN (-> neither grid)."""
+    from event_utils_amd.representations import voxel_grid as V
+    H, W, B = shape
+    x, y, t, _ = _events(n, n, H, W)
+    rng = np.random.default_rng(n)
+    p = rng.normal(size=n).astype(np.float32)
+    p[::7] = 0.0
+    p[5] = np.nan
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    vp, vn = V.events_to_neg_pos_voxel_torch(*cols, B, sensor_size=(H, W))
+    assert vp.shape == vn.shape == (B, H, W) and vp.is_cuda
+    close(vp.cpu().numpy(), R.events_to_voxel_torch(x, y, t, (p > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
+    close(vn.cpu().numpy(), R.events_to_voxel_torch(x, y, t, (p <= 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
+    assert abs(vp.double().sum().item() + vn.double().sum().item() - (n - 1)) <= 1e-3 * n ** 0.5   # every event but the NaN, once
+
+
+def test_neg_pos_voxel_edge_cases(E):
+    from event_utils_amd.representations import voxel_grid as V
+    H, W, B, n = 40, 60, 4, 5000
+    x, y, t, p = _events(2, n, H, W)
+    cols = lambda: [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    t_same = np.full(n, 0.25, np.float32)                         # dt == 0: NaN at every event pixel of BOTH grids (Q9)
+    vp, vn = V.events_to_neg_pos_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t_same, p)), B, sensor_size=(H, W))
+    rp = R.events_to_voxel_torch(x, y, t_same, (p > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
+    assert np.array_equal(np.isnan(vp.cpu().numpy()), np.isnan(rp)) and np.array_equal(np.isnan(vn.cpu().numpy()), np.isnan(rp))
+    x[11] = W + 2.0
+    with pytest.raises(IndexError):
+        V.events_to_neg_pos_voxel_torch(*cols(), B, sensor_size=(H, W))
