@@ -63,6 +63,15 @@ def to_device(a, dtype, device=None):
     return torch.from_numpy(a).to(device, non_blocking=False)
 
 
+def ends(col):
+    """(col[0], col[-1]) of a device column as python floats with ONE device-to-host transfer (each .item() is a
+    synchronisation of its own); a host column is read directly."""
+    if col.is_cuda:
+        a, b = torch.stack((col[0], col[-1])).tolist()
+        return float(a), float(b)
+    return float(col[0]), float(col[-1])
+
+
 def zeros(shape, dtype=torch.float32, device=None):
     return torch.zeros(shape, dtype=dtype, device=device or require_gpu())
 

@@ -131,11 +131,15 @@ class DeviceEvents:
         if polarity == "pm1" and p.dtype != torch.uint8:
             raise TypeError("polarity='pm1' maps uint8 / bool {0, 1} to -1 / +1; int8 columns are used literally")
         p_kind = NativeColumns.P_KINDS["pm1" if polarity == "pm1" else ("i8" if p.dtype == torch.int8 else "u8")]
+        # ts[0], ts[-1]: read from the caller's host array when there is one, else ONE transfer from the device
+        ends = None
+        if n:
+            ends = (float(np.asarray(ts).reshape(-1)[0]), float(np.asarray(ts).reshape(-1)[-1])) \
+                if not isinstance(ts, torch.Tensor) else D.ends(t)
         if t_offset is None:
-            t_offset = float(t[0].item()) if n else 0.0
+            t_offset = ends[0] if n else 0.0
         ev = cls(None, None, None, None, native=NativeColumns(x, y, t, p, stride, t_offset, p_kind))
-        if n:   # ts[0], ts[-1] as the kernels see them, without a host pass over the column
-            ends = (ts[0], ts[-1]) if not isinstance(ts, torch.Tensor) else (t[0].item(), t[-1].item())
+        if n:   # as the kernels see them: (float)(t - t_offset), the subtraction in float64
             ev._t_ends = tuple(float(np.float32(np.float64(e) - t_offset)) for e in ends)
         return ev
 

@@ -244,7 +244,7 @@ def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(18
     img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    t_first, t_last = np.float32(td[0].item()), np.float32(td[-1].item())
+    t_first, t_last = (np.float32(e) for e in D.ends(td))
     tdiv = np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
     mode, ta = (1, t_last) if timestamp_reverse else (0, t_first)
     img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)

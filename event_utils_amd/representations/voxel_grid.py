@@ -68,7 +68,7 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     dev = D.require_gpu()
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    t_first, t_last = float(td[0].item()), float(td[-1].item())
+    t_first, t_last = D.ends(td)
     out = _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last)
     return out.to(device)
 
@@ -108,7 +108,7 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
         cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
         H, W = int(sensor_size[0]), int(sensor_size[1])
         oob = D.OobCounter(dev)
-        both = tiled.voxel_neg_pos_f32(*cols, float(cols[2][0].item()), float(cols[2][-1].item()), B, H, W, oob)
+        both = tiled.voxel_neg_pos_f32(*cols, *D.ends(cols[2]), B, H, W, oob)
         if both is not None:
             oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
             both = both.to(xs.device if device is None else device)
