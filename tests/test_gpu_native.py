@@ -149,3 +149,26 @@ def test_contrast_maximisation_on_native_events(E, golden, monkeypatch, impl):
     iwe, _ = E.get_iwe(g["cmax_params"][1], ev, None, None, None, w, ss)
     xf, yf, tf, pf = f64(g["xs"]), f64(g["ys"]), g["ts"] - g["ts"][0], g["ps"] * 2.0 - 1.0
     close(iwe, R.get_iwe(g["cmax_params"][1], xf, yf, tf, pf, R.linvel_warp(), ss, accum="f64")[0])
+
+
+def test_optimize_on_native_events_equals_optimize_on_float_columns(E, golden):
+    """The whole BFGS driver on events held in their on-disk dtypes: same optimum as on the widened float32 columns."""
+    g8 = golden("f8_objective")
+    # the structured scene of f8, snapped to the int16 pixel grid and stamped with epoch-second float64 times
+    xs = np.rint(f64(g8["xs"])).astype(np.int16); ys = np.rint(f64(g8["ys"])).astype(np.int16)
+    ts = 1.6e9 + f64(g8["ts"]); ps = (f64(g8["ps"]) > 0)
+    size = tuple(int(v) for v in g8["img_size"])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = E.optimize(E.DeviceEvents.from_native(xs, ys, ts, ps), None, None, None, E.linvel_warp(), E.variance_objective(),
+                       numeric_grads=False, img_size=size)
+        cols = R.widen_native_events(xs, ys, ts, ps)
+        b = E.optimize(*cols, E.linvel_warp(), E.variance_objective(), numeric_grads=False, img_size=size)
+    # (snapped to whole pixels the scene is sharpest at zero flow -- every event sits exactly on a pixel -- so the
+    # optimum itself says nothing here; what is pinned is that both representations of the events give the same one)
+    assert np.linalg.norm(np.asarray(a) - np.asarray(b)) < 0.5
+    obj = E.variance_objective()
+    fa = obj.evaluate_function(np.asarray(a), E.DeviceEvents.from_native(xs, ys, ts, ps), None, None, None, E.linvel_warp(), size, 1.0)
+    fb = obj.evaluate_function(np.asarray(a), *cols, E.linvel_warp(), size, 1.0)
+    assert abs(float(fa) - float(fb)) <= TOL * abs(float(fb))
