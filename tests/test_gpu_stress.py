@@ -1,6 +1,8 @@
 """GPU (-m gpu): randomized tiled-vs-direct equivalence (both are HIP paths; the direct one is the simplest possible
 kernel and is itself pinned to the oracle in test_gpu_parity.py) over odd sensor sizes, bin counts, event counts, flows,
 clustered and degenerate inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -144,3 +146,77 @@ def test_full_size_voxel_per_gpu_share_of_configs4(monkeypatch):
     _close(va + vb, vt)
     monkeypatch.setenv("EVK_IMPL", "direct")
     _close(vt, _voxel_f32_device(*cols, B, (H, W), t0, t1))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_event_image_variants_equal_the_oracle(seed):
+    """events_to_image_torch over its whole option space -- nearest / bilinear, padding, clip_out_of_range, default,
+    integer or real coordinates, coordinates beyond the sensor (clipped ones pile up at (0, 0) with their weight, Q8) --
+    and events_to_image (numpy path, meanval / bilinear) against the oracle on random inputs."""
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    rng = np.random.default_rng(4000 + seed)
+    H, W = int(rng.integers(4, 90)), int(rng.integers(4, 120))
+    n = int(rng.choice([1, 33, 5000, 60_000]))
+    interp = [None, "bilinear"][seed % 2]
+    padding = bool((seed >> 1) & 1)
+    clip = bool((seed >> 2) & 1) or interp == "bilinear"          # un-clipped bilinear out-of-range raises upstream
+    default = float(rng.choice([0.0, 0.5]))
+    real = bool((seed >> 3) & 1)
+    hi_x, hi_y = (W + 3, H + 3) if clip else (W - 1, H - 1)        # beyond the sensor only when clipping is on
+    if real:
+        x = rng.uniform(0, hi_x, n).astype(np.float32); y = rng.uniform(0, hi_y, n).astype(np.float32)
+        if not clip:
+            x = np.minimum(x, np.float32(W - 1.001)); y = np.minimum(y, np.float32(H - 1.001))
+    else:
+        x = rng.integers(0, hi_x, n).astype(np.int64); y = rng.integers(0, hi_y, n).astype(np.int64)
+    p = rng.normal(size=n).astype(np.float32)
+    ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), clip_out_of_range=clip, interpolation=interp,
+                                  padding=padding, default=default, accum="f64")
+    got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W),
+                                  clip_out_of_range=clip, interpolation=interp, padding=padding, default=default)
+    assert tuple(got.shape) == ref.shape
+    assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * max(np.max(np.abs(ref)), 1e-30)
+    # numpy entry point: integer coordinates inside the (H+1, W+1) canvas, nearest, with and without meanval
+    xi, yi = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n)
+    pi = rng.integers(-3, 4, n)
+    for meanval in (False, True):
+        a = E.events_to_image(xi, yi, pi, sensor_size=(H, W), meanval=meanval, default=default)
+        b = R.events_to_image(xi, yi, pi, sensor_size=(H, W), meanval=meanval, default=default)
+        assert a.dtype == np.float64 and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_get_iwe_variants_equal_the_oracle(seed):
+    """get_iwe over its option space: polarity on / off, gradient on / off, the hard-wired (181, 241) canvas (Q1) or an
+    explicit sensor_size, img_size different from the canvas, flows that push events out of bounds (Q2, Q3), float64
+    inputs that are not float32-representable (float64 device columns), both kernel families."""
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([40, 3000, 200_000]))
+    sensor = None if seed % 3 == 0 else (int(rng.integers(20, 200)), int(rng.integers(20, 260)))
+    canvas = (180, 240) if sensor is None else sensor
+    img_size = canvas if seed % 2 else (canvas[0] + int(rng.integers(-10, 30)), canvas[1] + int(rng.integers(-10, 30)))
+    x = rng.uniform(-2, canvas[1] + 2, n); y = rng.uniform(-2, canvas[0] + 2, n)
+    t = np.sort(rng.uniform(0, 0.2, n)); p = rng.choice([-1.0, 1.0], n)
+    if seed % 4 != 3:       # float32-representable columns -> float32 device columns; else float64 ones
+        x, y, t = (a.astype(np.float32).astype(np.float64) for a in (x, y, t))
+        t = np.sort(t)
+    prm = rng.uniform(-400, 400, 2)
+    grad, pol = bool((seed >> 1) & 1), bool(seed & 1) or seed % 5 == 0
+    ri, rd = R.get_iwe(prm, x, y, t, p, R.linvel_warp(), img_size, compute_gradient=grad, use_polarity=pol,
+                       sensor_size=sensor, accum="f64")
+    for impl in ("direct", "tiled"):
+        os.environ["EVK_IMPL"] = impl
+        try:
+            iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), img_size, compute_gradient=grad, use_polarity=pol,
+                                  sensor_size=sensor)
+        finally:
+            os.environ.pop("EVK_IMPL", None)
+        assert iwe.shape == ri.shape and iwe.dtype == np.float32
+        assert np.max(np.abs(iwe.astype(np.float64) - ri)) <= 1e-5 * max(np.max(np.abs(ri)), 1e-30), impl
+        if grad:
+            assert np.max(np.abs(diwe.astype(np.float64) - rd)) <= 1e-5 * max(np.max(np.abs(rd)), 1e-30), impl
+        else:
+            assert diwe is None
