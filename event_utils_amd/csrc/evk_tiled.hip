@@ -859,11 +859,13 @@ template <int RR, typename C>
 static void launch_scatter_wc(const C &c, int64_t n, int64_t chunk, const TileGrid &g, int key_mode, int ntiles,
                               const uint32_t *table, const uint32_t *bucket_start, float *records, size_t lds_wc,
                               hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static uint64_t attr_set = 0;  // per device of this process (the attribute is per device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_set >> (dev & 63) & 1)) {
         (void)hipFuncSetAttribute((const void *)k_tile_scatter_wc<RR, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        attr_set = true;
+        attr_set |= (uint64_t)1 << (dev & 63);
     }
     k_tile_scatter_wc<RR, C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds_wc, s>>>(c, n, chunk, g, key_mode, ntiles, table,
                                                                                 bucket_start, (float4 *)records);
