@@ -217,3 +217,45 @@ def test_parameter_space_samplers_host_logic(golden):
                                                 "norm_max", "show"]
     assert names(C.optimize_r2) == names(C.optimize)
     assert names(C.grid_cmax) == ["xs", "ys", "ts", "ps", "roi_size", "step", "warp", "obj", "min_events"]
+
+
+def test_header_is_plain_c_and_the_library_is_usable_from_c(tmp_path):
+    """include/evk.h must compile as C99 on its own (no C++, no HIP, no torch types) and a C program must be able to
+    bind the library through it: the drop-in boundary is a C ABI, not a Python extension."""
+    import shutil
+    import subprocess
+    from event_utils_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_evk.c"
+    src.write_text(r"""
+#include <dlfcn.h>
+#include <stdio.h>
+#include "evk.h"
+int main(int argc, char **argv) {
+    void *h = dlopen(argv[1], RTLD_NOW);
+    if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+    int (*version)(void) = (int (*)(void))dlsym(h, "evk_version");
+    const char *(*errstr)(int) = (const char *(*)(int))dlsym(h, "evk_error_string");
+    int (*ntiles)(int, int, int, int) = (int (*)(int, int, int, int))dlsym(h, "evk_bucket_num_tiles");
+    if (!version || !errstr || !ntiles) return 3;
+    /* the prototypes of the header and the symbols must agree: take the address through the declared type */
+    int (*declared)(int, int, int, int) = evk_bucket_num_tiles; (void)declared;
+    printf("%d|%s|%d\n", version(), errstr(EVK_EINVAL), ntiles(480, 640, 5, 4));
+    return 0;
+}
+""")
+    exe = tmp_path / "use_evk"
+    lib = _lib.lib_path() if hasattr(_lib, "lib_path") else os.path.join(root, "event_utils_amd", "csrc", "libevk.so")
+    inc = os.path.join(root, "include")
+    hdr_only = tmp_path / "hdr.c"
+    hdr_only.write_text('#include "evk.h"\nint evk_header_is_c(void) { return EVK_OK; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(hdr_only), "-o",
+                    str(tmp_path / "hdr.o")], check=True, capture_output=True)
+    # (dlsym's void* -> function pointer conversion is what -pedantic would object to in the program itself)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe), "-ldl",
+           "-Wl,--unresolved-symbols=ignore-all"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    out = subprocess.run([str(exe), lib], check=True, capture_output=True, text=True).stdout.strip().split("|")
+    assert int(out[0]) >= 100 and out[1] and int(out[2]) == 20 * 30
