@@ -571,3 +571,28 @@ def test_f13_dense_flow_warp(E, golden):
     ref = R.events_to_image_torch(xw.cpu().numpy(), yw.cpu().numpy(), np.ones(len(xo), np.float32), sensor_size=(60, 80),
                                   interpolation='bilinear', accum="f64")
     close(img.numpy(), ref)
+
+
+@pytest.mark.parametrize("impl", ["auto", "tiled"])
+def test_f16_windowed_and_split_voxel_functions(E, golden, monkeypatch, impl):
+    """voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch / events_to_voxel_timesync_torch /
+    events_to_neg_pos_voxel[_torch] against what the REAL reference returned for the same stream (f16)."""
+    from event_utils_amd.representations import voxel_grid as V
+    monkeypatch.setenv("EVK_IMPL", impl)
+    g = golden("f16_voxel_windows")
+    ss, B = tuple(int(v) for v in g["sensor_size"]), int(g["B"])
+    x, y, t, p = g["xs"], g["ys"], g["ts"], g["ps"]
+    tx, ty, tt, tp = (torch.from_numpy(a).cuda() for a in (x, y, t, p))
+    for key, n in (("fixed_n", int(g["fixed_n_n"])), ("fixed_n_div", int(g["fixed_n_div_n"]))):
+        got = V.voxel_grids_fixed_n_torch(tx, ty, tt, tp, B, n, sensor_size=ss)
+        assert len(got) == len(g[key])
+        close(torch.stack(got).cpu().numpy(), g[key])
+    got = V.voxel_grids_fixed_t_torch(tx, ty, tt, tp, B, float(g["fixed_t_t"]), sensor_size=ss)
+    assert len(got) == len(g["fixed_t"])
+    close(torch.stack(got).cpu().numpy(), g["fixed_t"])
+    close(V.events_to_voxel_timesync_torch(tx, ty, tt, tp, B, 0.2, 0.5, sensor_size=ss).cpu().numpy(), g["timesync"])
+    vp, vn = V.events_to_neg_pos_voxel_torch(tx, ty, tt, tp, B, sensor_size=ss)
+    close(vp.cpu().numpy(), g["neg_pos_torch_pos"]); close(vn.cpu().numpy(), g["neg_pos_torch_neg"])
+    vp, vn = V.events_to_neg_pos_voxel(x.astype(np.int64), y.astype(np.int64), t.astype(np.float64), p, B, sensor_size=ss)
+    assert vp.dtype == np.float64
+    close(vp, g["neg_pos_numpy_pos"], 1e-12); close(vn, g["neg_pos_numpy_neg"], 1e-12)

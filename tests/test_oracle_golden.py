@@ -333,3 +333,32 @@ def test_torch_cpu_restatement_of_the_objective_matches_f8(golden):
                 assert np.allclose(T.variance_grad(prm, x, y, t, p, size, size, float(s)), g["grad"][i, j], rtol=1e-5, atol=1e-9)
     finally:
         torch.set_num_threads(nthreads)
+
+
+def test_f16_windowed_and_split_voxel_conventions(golden):
+    """The window / split conventions of voxel_grid.py:37-112,155-243 as the reference itself produced them:
+    range(0, len - n, n) windows (the last full one dropped when n divides len), np.arange(t0, t1 - T, T) time windows
+    located with searchsorted, timesync [t0, t1), ps > 0 / ps <= 0 (torch) and truthiness (numpy) splits -- each window
+    being one oracle voxelisation."""
+    g = golden("f16_voxel_windows")
+    x, y, t, p = g["xs"], g["ys"], g["ts"], g["ps"]
+    ss, B = tuple(int(v) for v in g["sensor_size"]), int(g["B"])
+    vox = lambda a, b, w=None: R.events_to_voxel_torch(x[a:b], y[a:b], t[a:b], (p if w is None else w)[a:b], B, sensor_size=ss)
+    for key, n in (("fixed_n", int(g["fixed_n_n"])), ("fixed_n_div", int(g["fixed_n_div_n"]))):
+        starts = list(range(0, len(x) - n, n))
+        assert len(starts) == len(g[key])
+        for k, s in enumerate(starts):
+            assert np.array_equal(vox(s, s + n), g[key][k])
+    T = float(g["fixed_t_t"])
+    t_starts = np.arange(t[0].item(), t[-1].item() - T, T)
+    assert len(t_starts) == len(g["fixed_t"])
+    for k, ts0 in enumerate(t_starts):
+        a, b = np.searchsorted(t, ts0), np.searchsorted(t, ts0 + T)
+        assert np.array_equal(vox(a, b), g["fixed_t"][k])
+    a, b = np.searchsorted(t, 0.2), np.searchsorted(t, 0.5)
+    assert np.array_equal(vox(a, b), g["timesync"])
+    assert np.array_equal(vox(0, len(x), (p > 0).astype(np.float32)), g["neg_pos_torch_pos"])
+    assert np.array_equal(vox(0, len(x), (p <= 0).astype(np.float32)), g["neg_pos_torch_neg"])
+    xi, yi, t64 = x.astype(np.int64), y.astype(np.int64), t.astype(np.float64)
+    assert np.array_equal(R.events_to_voxel(xi, yi, t64, np.where(p, 1, 0), B, sensor_size=ss), g["neg_pos_numpy_pos"])
+    assert np.array_equal(R.events_to_voxel(xi, yi, t64, np.where(p, 0, 1), B, sensor_size=ss), g["neg_pos_numpy_neg"])
