@@ -116,6 +116,11 @@ def main():
                 wk.wait()
                 works[k] = None
 
+    # device wake-up (clocks, first-touch of every buffer, RCCL channel setup), then the W warm-up steps asked for:
+    # with a small W the first timed steps would otherwise still be ramping (0.139 ms per step at K = 5, W = 1)
+    for i in range(30):
+        step(i)
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
