@@ -76,20 +76,92 @@ def zeros(shape, dtype=torch.float32, device=None):
     return torch.zeros(shape, dtype=dtype, device=device or require_gpu())
 
 
+def error_mode():
+    """'strict': a call that dropped out-of-range events raises before it returns (one stream synchronisation per
+    call, the reference's CPU behaviour).  'deferred': calls whose inputs AND outputs stay on the device only enqueue;
+    the exception surfaces at the next event_utils_amd call on that stream or at check_errors() -- the way the
+    reference's own CUDA path reports an out-of-range index_put_ (an asynchronous device-side assert).  Calls that hand
+    their result to the host are always strict (they synchronise anyway).  EVK_ERRORS overrides; default 'deferred'."""
+    import os
+    return os.environ.get("EVK_ERRORS", "deferred")
+
+
+class _ErrorState:
+    """Per (device, stream): ONE cumulative device counter of dropped events (never reset, so no memset per call) and
+    a ring of pinned host slots it is copied to asynchronously."""
+    RING = 64
+
+    def __init__(self, device):
+        from collections import deque
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+        self.seen = 0
+        self.slot = 0
+        self.pending = deque()
+
+    def _raise(self, value, exc_type, msg):
+        n, self.seen = (value - self.seen) & 0xFFFFFFFF, value
+        if n:
+            raise exc_type("%s (%d offending events)" % (msg, n))
+
+    def poll(self, wait=False):
+        while self.pending:
+            ev, k, exc_type, msg = self.pending[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self.pending.popleft()
+            self._raise(int(self.host[k]), exc_type, msg)
+
+    def strict(self, exc_type, msg):
+        self.poll(wait=True)
+        self._raise(int(self.counter.item()), exc_type, msg)      # synchronises; the reference is synchronous too
+
+    def defer(self, exc_type, msg):
+        if len(self.pending) >= self.RING - 1:
+            self.poll(wait=True)
+        k, self.slot = self.slot, (self.slot + 1) % self.RING
+        self.host[k:k + 1].copy_(self.counter, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, k, exc_type, msg))
+
+
+_errors = {}
+
+
+def _error_state(device):
+    key = (device.index, stream_id(device))
+    st = _errors.get(key)
+    if st is None:
+        st = _errors[key] = _ErrorState(device)
+    return st
+
+
+def check_errors():
+    """Synchronise and raise the exception of any earlier deferred call that dropped out-of-range events."""
+    torch.cuda.synchronize()
+    for st in list(_errors.values()):
+        st.poll(wait=True)
+
+
 class OobCounter:
-    """Lazily-checked device counter of events the reference would have rejected with an exception."""
+    """Device counter of events the reference would have rejected with an exception (see error_mode)."""
 
     def __init__(self, device=None):
-        self.t = torch.zeros(1, dtype=torch.int32, device=device or require_gpu())
+        self.state = _error_state(device or require_gpu())
+        self.state.poll()                      # surface what earlier deferred calls on this stream left behind
 
     @property
     def ptr(self):
-        return ptr(self.t)
+        return ptr(self.state.counter)
 
-    def raise_if_set(self, exc_type, msg):
-        n = int(self.t.item())  # synchronises; the reference is synchronous too
-        if n:
-            raise exc_type("%s (%d offending events)" % (msg, n))
+    def raise_if_set(self, exc_type, msg, deferrable=False):
+        if deferrable and error_mode() == "deferred":
+            self.state.defer(exc_type, msg)
+        else:
+            self.state.strict(exc_type, msg)
 
 
 _scratch = {}

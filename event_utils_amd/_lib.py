@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
 EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE = 1, 2, 4
+EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
+EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
 
 P = c_void_p  # every device / host pointer crosses as void*
 
@@ -58,6 +60,10 @@ SIGNATURES = {
                                      P, P, P, c_int64, P, c_int, P],
     "evk_native_to_columns_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, P, P, P, P, P],
     "evk_voxel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, c_int64, P],
+    "evk_voxel2_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, c_int64,
+                       P, P],
+    "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
+                              c_float, c_int, c_int, P, P, P, c_int64, P, P],
     "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, P, c_int64, P, P, P],
 }
@@ -70,6 +76,9 @@ _SPECIAL = {
     "evk_voxel_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
     "evk_bucket_index_len": ([c_int, c_int64], c_int64),
     "evk_bucket_max_items": ([c_int, c_int64], c_int),
+    "evk_voxel2_max_tiles": ([], c_int),
+    "evk_voxel2_index_len": ([c_int, c_int64], c_int64),
+    "evk_voxel2_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
 }
 
 

@@ -1,0 +1,661 @@
+// One-pass partition for the voxel grid (events_to_voxel_torch, voxel_grid.py:114-153).
+//
+// The three-pass counting sort of evk_tiled.hip (histogram -> scan -> scatter) reads every event twice and writes a
+// 16-byte record: 581 MB of traffic for 166 MB of algorithmic bytes at 10 M events (profiles/r01_pmc_traffic.json).
+// Here every partition workgroup sorts SUB-CHUNKS of <= 16 K consecutive events by tile entirely in LDS and writes each
+// sorted sub-chunk back as ONE contiguous, fully coalesced run of 8-byte records, plus one 4-byte (start, count) entry
+// per (tile, sub-chunk) in a tile-major table.  No global histogram, no scan kernels, no look-back: the events are
+// read once (16 B) and written once (8 B).  The tile kernel then walks its table row and pulls its ~100-200 byte
+// segments out of the runs (G lanes x 16 B per segment), accumulating in LDS exactly like k_voxel_tiled.
+//
+// 8-byte record: lo = float32 t (raw bits); hi = [31:11] the top 21 bits of the float32 polarity, [10] "wide" flag,
+// [9:0] pixel inside the tile.  A polarity whose low 11 mantissa bits are zero (+-1, 0, small integers, halves, ...:
+// every polarity the reference's loaders produce) is carried exactly; any other value sets the wide flag and is stored
+// in a side array at the record's index (rare path, 4 extra bytes for that event only), so the result is exact for
+// arbitrary float32 weights.
+//
+// Hot tiles (clustered data): every partition block adds its per-tile counts to global totals; the LAST block to
+// finish (ticket) builds the work-item plan (a tile with more than max(32768, 4n/T) events is split over several
+// workgroups, by sub-chunk range), exactly the plan k_tile_scan_totals builds for the three-pass path.
+#include <cstring>
+
+#include "evk_tiles.h"
+
+namespace evk {
+
+#define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info)
+#define V2_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
+#define V2_TOTALS V2_HDR
+#define V2_PART (V2_HDR + V2_MAX_TILES)            // part_start[T + 1]
+#define V2_COUNTER(T) (V2_PART + (T) + 1)          // counters[T]   (split-tile combine)
+#define V2_ITEM(T) (V2_PART + 2 * (T) + 1)         // item_tile[max_items]
+#define V2_WIDE 0x400u
+// ablation builds (tools/v2_ablate.sh): stop the partition kernel's per-sub-chunk work after stage A (0 loads, 1 ranks,
+// 2 scan + table, 3 placement, 4 = everything) / the tile kernel's after stage B (0 table entries, 1 record loads,
+// 2 decode, 3 = everything).  Results are wrong below the last stage; timing only.
+#ifndef V2_XY_PREFETCH
+#define V2_XY_PREFETCH 1   // load x, y of sub-chunk j + 1 before the placement of j (else at the top of j + 1)
+#endif
+#ifndef V2_ABLATE_A
+#define V2_ABLATE_A 99
+#endif
+#ifndef V2_ABLATE_B
+#define V2_ABLATE_B 99
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release, for which the
+// compiler drains this wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)): a full store round trip at every barrier,
+// and no load can be in flight across it.  Inside these kernels only LDS is shared between the waves of a workgroup.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t *tmp, uint32_t &total) {
+    constexpr int NW = THREADS / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) tmp[wave] = incl;
+    lds_barrier();
+    if (wave == 0) {
+        const uint32_t w = lane < NW ? tmp[lane] : 0u;
+        uint32_t wi = w;
+#pragma unroll
+        for (int off = 1; off < NW; off <<= 1) {
+            const uint32_t v = __shfl_up(wi, off, 64);
+            if (lane >= off) wi += v;
+        }
+        if (lane < NW) tmp[32 + lane] = wi - w;
+        if (lane == NW - 1) tmp[64] = wi;
+    }
+    lds_barrier();
+    total = tmp[64];
+    return tmp[32 + wave] + incl - mine;   // the caller puts a barrier before tmp is used again
+}
+
+// Nearest-pixel key (EVK_KEY_NEAREST of tile_key) that also returns the pixel inside the tile.
+__device__ __forceinline__ int key_local(float x, float y, const TileGrid &g, uint32_t &local) {
+    if (x != x || y != y) return -1;
+    int xi = (int)x, yi = (int)y;
+    if (xi < 0) xi += g.dom_w;
+    if (yi < 0) yi += g.dom_h;
+    if (xi < 0 || xi >= g.dom_w || yi < 0 || yi >= g.dom_h) return -1;
+    const int tw1 = (1 << g.tw_log2) - 1, th1 = (1 << g.th_log2) - 1;
+    local = (uint32_t)(((yi & th1) << g.tw_log2) | (xi & tw1));
+    return (yi >> g.th_log2) * g.tiles_x + (xi >> g.tw_log2);
+}
+
+struct Part2 {
+    int S;          // events per sub-chunk (% 4 == 0, <= THREADS * EPT)
+    int per_block;  // consecutive sub-chunks per partition block
+    int nsc;        // sub-chunks in the stream
+    int nt_pad;     // table row stride: table[sub-chunk][tile]
+    int nblk;
+};
+
+template <int THREADS, int EPT, int BPC, typename C>
+__global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(const C c, int64_t n, TileGrid g, int ntiles, Part2 q,
+                                                            float t_first, float t_last, float bm1, int t_from_events,
+                                                            uint2 *__restrict__ rec, float *__restrict__ pw,
+                                                            uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                            uint32_t cap, uint32_t *oob) {
+    constexpr int NQ = EPT / 4;
+    constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2 *sorted = reinterpret_cast<uint2 *>(smem);                           // [THREADS * EPT] + 2 (trash slot)
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts, then cursors; [ntiles] = dummy
+    uint32_t *tmp = hist + ((ntiles + 4) & ~3);                                 // [65] scan scratch
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int per = (ntiles + THREADS - 1) / THREADS;
+    const int i0 = tid * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
+    uint32_t mytot[PER_MAX];
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) mytot[k] = 0;
+    uint32_t dropped = 0, nwide = 0;
+    if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
+    const float dt = t_last - t_first;
+
+    // Quad k of sub-chunk sc = 4 consecutive events of thread tid, one 16-byte load per column.  A quad that is only
+    // partly inside the stream is loaded whole (the over-read stays inside an aligned block; the extra events are
+    // ignored); a quad entirely outside is not loaded.  There is no scalar tail path: it would put branches -- and the
+    // compiler's waits -- between the loads of one sub-chunk.
+    auto valid_in = [&](int sc, int k) -> int {  // events of quad k inside the stream (<= 0: none)
+        const int64_t lo = (int64_t)sc * q.S;
+        const int64_t hi = (lo + q.S < n) ? lo + q.S : n;
+        return (int)(hi - lo) - 4 * (tid + k * THREADS);
+    };
+    // Software pipeline over the two halves of an event: x, y are needed first (tile key, histogram), t, p only at
+    // placement.  t, p of sub-chunk j are loaded after its keys and land during its histogram + scan; x, y of j + 1 are
+    // loaded before the placement of j and land during its placement + write-out.  (gfx9 counts loads and stores with ONE
+    // counter that is in order only among loads, so a wave with stores in flight cannot wait for a particular load: the
+    // first use of loaded data waits for everything outstanding.  Deeper pipelines -- t, p one sub-chunk ahead as well --
+    // only added register spills: measured 150 us instead of 62.)
+    const int sc0 = blockIdx.x * q.per_block;
+    const int sc_end = (sc0 + q.per_block < q.nsc) ? sc0 + q.per_block : q.nsc;
+    Vec4<float> xv[NQ], yv[NQ], tv[NQ], pv[NQ];
+    auto load_xy = [&](int sc) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int nv = valid_in(sc, k);
+            if (nv > 0) c.xy4n((int64_t)sc * q.S, k * THREADS, (uint32_t)tid, nv, xv[k], yv[k]);
+        }
+    };
+    auto load_tp = [&](int sc) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int nv = valid_in(sc, k);
+            if (nv > 0) c.tp4n((int64_t)sc * q.S, k * THREADS, (uint32_t)tid, nv, tv[k], pv[k]);
+        }
+    };
+    if (sc0 < sc_end) load_xy(sc0);
+    for (int sc = sc0; sc < sc_end; ++sc) {
+        const int64_t lo = (int64_t)sc * q.S;
+        for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;
+        // ---- tile key + pixel in tile of every event
+        uint32_t kl[EPT];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int nv = valid_in(sc, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t local = 0;
+                const int key = e < nv ? key_local(xv[k].v[e], yv[k].v[e], g, local) : -1;
+                kl[4 * k + e] = key >= 0 ? (((uint32_t)key << 10) | local) : 0xFFFFFFFFu;
+                dropped += (key < 0 && e < nv) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < EPT; ++s2) asm volatile("" : "+v"(kl[s2])::"memory");  // keys first, the t, p loads after
+        load_tp(sc);    // land during the histogram and the scan
+        lds_barrier();  // hist is zero
+        // ---- histogram (no-return LDS atomics)
+#pragma unroll
+        for (int s2 = 0; s2 < EPT; ++s2)
+            if (kl[s2] != 0xFFFFFFFFu)
+                __hip_atomic_fetch_add(&hist[kl[s2] >> 10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_barrier();  // histogram complete
+        if (V2_ABLATE_A < 2) {
+            uint32_t sink = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2 >> 2].v[s2 & 3]) ^ __float_as_uint(pv[s2 >> 2].v[s2 & 3]);
+            if (sink == 0x12345u) hist[1] = 1;
+            if (sc + 1 < sc_end) load_xy(sc + 1);
+            continue;
+        }
+        // ---- exclusive scan of the tile counts (thread tid owns tiles [i0, i1)) -> cursors; table row; totals
+        uint32_t mine = 0;
+        for (int i = i0; i < i1; ++i) mine += hist[i];
+        uint32_t kept;
+        uint32_t run = block_excl_scan<THREADS>(mine, tmp, kept);
+        uint32_t *trow = table + (int64_t)sc * q.nt_pad;
+#pragma unroll
+        for (int k = 0; k < PER_MAX; ++k) {
+            const int i = i0 + k;
+            if (k < per && i < i1) {
+                const uint32_t cnt = hist[i];
+                hist[i] = run;
+                trow[i] = run | (cnt << 16);
+                mytot[k] += cnt;
+                run += cnt;
+            }
+        }
+        lds_barrier();  // cursors complete (also frees tmp)
+        // normalised time, in place (t has landed during the histogram and the scan); pinned so that the 4 * NQ divisions
+        // are not interleaved with the placement below (that costs ~70 registers of temporaries)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                tv[k].v[e] = (tv[k].v[e] - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+                asm volatile("" : "+v"(tv[k].v[e]));
+            }
+        if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during placement and write-out
+        if (V2_ABLATE_A < 3) {
+            uint32_t sink = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2 >> 2].v[s2 & 3]) ^ __float_as_uint(pv[s2 >> 2].v[s2 & 3]);
+            if (sink == 0x12345u) hist[1] = 1;
+            lds_barrier();
+            continue;
+        }
+        // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer;
+        //      the 8-byte record = normalised time | polarity | pixel in tile
+        uint32_t wide_mask = 0;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) {
+            if (kl[s] != 0xFFFFFFFFu) {
+                const uint32_t pos = atomicAdd(&hist[kl[s] >> 10], 1u);
+                const float tn = tv[s >> 2].v[s & 3];
+                const uint32_t pbits = __float_as_uint(pv[s >> 2].v[s & 3]);
+                const bool wide = (pbits & 0x7FFu) != 0u;
+                sorted[pos] = make_uint2(__float_as_uint(tn), (wide ? V2_WIDE : (pbits & 0xFFFFF800u)) | (kl[s] & 0x3FFu));
+                if (wide) wide_mask |= 1u << s, kl[s] = pos;   // kl is dead from here on: keep the slot instead
+            }
+        }
+        if (__any(wide_mask != 0u)) {  // rare: exact float32 polarities go to the side array at the record's index
+#pragma unroll
+            for (int s = 0; s < EPT; ++s)
+                if (wide_mask >> s & 1u) pw[lo + kl[s]] = pv[s >> 2].v[s & 3], ++nwide;
+        }
+        lds_barrier();
+        // ---- one contiguous, coalesced run of `kept` records
+        if (V2_ABLATE_A >= 4) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
+            uint4 *dst = reinterpret_cast<uint4 *>(rec + lo);
+            const int n16 = (int)((kept + 1) >> 1);
+            for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
+        }
+        lds_barrier();  // sorted / hist are rewritten by the next sub-chunk
+    }
+    if (dropped && oob) atomicAdd(oob, dropped);
+    // ---- totals -> global; the last block to arrive builds the work-item plan
+    uint32_t *gidx = index;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int i = i0 + k;
+        if (k < per && i < i1 && mytot[k])
+            __hip_atomic_fetch_add(gidx + V2_TOTALS + i, mytot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (nwide) __hip_atomic_fetch_add(gidx + 3, nwide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && tid == 0 && n > 0) {
+        __hip_atomic_store(gidx + 0, __float_as_uint(c.t1(0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gidx + 1, __float_as_uint(c.t1(n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = __hip_atomic_fetch_add(gidx + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == gridDim.x - 1);
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- plan (as k_tile_scan_totals): part_start, per-tile combine counters, item -> tile; totals / ticket back to 0
+    uint32_t *part_start = index + V2_PART, *counters = index + V2_COUNTER(ntiles), *item_tile = index + V2_ITEM(ntiles);
+    uint32_t tot[PER_MAX];
+    uint32_t np = 0;
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int i = i0 + k;
+        tot[k] = 0;
+        if (k < per && i < i1) {
+            tot[k] = __hip_atomic_load(gidx + V2_TOTALS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gidx + V2_TOTALS + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            np += tot[k] > cap ? (tot[k] + cap - 1) / cap : 1u;
+        }
+    }
+    uint32_t total_parts;
+    uint32_t prun = block_excl_scan<THREADS>(np, tmp, total_parts);
+#pragma unroll
+    for (int k = 0; k < PER_MAX; ++k) {
+        const int i = i0 + k;
+        if (k < per && i < i1) {
+            const uint32_t parts = tot[k] > cap ? (tot[k] + cap - 1) / cap : 1u;
+            part_start[i] = prun;
+            counters[i] = 0;
+            for (uint32_t jj = 0; jj < parts; ++jj) item_tile[prun + jj] = (uint32_t)i;
+            prun += parts;
+        }
+    }
+    if (tid == 0) {
+        part_start[ntiles] = total_parts;
+        __hip_atomic_store(gidx + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Voxel tiles from the sorted runs: one workgroup per work item (tile, or part of a hot tile = a range of sub-chunks).
+// A tile's records sit in ~100-200 byte segments, one per sub-chunk.  Every thread fetches the table entry of one
+// sub-chunk; each wave then cuts its 64 segments into 64-byte CHUNKS (8 records, 16-byte aligned), lists the chunks
+// in LDS (wave scan of the chunk counts) and hands them out to groups of 4 lanes, 16 bytes per lane: all lanes stay busy
+// whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 64
+// records (clustered scenes) are streamed by the whole wave instead.
+#define V2_CHUNK_CAP 512  // 64 segments x <= 8 chunks
+template <int WG, int U>
+__global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
+                                                     const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                     TileGrid g, Part2 q, int B, int flags, float *__restrict__ vox,
+                                                     float *__restrict__ staging) {
+    constexpr int NW = WG / 64;
+    const int overwrite = flags & EVK_VOXEL_OVERWRITE;
+    const bool split = flags & EVK_VOXEL_SPLIT_POLARITY;
+    const int NB = split ? 2 * B : B;
+    extern __shared__ __attribute__((aligned(16))) acc_t acc[];
+    __shared__ unsigned short cseg[NW][V2_CHUNK_CAP];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
+    if (blockIdx.x >= part_start[ntiles]) return;
+    const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
+    const int tile = (int)item_tile[blockIdx.x];
+    const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
+    const uint32_t part_id = blockIdx.x - first_item;
+    const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+    for (int i = threadIdx.x; i < NB * tpix; i += WG) acc[i] = 0.0;
+    const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
+    const uint32_t *col = table + tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, grp = lane >> 2;
+    auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
+        const int local = (int)(hi_w & 0x3FFu);
+        const float p = (hi_w & V2_WIDE) ? pw[ridx] : __uint_as_float(hi_w & 0xFFFFF800u);
+        const float tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
+        if (V2_ABLATE_B < 3) {
+            if (tn * p == 1.2345e-30f) acc[local] = 1.0;
+            return;
+        }
+        if (!split) {
+            voxel_bins_lds(acc, tpix, local, B, tn, p);
+        } else if (tn != tn) {
+            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+        } else if (p > 0.0f) {
+            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
+        } else if (p <= 0.0f) {
+            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+        }
+    };
+    auto pair = [&](const uint4 &v, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
+        if (V2_ABLATE_B < 2) {
+            if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345u) acc[1] = 1.0;
+            return;
+        }
+        if (pos >= beg) one(v.x, v.y, pos);
+        if (pos + 1 < end) one(v.z, v.w, pos + 1);
+    };
+    uint32_t ent_next = 0;
+    {
+        const int my = sc_lo + (int)threadIdx.x;
+        if (my < sc_hi) ent_next = col[(int64_t)my * q.nt_pad];
+    }
+    for (int base = sc_lo; base < sc_hi; base += WG) {
+        const uint32_t ent = ent_next;
+        {   // next batch's entries: in flight while this batch is processed
+            const int my = base + WG + (int)threadIdx.x;
+            ent_next = my < sc_hi ? col[(int64_t)my * q.nt_pad] : 0u;
+        }
+        if (V2_ABLATE_B < 1) {
+            if (ent == 0xFFFFFFFFu) acc[0] = 1.0;
+            continue;
+        }
+        const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
+        const uint32_t span = cnt ? (start + cnt) - (start & ~1u) : 0u;  // records from the aligned start
+        const uint32_t nch = (span + 7u) >> 3;
+        const bool is_long = nch > 8u;
+        const uint32_t mych = is_long ? 0u : nch;
+        uint32_t incl = mych;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
+        __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
+        for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = (unsigned short)(lane | (k << 6));
+        __syncthreads();
+        const uint32_t wbase = (uint32_t)(base + wave * 64);  // sub-chunk of lane 0's entry
+        // chunk rounds: U loads per lane in flight, then accumulated (double-buffering them measured slower: 60 vs 46 us)
+        auto issue = [&](uint32_t j0, uint4(&v)[U], uint32_t(&pos)[U], uint32_t(&beg)[U], uint32_t(&end)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = j0 + 16u * u + grp;
+                const uint32_t cs = j < total ? cseg[wave][j] : 0u;
+                const int s = cs & 63u;
+                const uint32_t e2 = __shfl(ent, s, 64);
+                const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
+                const uint32_t rb = (wbase + s) * (uint32_t)q.S;
+                beg[u] = rb + st;
+                end[u] = j < total ? beg[u] + cn : 0u;
+                pos[u] = rb + (st & ~1u) + 8u * (cs >> 6) + 2u * sub;
+                if (pos[u] < end[u]) v[u] = *reinterpret_cast<const uint4 *>(rec + pos[u]);
+            }
+        };
+        auto consume = [&](uint4(&v)[U], uint32_t(&pos)[U], uint32_t(&beg)[U], uint32_t(&end)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (pos[u] < end[u]) pair(v[u], pos[u], beg[u], end[u]);
+        };
+        uint4 va[U];
+        uint32_t pa[U], ba[U], ea[U];
+        for (uint32_t j0 = 0; j0 < total; j0 += 16u * U) {
+            issue(j0, va, pa, ba, ea);
+            consume(va, pa, ba, ea);
+        }
+        // long segments (> 64 records): the whole wave streams each of them, 16 bytes per lane
+        uint64_t m = __ballot(is_long);
+        while (m) {
+            const int s = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t e2 = __shfl(ent, s, 64);
+            const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
+            const uint32_t rb = (wbase + s) * (uint32_t)q.S;
+            const uint32_t b2 = rb + st, e3 = b2 + cn;
+            for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 128u) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(rec + p2);
+                pair(v, p2, b2, e3);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    auto flush = [&](auto value_of) {
+        for (int c = threadIdx.x; c < NB * tpix; c += WG) {
+            const int b = c / tpix, l = c - b * tpix;
+            const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
+            if (X < g.dom_w && Y < g.dom_h) {
+                float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
+                const float v = value_of(c);
+                *o = overwrite ? v : *o + v;
+            }
+        }
+    };
+    if (nparts == 1) {
+        flush([&](int c) { return (float)acc[c]; });
+        return;
+    }
+    // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
+    const int cells = NB * tpix;
+    float *mine = staging + (int64_t)blockIdx.x * cells;
+    for (int c = threadIdx.x; c < cells; c += WG) mine[c] = (float)acc[c];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t *counter = index + V2_COUNTER(ntiles) + tile;
+        const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == nparts - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const float *parts = staging + (int64_t)first_item * cells;
+    flush([&](int c) {
+        float sum = 0.0f;
+        for (uint32_t p = 0; p < nparts; ++p) sum += parts[(int64_t)p * cells + c];
+        return sum;
+    });
+}
+
+// ---- host-side geometry -----------------------------------------------------------------------------------------
+struct V2Config {
+    int threads, ept, blocks_per_cu, wg, u;
+};
+static const V2Config &v2_config() {
+    static V2Config cfg = [] {
+        V2Config c{512, 32, 1, 512, 2};
+        // partition geometries (threads x events per thread, blocks per CU): "1024x16" S = 16 K, 1 block;
+        // "512x32" the same with 8 waves and 256 registers; "1024x8", "512x16", "768x12" S = 8-9 K, 2 blocks per CU
+        const char *geo = getenv("EVK_V2_PART");
+        if (geo && !strcmp(geo, "512x32")) c.threads = 512, c.ept = 32, c.blocks_per_cu = 1;
+        else if (geo && !strcmp(geo, "1024x8")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 2;
+        else if (geo && !strcmp(geo, "512x16")) c.threads = 512, c.ept = 16, c.blocks_per_cu = 2;
+        else if (geo && !strcmp(geo, "768x12")) c.threads = 768, c.ept = 12, c.blocks_per_cu = 2;
+        else if (geo && !strcmp(geo, "1024x16")) c.threads = 1024, c.ept = 16, c.blocks_per_cu = 1;
+        else c.threads = 512, c.ept = 32, c.blocks_per_cu = 1;
+        if (const char *s = getenv("EVK_V2_WG")) c.wg = atoi(s) == 512 ? 512 : (atoi(s) == 1024 ? 1024 : 256);
+        if (const char *s = getenv("EVK_V2_U")) c.u = atoi(s) == 2 ? 2 : (atoi(s) == 8 ? 8 : 4);
+        return c;
+    }();
+    return cfg;
+}
+#define V2_MIN_SUBCHUNK 8192
+
+static Part2 v2_geometry(int64_t n, int ntiles) {
+    const V2Config &c = v2_config();
+    const int64_t smax = (int64_t)c.threads * c.ept;
+    int64_t nblk = (n + V2_MIN_SUBCHUNK - 1) / V2_MIN_SUBCHUNK;
+    const int64_t maxblk = (int64_t)EVK_NUM_CU * c.blocks_per_cu;
+    if (nblk > maxblk) nblk = maxblk;
+    if (nblk < 1) nblk = 1;
+    int64_t per_block = (n + nblk * smax - 1) / (nblk * smax);
+    if (per_block < 1) per_block = 1;
+    int64_t S = (n + nblk * per_block - 1) / (nblk * per_block);
+    S = (S + 3) & ~(int64_t)3;
+    if (S < 4) S = 4;
+    Part2 q;
+    q.S = (int)S, q.per_block = (int)per_block, q.nblk = (int)nblk;
+    q.nsc = (int)((n + S - 1) / S);
+    if (q.nsc < 1) q.nsc = 1;
+    q.nt_pad = (ntiles + 15) & ~15;
+    return q;
+}
+static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
+
+struct V2Layout {
+    int64_t table, rec, pw, staging, total;
+};
+static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
+    const Part2 q = v2_geometry(n, ntiles);
+    const int64_t slots = (int64_t)q.nsc * q.S;
+    V2Layout L;
+    L.table = 0;
+    L.rec = al256((int64_t)q.nsc * q.nt_pad * 4);
+    L.pw = L.rec + al256(slots * 8);
+    L.staging = L.pw + al256(slots * 4);
+    L.total = L.staging + al256((int64_t)bucket_max_items(n, ntiles) * ((int64_t)planes << (tw_log2 + th_log2)) * 4);
+    return L;
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" int64_t evk_voxel2_index_len(int ntiles, int64_t n) {
+    if (ntiles <= 0 || ntiles > V2_MAX_TILES || n < 0) return 0;
+    return (int64_t)V2_ITEM(ntiles) + bucket_max_items(n, ntiles);
+}
+
+extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
+    if (ntiles <= 0 || n < 0 || planes <= 0) return 0;
+    return v2_layout(ntiles, n, planes, tw_log2, th_log2).total;
+}
+
+// largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
+extern "C" int evk_voxel2_max_tiles(void) {
+    const V2Config &c = v2_config();
+    const int64_t budget = (int64_t)160 * 1024 / c.blocks_per_cu - (int64_t)c.threads * c.ept * 8 - 1024;
+    const int64_t t = budget / 4;
+    return (int)(t < V2_MAX_TILES ? (t > 0 ? t : 0) : V2_MAX_TILES);
+}
+
+template <int THREADS, int EPT, int BPC, typename C>
+static void launch_part(const C &c, int64_t n, const TileGrid &g, int ntiles, const Part2 &q, float t_first, float t_last,
+                        float bm1, int t_from_events, uint2 *rec, float *pw, uint32_t *table, uint32_t *index,
+                        uint32_t *oob, hipStream_t s) {
+    const size_t lds = (size_t)THREADS * EPT * 8 + 16 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
+    static uint64_t attr_set = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_set >> (dev & 63) & 1)) {
+        // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
+        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, BPC, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set |= (uint64_t)1 << (dev & 63);
+    }
+    k_part_sorted<THREADS, EPT, BPC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
+                                                                    rec, pw, table, index, (uint32_t)bucket_cap(n, ntiles), oob);
+}
+
+template <typename C>
+static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first, float t_last, int B,
+                  int flags, float *vox, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                  void *stream) {
+    TileGrid g;
+    const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
+                      EVK_VOXEL2_TILES_ONLY;
+    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
+        n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > 10)
+        return EVK_EINVAL;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
+    const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
+    const size_t lds_acc = (size_t)planes * sizeof(acc_t) << (tw_log2 + th_log2);
+    if (lds_acc > 64 * 1024) return EVK_EINVAL;
+    const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2);
+    if (scratch_bytes < L.total) return EVK_ESCRATCH;
+    if (!aligned16(scratch)) return EVK_EALIGN;
+    const Part2 q = v2_geometry(n, ntiles);
+    char *sb = (char *)scratch;
+    uint32_t *table = (uint32_t *)(sb + L.table);
+    uint2 *rec = (uint2 *)(sb + L.rec);
+    float *pw = (float *)(sb + L.pw);
+    float *staging = (float *)(sb + L.staging);
+    hipStream_t s = (hipStream_t)stream;
+    const V2Config &cfg = v2_config();
+    const float bm1 = (float)(B - 1);
+    const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
+        if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else if (cfg.threads == 768) launch_part<768, 12, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else launch_part<1024, 16, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+    }
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
+        const int items = bucket_max_items(n, ntiles);
+        const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY);
+#define V2_LAUNCH(WG, U)                                                                                           \
+    k_voxel_tiles2<WG, U><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging)
+#define V2_LAUNCH_U(WG)                    \
+    do {                                   \
+        if (cfg.u == 2) V2_LAUNCH(WG, 2);  \
+        else if (cfg.u == 8) V2_LAUNCH(WG, 8); \
+        else V2_LAUNCH(WG, 4);             \
+    } while (0)
+        if (cfg.wg == 1024) V2_LAUNCH_U(1024);
+        else if (cfg.wg == 256) V2_LAUNCH_U(256);
+        else V2_LAUNCH_U(512);
+#undef V2_LAUNCH_U
+#undef V2_LAUNCH
+    }
+    return launch_status();
+}
+
+extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
+                              int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                              uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, void *stream) {
+    if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    const ColsF32 c{x, y, t, p};
+    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, stream);
+}
+
+extern "C" int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
+                                     double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2,
+                                     int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                                     uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                     void *stream) {
+    ColsNative c;
+    const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
+    if (rc != EVK_OK) return rc;
+    if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, stream);
+}

@@ -11,10 +11,12 @@ from .. import _lib
 
 
 def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None, check=True, impl=None, fresh=None,
-                      native=None):
+                      native=None, deferrable=False):
     """Device-resident core of events_to_voxel_torch.  out=None: a new (B, H, W) float32 grid is returned; else the
     events are accumulated into `out` (fresh=True: `out` is overwritten instead, no memset needed).
-    native = events.NativeColumns replaces the four float32 columns (on-disk dtypes, widened in the kernels)."""
+    native = events.NativeColumns replaces the four float32 columns (on-disk dtypes, widened in the kernels).
+    t_first = None: ts[0] / ts[-1] are taken from the column on the device (no transfer before the launch).
+    deferrable: the out-of-range check may be reported asynchronously (_device.error_mode)."""
     dev = xd.device if native is None else native.t.device
     H, W = int(sensor_size[0]), int(sensor_size[1])
     if out is None:
@@ -22,10 +24,10 @@ def _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last, out=None,
         fresh = True
     oob = D.OobCounter(dev) if check else None
     from .. import tiled
-    tiled.voxel_f32(xd, yd, td, pd, float(t_first), float(t_last), B, H, W, out, oob, impl=impl, fresh=bool(fresh),
-                    native=native)
+    tiled.voxel_f32(xd, yd, td, pd, None if t_first is None else float(t_first), None if t_first is None else float(t_last),
+                    B, H, W, out, oob, impl=impl, fresh=bool(fresh), native=native)
     if check:
-        oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+        oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),), deferrable)
     return out
 
 
@@ -68,8 +70,11 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     dev = D.require_gpu()
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    t_first, t_last = D.ends(td)
-    out = _voxel_f32_device(xd, yd, td, pd, B, sensor_size, t_first, t_last)
+    if len(xs) == 0:
+        raise IndexError("index -1 is out of bounds for dimension 0 with size 0")   # ts[-1], voxel_grid.py:133
+    # ts[0] / ts[-1] are read by the kernels themselves; events and grid that stay on the device never wait for the host
+    resident = xs.is_cuda and torch.device(device).type == "cuda"
+    out = _voxel_f32_device(xd, yd, td, pd, B, sensor_size, None, None, deferrable=resident)
     return out.to(device)
 
 

@@ -33,6 +33,21 @@ def _buf(key, nbytes, device):
     return b
 
 
+_zpersist = {}
+
+
+def _zbuf(key, nwords, device):
+    """Grow-only persistent uint32 scratch that is ZERO when handed out for the first time (the one-pass voxel path keeps
+    self-resetting counters in it: evk.h, evk_voxel2_f32)."""
+    import torch
+    k = (key, device.index, D.stream_id(device))
+    b = _zpersist.get(k)
+    if b is None or b.numel() < nwords:
+        b = torch.zeros(max(int(nwords), 1), dtype=torch.int32, device=device)
+        _zpersist[k] = b
+    return b
+
+
 class Buckets:
     """Events partitioned by tile: `records` (n_kept, 4) float32 (x, y, t, p), `bucket_start` (ntiles+1) offsets."""
 
@@ -119,6 +134,48 @@ def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
               D.stream())
 
 
+def voxel_path():
+    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip)."""
+    return os.environ.get("EVK_VOXEL_PATH", "v2")
+
+
+def voxel2_shape(H, W, planes):
+    """Tile shape for the one-pass voxel path, or None when it does not apply (more tiles than the partition kernel's
+    LDS holds, accumulators beyond 64 KB)."""
+    L = _lib.lib()
+    tw, th = voxel_tile_shape(H, W, planes)
+    for a, b in ((tw, th), (5, 5)):
+        if a + b <= 10 and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= L.evk_voxel2_max_tiles() and planes * 8 << (a + b) <= 65536:
+            return a, b
+    return None
+
+
+def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
+    """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
+    ts[-1] are read on the device (no transfer before the launch)."""
+    L = _lib.lib()
+    dev = out.device
+    planes = 2 * B if split_polarity else B
+    ntiles = L.evk_bucket_num_tiles(H, W, tw, th)
+    key = (ntiles, n, planes, tw, th)
+    sizes = _staging_bytes.get(("v2",) + key)
+    if sizes is None:
+        sizes = _staging_bytes[("v2",) + key] = (int(L.evk_voxel2_index_len(ntiles, n)),
+                                                 int(L.evk_voxel2_scratch_bytes(ntiles, n, planes, tw, th)))
+    index = _zbuf("voxel2_index", sizes[0], dev)
+    scratch = _buf("voxel2_scratch", sizes[1], dev)
+    flags = (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | (_lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0) | stage
+    if t_first is None:
+        flags |= _lib.EVK_VOXEL_T_FROM_EVENTS
+        t_first = t_last = 0.0
+    tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
+            oob.ptr if oob is not None else None, D.stream())
+    if native is None:
+        _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, *tail)
+    else:
+        _lib.call("evk_voxel2_native_f32", *native.head(), *tail)
+
+
 def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
     """events_to_neg_pos_voxel_torch core: (2, B, H, W) float32 = [positive events, non-positive events] from ONE
     bucketing pass and ONE tile-kernel pass, or None when the tiled path does not apply (the caller then voxelises the
@@ -127,10 +184,14 @@ def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=N
     impl = impl or default_impl()
     if not (can_tile((xd, yd, td, pd), impl) and 2 * B * 8 * 64 <= 65536):
         return None
+    out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
+    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() == "v2" else None
+    if shape2 is not None:
+        voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
+        return out
     tw, th = voxel_tile_shape(H, W, 2 * B)
     if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:
         return None
-    out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
     bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
     voxel_tiled(bk, t_first, t_last, B, H, W, out, True, split_polarity=True)
     return out
@@ -146,6 +207,14 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
     else:
         tileable = can_tile((xd, yd, td, pd), impl)
+    if tileable and voxel_path() == "v2":
+        shape2 = voxel2_shape(H, W, B)
+        if shape2 is not None:
+            voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
+                   out, oob, fresh)
+            return out
+    if t_first is None:          # the other kernels take ts[0] / ts[-1] as host scalars
+        t_first, t_last = D.ends(td) if native is None else (None, None)
     if tileable and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:     # sensors beyond 8192 tiles: enlarge the tiles
@@ -321,9 +390,18 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
         ms = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="direct"), reps)
         return {"impl": "direct", "dominant": "k_voxel_f32", "dominant_ms": ms, "total_ms": ms,
                 "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
-    tw, th = voxel_tile_shape(H, W, B)
     total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True),
                      reps)
+    shape2 = voxel2_shape(H, W, B) if voxel_path() == "v2" else None
+    if shape2 is not None:
+        n = xd.shape[0]
+        run2 = lambda stage: voxel2((xd, yd, td, pd), None, n, t_first, t_last, B, H, W, *shape2, out, None, True, stage=stage)
+        ms = {"k_part_sorted": _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
+              "k_voxel_tiles2": _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
+        dom = max(ms, key=ms.get)
+        return {"impl": "one-pass partition, tiles %dx%d" % (1 << shape2[0], 1 << shape2[1]), "dominant": dom,
+                "dominant_ms": ms[dom], "total_ms": total, "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}
+    tw, th = voxel_tile_shape(H, W, B)
     bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)
     ms = {}
     run = lambda st: bucket_events(xd, yd, td, pd, 0, H, W, tw, th, stages=st, into=bk)

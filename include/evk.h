@@ -297,6 +297,36 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
                         float t_first, float t_last, int B, int flags, float *vox, void *staging,
                         int64_t staging_bytes, void *stream);
 
+/* ---- one-pass voxel path (evk_voxel2.hip; DESIGN.md section 3, K1') ---------------------------------------------
+ * events_to_voxel_torch (voxel_grid.py:114-153) straight from the event columns in TWO launches: a partition kernel
+ * that sorts sub-chunks of <= 16 K events by tile in LDS and writes them back as contiguous runs of 8-byte records
+ * (float32 t | 21-bit polarity | pixel in tile; polarities that need more bits go, exactly, to a side array) with a
+ * (tile, sub-chunk) table, and a tile kernel that pulls every tile's segments and accumulates in LDS (float64) --
+ * the events are read once and written once (24 B/event + the grid instead of 56).  Same per-event arithmetic and
+ * results as evk_voxel_f32 / evk_voxel_tiled_f32.
+ *   index    evk_voxel2_index_len(ntiles, n) uint32, ZEROED ONCE by the caller when it is allocated; the library
+ *            leaves its counters at zero after every call (persistent across calls on one stream)
+ *   scratch  evk_voxel2_scratch_bytes(...) bytes, 16-byte aligned, uninitialised
+ *   flags    EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY as evk_voxel_tiled_f32;
+ *            EVK_VOXEL_T_FROM_EVENTS: t_first / t_last are read on the device from t[0] / t[n-1] (voxel_grid.py:133-134
+ *            takes them from the same column), so the caller needs no device-to-host transfer before the launch;
+ *            EVK_VOXEL2_PARTITION_ONLY / EVK_VOXEL2_TILES_ONLY: launch one of the two kernels (timing).
+ * Tiles: 2^tw_log2 x 2^th_log2 <= 1024 pixels, at most evk_voxel2_max_tiles() of them. */
+#define EVK_VOXEL_T_FROM_EVENTS 4
+#define EVK_VOXEL2_PARTITION_ONLY 16
+#define EVK_VOXEL2_TILES_ONLY 32
+int evk_voxel2_max_tiles(void);
+int64_t evk_voxel2_index_len(int ntiles, int64_t n);
+int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2);
+int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
+                   int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                   uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, void *stream);
+/* the same from the reference's on-disk dtypes (see evk_bucket_events_native_f32) */
+int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind, double t_offset,
+                          const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first,
+                          float t_last, int B, int flags, float *vox, uint32_t *index, void *scratch,
+                          int64_t scratch_bytes, uint32_t *oob, void *stream);
+
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
  * one workgroup per (work item, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted
  * by the slice's displacement), stores it to `staging`; a gather kernel adds the windows covering each canvas pixel to
