@@ -2,15 +2,18 @@
 """
 bench.py -- headline benchmark (BASELINE.json): Mevents/s of events_to_voxel_torch, 5 temporal bins, 640x480, 10 M
 synthetic events per GPU resident in HBM (configs[1]); plus contrast-maximisation evaluations/s (configs[2] shape) in
-the `cmax` object.
+the `cmax` object, one GPU's share of configs[4] (`c5_share`: 50 M events, 1280x720, beyond the Infinity Cache) and the
+reference's CPU paths timed on this host (`cpu_baseline`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank voxelises ITS shard of the stream
-(weak scaling: 10 M events per rank, disjoint time-sorted slices of one N*10 M stream) and the (B, H, W) grids are
-all-reduced (the path's only exchange step).  value = events of all ranks / max-over-ranks time.
-
-A "step" = one full voxelisation of the resident events (everything the product does for one call, including any
-bucketing pre-pass and the output memset; excluding only the host<->device copies of the events).
+N = 1: a "step" is ONE call of the public drop-in signature events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=...) on
+device tensors -- grid allocation, ts[0] / ts[-1], the out-of-range check and every kernel of the call included; only
+the host<->device copies of the events are excluded.  `internal_step_ms` times the same kernels through the internal
+entry point (resident grid, no check) beside it.
+N > 1: `python bench.py --gpus N` re-launches itself under torch.distributed.run (one rank per GPU, RCCL; the driver's
+own torchrun command line works as well).  Every rank voxelises ITS shard of the stream (weak scaling: 10 M events per
+rank, disjoint time-sorted slices of one N*10 M stream) and the (B, H, W) grids are all-reduced (the path's only
+exchange step); value = events of all ranks / max-over-ranks time; the reduced grid is checked (`checked`).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -43,6 +46,19 @@ def synth(seed, n, t_lo, t_hi, real_xy=False):
     return x, y, t, p
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: re-exec under it (one rank per GPU, RCCL),
+    forwarding every argument.  On a box with fewer than N GPUs rank >= n_visible fails loudly at set_device."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,20 +69,28 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-cmax", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)          # fails loudly when this rank has no GPU
     dev = torch.device("cuda", local_rank)
     dist = None
-    # EVK_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1) drives the N > 1 code path -- process group, async
-    # all-reduce, barriers -- on a single GPU: a smoke test of the scaling harness where only one GPU is available
+    # EVK_BENCH_FORCE_DIST=1 (with --gpus 1) drives the N > 1 code path -- process group, async all-reduce, barriers,
+    # the self-check -- on a single GPU: a smoke test of the scaling harness where only one GPU is available
     use_dist = world > 1 or os.environ.get("EVK_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     import event_utils_amd as E
     from event_utils_amd import tiled
@@ -78,7 +102,6 @@ def main():
     span = 0.1 / world
     x, y, t, p = synth(1 + rank, n, rank * span, (rank + 1) * span)
     xd, yd, td, pd = (torch.from_numpy(a).to(dev) for a in (x, y, t, p))
-    t_first, t_last = 0.0, 0.1
     if use_dist:   # global ts[0] / ts[-1]: two scalars, agreed once outside the timed region
         lo = torch.tensor([float(t[0])], device=dev)
         hi = torch.tensor([float(t[-1])], device=dev)
@@ -96,19 +119,30 @@ def main():
     works = [None] * len(outs)
     out = outs[0]
 
-    def step(i):
-        # one complete voxelisation: bucketing + tile kernel (which writes every cell: no memset) on the tiled path,
-        # memset + global-atomic kernel on the direct path; then the grid is summed over the ranks
+    def step_sharded(i):
+        # one complete voxelisation of this rank's shard into a resident grid (global ts[0] / ts[-1] agreed once), then
+        # the grid is summed over the ranks: the path's only exchange step
         k = i % len(outs)
         if works[k] is not None:
             works[k].wait()          # stream-level: this buffer's previous all-reduce has finished
             works[k] = None
         _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=outs[k], check=False, impl=impl, fresh=True)
-        if use_dist:
-            if overlap:
-                works[k] = dist.all_reduce(outs[k], op=dist.ReduceOp.SUM, async_op=True)
-            else:
-                dist.all_reduce(outs[k], op=dist.ReduceOp.SUM)
+        if overlap:
+            works[k] = dist.all_reduce(outs[k], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            dist.all_reduce(outs[k], op=dist.ReduceOp.SUM)
+
+    keep = [None]
+
+    def step_public(i):
+        # N = 1: the reference's own call on device tensors -- events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=...)
+        # (voxel_grid.py:114): allocates the grid, reads ts[0] / ts[-1] on the device, counts out-of-range events
+        keep[0] = E.events_to_voxel_torch(xd, yd, td, pd, B, sensor_size=(H, W))
+
+    def step_internal(i):
+        _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True)
+
+    step = step_sharded if use_dist else step_public
 
     def drain():
         for k, wk in enumerate(works):
@@ -116,29 +150,34 @@ def main():
                 wk.wait()
                 works[k] = None
 
-    # device wake-up (clocks, first-touch of every buffer, RCCL channel setup), then the W warm-up steps asked for:
-    # with a small W the first timed steps would otherwise still be ramping (0.139 ms per step at K = 5, W = 1)
-    for i in range(30):
-        step(i)
-    drain()
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(fn, steps, warm):
+        # device wake-up (clocks, first-touch of every buffer, RCCL channel setup), then the W warm-up steps asked for:
+        # with a small W the first timed steps would otherwise still be ramping
+        for i in range(30):
+            fn(i)
+        drain()
+        for i in range(warm):
+            fn(i)
+        drain()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        drain()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    elapsed = timed(step, args.steps, args.warmup)
+    E.check_errors()                     # deferred out-of-range reports of the timed calls (none expected)
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world / (elapsed / args.steps) / 1e6
     # device-side time per step, outside the timed region (an event pair around every step of the timed loop would
@@ -155,16 +194,7 @@ def main():
     # ---- roofline of the dominant kernel(s): HIP-event timing of the voxel call alone (no memset, no collective) ----
     kinfo = tiled.time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=impl, reps=max(5, args.steps))
     alg_bytes = 16.0 * n + out.numel() * 4.0
-    dom_ms = kinfo["dominant_ms"]
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(kinfo["dominant"], n)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kinfo["dominant"],
-                "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": alg_bytes,
-                "whole_call_ms": round(kinfo["total_ms"], 4),
-                "whole_call_frac": round(alg_bytes / (kinfo["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "kernels_ms": kinfo["kernels_ms"]}
+    roofline = roofline_block(kinfo, alg_bytes, n, "c2")
 
     result = {
         "metric": "Mevents/s (voxel 5-bin 640x480)", "value": round(value, 1), "unit": "Mevents/s",
@@ -173,12 +203,30 @@ def main():
         "config": {"workload": "configs[1]: 10M events/GPU, 640x480, events_to_voxel_torch 5 temporal bins "
                                "(temporal-bilinear, nearest pixel), uniform-random events, columns resident in HBM",
                    "events_per_gpu": n, "sensor": [H, W], "bins": B, "impl": kinfo["impl"],
+                   "timed_call": ("_voxel_f32_device on this rank's shard (global ts[0]/ts[-1] agreed once, resident "
+                                  "output grids) + all_reduce(SUM) of the grid" if use_dist else
+                                  "the public events_to_voxel_torch(xs, ys, ts, ps, B, sensor_size=(480, 640)) on device "
+                                  "tensors: allocates the grid, reads ts[0]/ts[-1] on the device, counts out-of-range "
+                                  "events (EVK_ERRORS=%s)" % E.error_mode()),
                    "parallelism": ("event-sharded x%d, RCCL all-reduce of the (B,H,W) grid per step%s"
                                    % (world, ", overlapped with the next step's kernels" if overlap else ""))
                    if use_dist else "single GPU"},
         "device_ms_per_step": round(dev_ms, 4),
         "roofline": roofline,
     }
+    if use_dist:
+        result["rccl_ranks"] = dist.get_world_size()
+        result.update(check_sharded(dist, dev, out if not overlap else outs[(args.steps - 1) % 2], pd, n, world))
+    else:
+        # the same work through the internal entry point (resident output, host-supplied ts[0]/ts[-1], no out-of-range
+        # check) and through the public call with per-call synchronous error reporting
+        el_int = timed(step_internal, args.steps, args.warmup)
+        os.environ["EVK_ERRORS"] = "strict"
+        el_strict = timed(step_public, args.steps, args.warmup)
+        os.environ.pop("EVK_ERRORS")
+        result["public_api_ms"] = round(ms_per_step, 4)
+        result["internal_step_ms"] = round(el_int / args.steps * 1e3, 4)
+        result["public_api_strict_errors_ms"] = round(el_strict / args.steps * 1e3, 4)
 
     if use_dist and not args.no_cmax:
         try:   # extra information only: it must never cost the scaling run its JSON line
@@ -186,17 +234,78 @@ def main():
         except Exception as e:  # noqa: BLE001
             c5 = {"error": repr(e)}
         result["c5"] = c5
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not use_dist:
+        try:
+            result["c5_share"] = bench_c5_share(tiled, dev, impl)
+        except Exception as e:  # noqa: BLE001
+            result["c5_share"] = {"error": repr(e)}
         result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
                                                max(5, args.steps))
-    if rank == 0 and world == 1 and not args.no_cmax:
+    if rank == 0 and world == 1 and not use_dist and not args.no_cmax:
         result["cmax"] = bench_cmax(E, DeviceEvents, dev, impl)
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not use_dist and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(x, y, t, p)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def roofline_block(kinfo, alg_bytes, n, tag):
+    dom_ms = kinfo["dominant_ms"]
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src, call_traffic = pmc_traffic(kinfo["dominant"], tag)
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "kernel": kinfo["dominant"],
+         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes": alg_bytes,
+         "whole_call_ms": round(kinfo["total_ms"], 4),
+         "whole_call_frac": round(alg_bytes / (kinfo["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "kernels_ms": kinfo["kernels_ms"]}
+    if call_traffic:
+        r["whole_call_traffic"] = call_traffic
+    return r
+
+
+def check_sharded(dist, dev, grid, pd, n, world):
+    """Self-check of the N > 1 line: (a) every event puts its polarity, split over two bins, into the grid, so the
+    reduced grid must sum to the polarity sum of ALL ranks' events; (b) every rank must hold the same reduced grid."""
+    torch.cuda.synchronize()
+    psum = pd.double().sum().reshape(1)
+    dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+    gsum = float(grid.double().sum().item())
+    w = torch.arange(grid.numel(), device=dev, dtype=torch.float64).reshape(grid.shape) % 251.0
+    cs = (grid.double() * w).sum().reshape(1)
+    cmin, cmax = cs.clone(), cs.clone()
+    dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    tol = 1e-3 * float(np.sqrt(n * world))
+    ok = abs(gsum - float(psum.item())) <= tol and float(cmin.item()) == float(cmax.item())
+    if not ok:
+        raise SystemExit("sharded voxel grid failed its self-check: grid sum %r vs polarity sum %r (tol %g), checksum "
+                         "min %r max %r over ranks" % (gsum, float(psum.item()), tol, float(cmin.item()), float(cmax.item())))
+    return {"checked": True, "check": {"grid_sum": gsum, "polarity_sum_all_ranks": float(psum.item()), "tolerance": tol,
+                                        "grid_checksum_identical_on_all_ranks": True}}
+
+
+def bench_c5_share(tiled, dev, impl):
+    """One GPU's share of configs[4]: 50 M events, 1280x720, 5 bins -- 800 MB of columns, beyond the 256 MB Infinity
+    Cache, i.e. the HBM-resident size of the voxel call (the 10 M-event headline re-reads 160 MB that stay in the MALL)."""
+    H5, W5, n5 = 720, 1280, 50_000_000
+    rng = np.random.default_rng(40)
+    x = rng.integers(0, W5, n5).astype(np.float32)
+    y = rng.integers(0, H5, n5).astype(np.float32)
+    t = np.sort(rng.uniform(0.0, 0.1, n5)).astype(np.float32)
+    p = (rng.integers(0, 2, n5) * 2 - 1).astype(np.float32)
+    cols = [torch.from_numpy(a).to(dev) for a in (x, y, t, p)]
+    kinfo = tiled.time_voxel_kernels(*cols, float(t[0]), float(t[-1]), B, H5, W5, impl=impl, reps=10)
+    alg = 16.0 * n5 + B * H5 * W5 * 4.0
+    res = {"workload": "one rank's share of configs[4]: 50M events, 1280x720, 5 bins, single GPU, HBM-resident (800 MB)",
+           "ms_per_call": round(kinfo["total_ms"], 4), "Mevents_per_s": round(n5 / kinfo["total_ms"] / 1e3, 1),
+           "roofline": roofline_block(kinfo, alg, n5, "c5_share")}
+    del cols
+    torch.cuda.empty_cache()
+    return res
 
 
 def bench_native(DeviceEvents, voxel, x, y, t, p, B, H, W, impl, reps):
@@ -230,22 +339,23 @@ def bench_native(DeviceEvents, voxel, x, y, t, p, B, H, W, impl, reps):
     return res
 
 
-def pmc_traffic(kernel, n):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, gfx950 correction applied).  PMC counters
-    cannot be collected from inside the timed process, so this is the recorded measurement for the default workload
-    (10 M events); None for any other size or when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if n != N_PER_GPU or not os.path.isfile(path):
-        return None, None
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` (and of the whole call) from the committed rocprofv3 PMC passes
+    (profiles/r02_pmc_traffic.json: separate --pmc passes for reads and writes of this same workload, gfx950 corrections
+    applied as MI355X_MICROARCH.md prescribes; tools/profile_round.sh).  PMC counters cannot be collected from inside the
+    timed process, so this is the recorded measurement of the workload `tag`; None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.isfile(path):
+        return None, None, None
     try:
-        ks = json.load(open(path))["kernels"]
-        for name, v in ks.items():
+        prof = json.load(open(path)).get(tag, {})
+        for name, v in prof.get("kernels", {}).items():
             if kernel.split("(")[0] in name:
-                return v["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, per launch)"
+                return (v["hbm_bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json[%s] (rocprofv3 --pmc, per launch)" % tag,
+                        prof.get("whole_call_bytes"))
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def _time_evals(obj, w, ev, prm, size, reps=10):
@@ -424,11 +534,11 @@ def cmax_cpu_baseline(x, y, t, p, m=2_000_000):
     xs, ys, ts, ps = (a[:m].astype(np.float64) for a in (x, y, t, p))
     prm = np.array([30.0, -20.0])
     res = {"unit": "Mevents/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "first %d events of the configs[2] stream, 640x480, median of 3 runs" % m}
+           "sample": "first %d events of the configs[2] stream, 640x480, median of 5 runs" % m}
     for name, fn in (("f", T.variance_f), ("grad", T.variance_grad)):
         fn(prm, xs, ys, ts, ps, (H, W), (H, W), 1.0)
         ts_ = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             fn(prm, xs, ys, ts, ps, (H, W), (H, W), 1.0)
             ts_.append(time.perf_counter() - t0)
@@ -438,13 +548,13 @@ def cmax_cpu_baseline(x, y, t, p, m=2_000_000):
 
 def cpu_baseline(x, y, t, p):
     """The reference's numpy CPU path (events_to_voxel, voxel_grid.py:184-217) as restated in oracle/reference_np.py,
-    timed on this box's host, one thread, on the same 10 M-event workload (bounded: 1 warm-up on 1 M, 2 timed reps)."""
+    timed on this box's host, one thread, on the same 10 M-event workload (bounded: 1 warm-up on 1 M, 5 timed reps)."""
     from oracle import reference_np as R
     xi, yi = x.astype(np.int64), y.astype(np.int64)
     t64, p64 = t.astype(np.float64), p.astype(np.float64)
     m = 1_000_000
     R.events_to_voxel(xi[:m], yi[:m], t64[:m], p64[:m], B, sensor_size=(H, W))
-    reps, best = 2, []
+    reps, best = 5, []
     for _ in range(reps):
         t0 = time.perf_counter()
         R.events_to_voxel(xi, yi, t64, p64, B, sensor_size=(H, W))

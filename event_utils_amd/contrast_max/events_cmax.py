@@ -19,12 +19,12 @@ import scipy.optimize as opt
 
 from ..events import DeviceEvents
 from .objectives import get_iwe, objective_function, soe_objective, variance_objective  # noqa: F401
-from .warps import linvel_warp, warp_function  # noqa: F401
+from .warps import linvel_warp, uses_fused_linvel, warp_function  # noqa: F401
 
 
 def _resident(xs, ys, ts, ps, warp_function, objective):
     """Upload the events once for the fused linear-flow path; plugin warps keep their host arrays."""
-    if getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function):
+    if uses_fused_linvel(warp_function) and isinstance(objective, objective_function):
         ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
         return ev, None, None, None
     return xs, ys, ts, ps
@@ -179,7 +179,7 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
     x0 = [0, 0], objective.iter_update(x0), then fmin_bfgs(f, x0, fprime | epsilon=1, args, callback=iter_update).
     xs may also be a DeviceEvents (ys, ts, ps are then ignored).
     """
-    fused = getattr(warp_function, "fused_kernel", None) == "linvel" and isinstance(objective, objective_function)
+    fused = uses_fused_linvel(warp_function) and isinstance(objective, objective_function)
     xs, ys, ts, ps = _resident(xs, ys, ts, ps, warp_function, objective)         # resident events, uploaded once
     if grid_search_init and x0 is None:
         # events_cmax.py:333-337: coarse-to-fine grid search on a copy of the objective without adaptive lifespan
@@ -261,7 +261,7 @@ def grid_cmax(xs, ys, ts, ps, roi_size=(20, 20), step=None, warp=None, obj=None,
     """
     warp = linvel_warp() if warp is None else warp
     step = roi_size if step is None else step
-    if getattr(warp, "fused_kernel", None) != "linvel":
+    if not uses_fused_linvel(warp):
         raise NotImplementedError("grid_cmax is provided for the fused linear-flow warp (upstream hard-wires it too, :47)")
     # the events go to the device once; the cells are cut out of the resident columns there
     everything = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)

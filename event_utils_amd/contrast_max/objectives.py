@@ -23,6 +23,7 @@ from .. import tiled
 from ..events import DeviceEvents
 from ..representations.image import _events_to_image_drv_device, image_to_event_weights
 from ..util.event_util import events_bounds_mask
+from .warps import uses_fused_linvel
 
 
 def gaussian_kernel1d(sigma, truncate=4.0):
@@ -109,7 +110,7 @@ def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, 
     linvel_warp uses the fused kernel; any other warp_function plugin is called as upstream and its output goes
     through the generic mask + splat kernels.
     """
-    fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
+    fused = uses_fused_linvel(warpfunc)
     if fused and not return_events and not return_per_event_contrast:
         ev = _as_device_events(xs, ys, ts, ps)
         iwe, diwe = iwe_device(params, ev, img_size, compute_gradient, use_polarity, sensor_size)
@@ -214,7 +215,7 @@ class objective_function(ABC):
     def _one_call(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, grad, post_flags):
         """Whole evaluation in ONE library call (tiled.cmax_variance) -> 4 doubles on the host, or None when that
         path does not apply (plugin warp, event-sharded run, direct-kernel fallback)."""
-        if getattr(warpfunc, "fused_kernel", None) != "linvel" or self.distributed or self.process_group is not None:
+        if not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None:
             return None
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
         if len(ev) == 0:
@@ -233,7 +234,7 @@ class objective_function(ABC):
         return out.cpu().numpy() if ok else None
 
     def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):
-        fused = getattr(warpfunc, "fused_kernel", None) == "linvel"
+        fused = uses_fused_linvel(warpfunc)
         if fused:
             ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
             return iwe_device(params, ev, img_size, compute_gradient, self.use_polarity, self.sensor_size, self.impl,
@@ -281,7 +282,7 @@ class variance_objective(objective_function):
     def _batch3_setup(self, xs, ys, ts, ps, warpfunc, blur_sigma):
         """Device state shared by the three-flows-per-pass launches, or None when that kernel does not apply (plugin
         warp, event-sharded run, no events)."""
-        if (getattr(warpfunc, "fused_kernel", None) != "linvel" or self.distributed or self.process_group is not None):
+        if (not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None):
             return None
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
         if len(ev) == 0:

@@ -28,7 +28,7 @@ class linvel_warp(warp_function):
     When get_iwe / the objectives see this class they use the fused warp->mask->splat kernel instead of calling
     .warp() and materialising x', y' and the two (2, N) Jacobians."""
 
-    fused_kernel = "linvel"
+    fused_kernel = "linvel"          # informational; dispatch goes through uses_fused_linvel()
 
     def __init__(self):
         warp_function.__init__(self, 'linvel_warp', 2)
@@ -47,6 +47,12 @@ class linvel_warp(warp_function):
             return xo, yo, jx, jy
         return (xo.cpu().numpy(), yo.cpu().numpy(), jx.cpu().numpy() if compute_grad else None,
                 jy.cpu().numpy() if compute_grad else None)
+
+
+def uses_fused_linvel(warpfunc):
+    """True when `warpfunc` warps exactly like linvel_warp, so that the fused warp -> mask -> splat kernels may replace
+    its warp(): the class itself, or a subclass that did NOT override warp() (a plugin that did must be called)."""
+    return isinstance(warpfunc, linvel_warp) and type(warpfunc).warp is linvel_warp.warp
 
 
 def warp_events(xs, ys, ts, ps, t0, params, compute_grad=False):

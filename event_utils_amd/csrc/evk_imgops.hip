@@ -211,12 +211,15 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     extern __shared__ float sm[];
     const int r = bw.radius, PW = EVK_POST_T + 2 * r;
     float *patch = sm, *inter = sm + PW * PW;
-    const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T;
-    const int y0 = (blockIdx.x / tiles_x) * EVK_POST_T, x0 = (blockIdx.x % tiles_x) * EVK_POST_T;
+    const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T, ntile = tiles_x * ((ch + EVK_POST_T - 1) / EVK_POST_T);
     const int64_t plane = (int64_t)ch * cw;
     iwe += blockIdx.y * plane;                                         // MODE 0 batched over image planes
     partials += (int64_t)blockIdx.y * gridDim.x * EVK_REDUCE_K;
     double acc[EVK_REDUCE_K] = {};
+    // one 32x32 output tile per workgroup, or several (grid-stride) when the image has more tiles than the reduction
+    // scratch has slots (1080p x 3 planes, 4K): the partial sums of a workgroup's tiles are added in tile order
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int y0 = (tile / tiles_x) * EVK_POST_T, x0 = (tile % tiles_x) * EVK_POST_T;
     if constexpr (MODE == 0 || MODE == 2) {
         float v[4];
         blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
@@ -278,6 +281,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
                 }
             }
         }
+    }
     }
     block_sum<EVK_REDUCE_K>(acc, partials + (int64_t)blockIdx.x * EVK_REDUCE_K);
 }
@@ -356,8 +360,8 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
         return EVK_OK;
     }
     if (!host_weights || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
-    const int grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
-    if (grid * nplanes > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
+    int grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
+    if (grid > EVK_REDUCE_MAX_BLOCKS / nplanes) grid = EVK_REDUCE_MAX_BLOCKS / nplanes;  // the kernel strides over the tiles
     BlurWeights bw;
     bw.radius = radius;
     for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
@@ -408,7 +412,7 @@ __global__ void k_stats_finish(const double *__restrict__ wide, const unsigned i
 static int blur_setup(int h, int w, const double *host_weights, int radius, BlurWeights &bw, int &grid, size_t &lds) {
     if (!host_weights || radius < 0 || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
     grid = ((h + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
-    if (grid > EVK_REDUCE_MAX_BLOCKS) return EVK_EINVAL;
+    if (grid > EVK_REDUCE_MAX_BLOCKS - 8) grid = EVK_REDUCE_MAX_BLOCKS - 8;  // the kernel strides over the tiles
     bw.radius = radius;
     for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
     const int PW = EVK_POST_T + 2 * radius;
@@ -433,7 +437,6 @@ extern "C" int evk_objective_stats_f32(const float *img, int h, int w, const dou
     // tail of the scratch: 8 doubles of wide sums + the running max
     double *wide = (double *)scratch + (int64_t)EVK_REDUCE_MAX_BLOCKS * EVK_REDUCE_K - 16;
     unsigned int *max_bits = (unsigned int *)(wide + 8);
-    if (grid * EVK_REDUCE_K > EVK_REDUCE_MAX_BLOCKS * EVK_REDUCE_K - 16) return EVK_EINVAL;
     hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(unsigned int), s);
     if (e != hipSuccess) return (int)e;
     PostParams pp;

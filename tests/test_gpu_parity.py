@@ -90,8 +90,12 @@ def test_f2_voxel_numpy(E, golden, tag, Bs):
         close(v, g["%s_voxel_B%d" % (tag, B)], 1e-12)
 
 
+@pytest.mark.parametrize("impl", ["auto", "direct", "tiled-v2", "tiled-v1"])
 @pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
-def test_f3_voxel_torch(E, golden, tag, Bs):
+def test_f3_voxel_torch(E, golden, tag, Bs, impl, monkeypatch):
+    # every kernel family against the reference's own outputs: global atomics, one-pass partition, three-pass sort
+    monkeypatch.setenv("EVK_IMPL", impl.split("-")[0])
+    monkeypatch.setenv("EVK_VOXEL_PATH", impl.split("-")[1] if "-" in impl else "v2")
     g = golden("f3_voxel_torch")
     xs, ys, ts = (torch.from_numpy(g[tag + k]) for k in ("_xs", "_ys", "_ts"))
     ps = torch.from_numpy(g[tag + "_ps"].astype(np.float32))
@@ -235,7 +239,9 @@ def test_f5_warp_bit_exact(E, golden):
 
 
 # ------------------------------------------------------------------------------------------------ F6 / F7 IWE
-def test_f6_get_iwe_verbatim(E, golden):
+@pytest.mark.parametrize("impl", ["auto", "direct", "tiled"])
+def test_f6_get_iwe_verbatim(E, golden, impl, monkeypatch):
+    monkeypatch.setenv("EVK_IMPL", impl)
     g = golden("f6_get_iwe")
     x, y, t, p = f64(g["xs"]), f64(g["ys"]), f64(g["ts"]), f64(g["ps"])
     w = E.linvel_warp()
@@ -252,8 +258,10 @@ def test_f6_get_iwe_verbatim(E, golden):
     close(iwe, g["q1_iwe"]); close(diwe, g["q1_diwe"])
 
 
+@pytest.mark.parametrize("impl", ["auto", "direct", "tiled"])
 @pytest.mark.parametrize("tag", ["s48", "vga"])
-def test_f7_iwe_sized_and_generic_plugin_path(E, golden, tag):
+def test_f7_iwe_sized_and_generic_plugin_path(E, golden, tag, impl, monkeypatch):
+    monkeypatch.setenv("EVK_IMPL", impl)
     g = golden("f7_iwe_sized")
     x, y, t, p = f64(g[tag + "_xs"]), f64(g[tag + "_ys"]), f64(g[tag + "_ts"]), f64(g[tag + "_ps"])
     ss = tuple(g[tag + "_sensor_size"])

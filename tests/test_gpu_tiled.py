@@ -74,7 +74,7 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
     close(v.cpu().numpy(), ref)
 
 
-def test_voxel_tiled_errors_and_wrap(E):
+def test_voxel_tiled_errors_and_wrap(E, monkeypatch):
     n, H, W = 2000, 40, 60
     x, y, t, p = _events(1, n, H, W)
     x[5] = -1.0; y[7] = -3.0                      # wrap like torch index_put_
@@ -82,8 +82,23 @@ def test_voxel_tiled_errors_and_wrap(E):
     v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), 4, sensor_size=(H, W))
     close(v.cpu().numpy(), ref)
     x[11] = W + 2.0
+    bad = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    monkeypatch.setenv("EVK_ERRORS", "strict")        # one synchronisation per call, the reference's CPU behaviour
     with pytest.raises(IndexError):
-        E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), 4, sensor_size=(H, W))
+        E.events_to_voxel_torch(*bad, 4, sensor_size=(H, W))
+    with pytest.raises(IndexError):                   # host tensors: always strict
+        E.events_to_voxel_torch(*(c.cpu() for c in bad), 4, sensor_size=(H, W))
+    monkeypatch.setenv("EVK_ERRORS", "deferred")      # device in, device out: reported like a CUDA device-side assert
+    v = E.events_to_voxel_torch(*bad, 4, sensor_size=(H, W))     # enqueues, returns
+    assert v.is_cuda
+    with pytest.raises(IndexError):
+        E.check_errors()                               # ... and surfaces here (or at the next call on the stream)
+    E.check_errors()                                   # reported once
+    E.events_to_voxel_torch(*bad, 4, sensor_size=(H, W))
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):                   # the next call on the stream reports the previous one
+        E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (np.abs(x) % W, y, t, p)), 4, sensor_size=(H, W))
+    E.check_errors()
     # all events in one pixel (one hot tile, every other tile empty)
     x[:] = 17; y[:] = 23
     ref = R.events_to_voxel_torch(x, y, t, p, 4, sensor_size=(H, W), accum="f64")
