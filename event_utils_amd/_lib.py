@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
+EVK_IWE_PACK32 = 8
 EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE = 1, 2, 4
 EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
 EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
@@ -42,15 +43,15 @@ SIGNATURES = {
     "evk_objective_variance_f32": [P, c_int, c_int, P, c_int, P, P, c_int64, P],
     "evk_objective_variance_grad_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_cmax_variance_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
-                                    c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, P, c_int,
+                                    c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, c_double, P, c_int,
                                     c_uint32, P, c_int64, P, P, P, c_int64, P],
     "evk_iwe_linvel_tiled_batch3_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                         c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
-                                        P, c_int64, P, P],
+                                        c_double, P, c_int64, P, P],
     "evk_objective_variance_planes_f32": [P, c_int, c_int, c_int, P, c_int, P, P, c_int64, P],
     "evk_cmax_variance_batch3_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                            c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
-                                           P, c_int, P, c_int64, P, P, P, c_int64, P],
+                                           c_double, P, c_int, P, c_int64, P, P, P, c_int64, P],
     "evk_objective_stats_f32": [P, c_int, c_int, P, c_int, c_double, c_double, P, P, c_int64, P],
     "evk_objective_variance_fg_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_objective_gradsums_f32": [P, P, c_int, c_int, P, c_int, c_uint32, c_int, c_double, P, P, c_int64, P],
@@ -65,7 +66,8 @@ SIGNATURES = {
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
                               c_float, c_int, c_int, P, P, P, c_int64, P, P],
     "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
-                                 c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, P, c_int64, P, P, P],
+                                 c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, c_double, P, c_int64,
+                                 P, P, P],
 }
 _SPECIAL = {
     "evk_version": ([], c_int),

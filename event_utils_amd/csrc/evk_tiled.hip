@@ -422,7 +422,8 @@ struct IweParams {
     int abs_p, grad;
     int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
     double vxb[2], vyb[2];           // MODE 2 (batch of 3 nearby flows): flows 1 and 2 (flow 0 is vx, vy)
-    double fx_scale, fx_inv;         // FIXED: LDS cells hold sum(value * 2^k) as int64 (2^k = fx_scale)
+    double fx_scale, fx_inv;         // FIXED 1: LDS cells hold sum(value * 2^k) as int64 (2^k = fx_scale)
+    float pair_sI, pair_sE, pair_invI, pair_invE;  // FIXED 2: 2^20 / pow2ceil(bound) for the IWE / E planes, inverses
 };
 
 // Same per-event arithmetic as evk_scatter.hip's iwe_event (kept textually identical: parity depends on it).
@@ -453,7 +454,59 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
 // the host so that n * max|contribution| < 2^61 cannot overflow (k >= 26, typically 30-36): quantisation <= 2^-(k+1) per
 // event, orders of magnitude below the float32 rounding of the result, and integer adds commute, so the window sums
 // are bit-reproducible from run to run.
-template <int MODE, bool FIXED>
+//
+// FIXED 2 -- PACKED PAIRS (gradient and three-flow modes).  With 8 / 12 64-bit atomics per event these modes are LDS-atomic
+// bound, 40 % of the LDS cycles being bank conflicts of randomly placed 8-byte cells
+// (profiles/r01_c4_iwe_lds_counters.json).  The bilinear splat always touches PAIRS of neighbouring cells, so two 32-bit
+// fixed-point accumulators are packed in one 64-bit word and a pair takes ONE ds_add_rtn_u64:
+//     word += (int64)lo + ((int64)hi << 32)
+// That sum is exact modulo 2^64: the low field holds sum(lo) modulo 2^32 -- read back as a signed 32-bit number it IS
+// sum(lo) while |sum(lo)| < 2^31 -- and the high field holds sum(hi) plus the carries of the low one, which
+// (word - lo) >> 32 removes exactly.  A pair can start on an even or an odd cell, so every line has two word arrays:
+// A[j] = cells (2j, 2j+1), B[j] = cells (2j+1, 2j+2); cell c = its field in A + its field in B (same LDS footprint as
+// one 64-bit cell per pixel).  Horizontal pairs serve the IWE rows (x, x+1) and the gradient's E1 plane; the E0 plane
+// pairs (y, y+1), so it is held column-major.  Atomics per event: 4 (gradient) / 6 (three flows) instead of 8 / 12.
+// Resolution and range: every contribution is scaled by 2^20 / (its bound rounded up to a power of two), i.e.
+// |contribution| < 2^20 with a quantisation of 2^-21 of the bound (float32 inputs carry 2^-24).  A field therefore
+// overflows only after the equivalent of 1024 full-weight events on ONE pixel; the atomic returns the old word, so the
+// lane that pushes a field beyond 2^30 takes the whole word out (exchange with 0) and adds it to the output image
+// with global atomics, exactly like an event outside the window.  Nothing is lost (the exchange is atomic, and fewer than
+// 2^10 concurrent adds cannot carry a field from 2^30 past 2^31); only such hot pixels lose run-to-run bit
+// reproducibility.
+#define EVK_PAIR_SHIFT 20
+struct PairOverflow {  // where the two cells of a word live in the output image, for the rare drain
+    float *lo_minus, *lo_plus, *hi_minus, *hi_plus;  // value is added to *_plus and subtracted from *_minus (nullptr: skip)
+};
+__device__ __forceinline__ long long pair_lo(unsigned long long w) { return (long long)(int)(unsigned int)w; }
+__device__ __forceinline__ long long pair_hi(unsigned long long w) { return ((long long)w - pair_lo(w)) >> 32; }
+template <typename OVF>
+__device__ __forceinline__ void add_pair(unsigned long long *word, float vlo, float vhi, float scale, float inv, OVF where) {
+    const int lo = __float2int_rn(vlo * scale), hi = __float2int_rn(vhi * scale);
+    const unsigned long long packed = (unsigned long long)(unsigned int)lo |
+                                      ((unsigned long long)(unsigned int)(hi + (lo >> 31)) << 32);
+    const unsigned long long now =
+        __hip_atomic_fetch_add(word, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + packed;
+    // a 32-bit field has left [-2^30, 2^30) iff its two top bits differ (the high field is off by the low one's borrow,
+    // i.e. by at most 1: irrelevant here)
+    const unsigned int wl = (unsigned int)now, wh = (unsigned int)(now >> 32);
+    if (((wl ^ (wl << 1)) | (wh ^ (wh << 1))) & 0x80000000u) {  // rare: a hot pixel; drain the word into the image
+        const unsigned long long taken = __hip_atomic_exchange(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const PairOverflow o = where();
+        const float fl = (float)pair_lo(taken) * inv, fh = (float)pair_hi(taken) * inv;
+        if (o.lo_plus) atomic_add(o.lo_plus, fl);
+        if (o.lo_minus) atomic_add(o.lo_minus, -fl);
+        if (o.hi_plus) atomic_add(o.hi_plus, fh);
+        if (o.hi_minus) atomic_add(o.hi_minus, -fh);
+    }
+}
+// cell c of a line of `len` cells held as A[0 .. len/2) | B[0 .. len/2)
+__device__ __forceinline__ long long pair_cell(const unsigned long long *line, int len, int c) {
+    const int half = len >> 1, j = c >> 1;
+    if (c & 1) return pair_hi(line[j]) + pair_lo(line[half + j]);
+    return pair_lo(line[j]) + (j > 0 ? pair_hi(line[half + j - 1]) : 0ll);
+}
+
+template <int MODE, int FIXED>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
                                                          const uint32_t *__restrict__ index, TileGrid g,
                                                          IweParams q, float *__restrict__ staging,
@@ -498,8 +551,10 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     }
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
+    const float sI = q.pair_sI, sE = q.pair_sE, invI = q.pair_invI, invE = q.pair_invE;
+    const int halfw = q.win_w >> 1, halfh = q.win_h >> 1;
     auto lds_acc = [&](acc_t *cell, float v) {
-        if constexpr (FIXED) {
+        if constexpr (FIXED == 1) {
             // round-to-nearest double -> int64 with one add: for |x| < 2^51 the low mantissa bits of x + 1.5*2^52 hold
             // x as a two's-complement integer (the host caps k so that every contribution satisfies |x| < 2^50)
             const double magic = 6755399441055744.0;
@@ -518,6 +573,27 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         const int lx = px - wx0, ly = py - wy0;
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
+            if constexpr (FIXED == 2) {
+                unsigned long long *W = reinterpret_cast<unsigned long long *>(wp);
+                const int col = (lx & 1) ? halfw + (lx >> 1) : (lx >> 1);
+                float *gc = gp + (int64_t)py * q.cw + px;  // the event's top-left pixel in the output image
+                add_pair(W + ly * q.win_w + col, mp * ax * ay, mp * dx * ay, sI, invI,
+                         [&] { return PairOverflow{nullptr, gc, nullptr, gc + 1}; });
+                add_pair(W + (ly + 1) * q.win_w + col, mp * ax * dy, mp * dx * dy, sI, invI,
+                         [&] { return PairOverflow{nullptr, gc + q.cw, nullptr, gc + q.cw + 1}; });
+                if constexpr (GRAD) {
+                    // E0 = (a*ay at (x, y), a*dy at (x, y+1)): a vertical pair, plane held column-major;
+                    // E1 = (a*ax at (x, y), a*dx at (x+1, y)): a horizontal pair.  In the image E0(x, y) is -d0[y][x],
+                    // +d0[y][x+1] and E1(x, y) is -d1[y][x], +d1[y+1][x] (the finite differences of the flush).
+                    unsigned long long *V = W + wcells, *H1 = V + wcells;
+                    float *d0 = diwe + (int64_t)py * q.cw + px, *d1 = d0 + plane;
+                    add_pair(V + lx * q.win_h + ((ly & 1) ? halfh + (ly >> 1) : (ly >> 1)), a * ay, a * dy, sE, invE,
+                             [&] { return PairOverflow{d0, d0 + 1, d0 + q.cw, d0 + q.cw + 1}; });
+                    add_pair(H1 + ly * q.win_w + col, a * ax, a * dx, sE, invE,
+                             [&] { return PairOverflow{d1, d1 + q.cw, d1 + 1, d1 + q.cw + 1}; });
+                }
+                return;
+            }
             acc_t *c = wp + ly * q.win_w + lx;
             lds_acc(c, mp * ax * ay);
             lds_acc(c + 1, mp * dx * ay);
@@ -564,12 +640,34 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
     // cell value / difference of two cells as float (exact integer difference on the fixed-point path)
+    if constexpr (FIXED == 2) {
+        const unsigned long long *W = reinterpret_cast<const unsigned long long *>(win);
+        for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
+            const int lx = c % q.win_w, ly = c / q.win_w;
+            st[c] = (float)((double)pair_cell(W + ly * q.win_w, q.win_w, lx) * (double)invI);
+            if constexpr (GRAD) {
+                const unsigned long long *V = W + wcells, *H1 = V + wcells;
+                const long long e0 = pair_cell(V + lx * q.win_h, q.win_h, ly);
+                const long long e0l = lx > 0 ? pair_cell(V + (lx - 1) * q.win_h, q.win_h, ly) : 0ll;
+                const long long e1 = pair_cell(H1 + ly * q.win_w, q.win_w, lx);
+                const long long e1u = ly > 0 ? pair_cell(H1 + (ly - 1) * q.win_w, q.win_w, lx) : 0ll;
+                st[wcells + c] = (float)((double)(e0l - e0) * (double)invE);      // d0[y][x] = E0[y][x-1] - E0[y][x]
+                st[2 * wcells + c] = (float)((double)(e1u - e1) * (double)invE);  // d1[y][x] = E1[y-1][x] - E1[y][x]
+            }
+            if constexpr (MODE == 2) {
+                st[wcells + c] = (float)((double)pair_cell(W + wcells + ly * q.win_w, q.win_w, lx) * (double)invI);
+                st[2 * wcells + c] = (float)((double)pair_cell(W + 2 * wcells + ly * q.win_w, q.win_w, lx) * (double)invI);
+            }
+        }
+        if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
+        return;
+    }
     auto cell = [&](const acc_t *a) -> float {
-        if constexpr (FIXED) return (float)((double)*reinterpret_cast<const long long *>(a) * q.fx_inv);
+        if constexpr (FIXED == 1) return (float)((double)*reinterpret_cast<const long long *>(a) * q.fx_inv);
         else return (float)*a;
     };
     auto diff = [&](const acc_t *a, const acc_t *b) -> float {  // a - b; a == nullptr means 0
-        if constexpr (FIXED) {
+        if constexpr (FIXED == 1) {
             const long long va = a ? *reinterpret_cast<const long long *>(a) : 0ll;
             return (float)((double)(va - *reinterpret_cast<const long long *>(b)) * q.fx_inv);
         } else {
@@ -850,7 +948,7 @@ extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices
 static int launch_iwe_tiled(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                             int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
                             const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h,
-                            int canvas_w, uint32_t flags, double p_scale, double acc_bound, void *staging,
+                            int canvas_w, uint32_t flags, double p_scale, double p_bound, double dt_bound, void *staging,
                             int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_index || !iwe || !staging)
@@ -879,7 +977,22 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     }
     q.sx_lo = (int)floor(dx_lo) - 1, q.sx_hi = (int)floor(dx_hi) - 1;
     q.sy_lo = (int)floor(dy_lo) - 1, q.sy_hi = (int)floor(dy_hi) - 1;
-    // fixed-point LDS accumulation when the caller can bound every cell sum (acc_bound >= n * max|contribution|)
+    // fixed-point LDS accumulation when the caller can bound every contribution: |p * p_scale| <= p_bound, |t - t_ref| <=
+    // dt_bound.  64-bit cells: one scale for the launch from n * p_bound * max(1, dt_bound) >= any cell sum.
+    // Packed 32-bit pairs (EVK_IWE_PACK32; gradient and three-flow modes, see k_iwe_tiled): scale 2^20 / pow2ceil(bound).
+    const double acc_bound = (p_bound > 0.0 && dt_bound >= 0.0) ? (double)n * p_bound * fmax(1.0, dt_bound) : 0.0;
+    bool pack32 = false;
+    q.pair_sI = q.pair_sE = q.pair_invI = q.pair_invE = 1.0f;
+    if ((flags & EVK_IWE_PACK32) && mode != 0 && acc_bound > 0.0 && acc_bound < 1e300 && win_w % 2 == 0 && win_h % 2 == 0) {
+        int eI, eE;
+        (void)frexp(p_bound * 1.0000002, &eI);                          // p_bound < 2^eI
+        (void)frexp(fmax(p_bound * dt_bound, 1e-30) * 1.0000002, &eE);
+        if (eI > -80 && eI < 80 && eE > -80 && eE < 80) {
+            pack32 = true;
+            q.pair_sI = (float)ldexp(1.0, EVK_PAIR_SHIFT - eI), q.pair_invI = (float)ldexp(1.0, eI - EVK_PAIR_SHIFT);
+            q.pair_sE = (float)ldexp(1.0, EVK_PAIR_SHIFT - eE), q.pair_invE = (float)ldexp(1.0, eE - EVK_PAIR_SHIFT);
+        }
+    }
     int k = 0;
     if (acc_bound > 0.0 && acc_bound < 1e300) {
         int e;
@@ -902,8 +1015,9 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     const float4 *rec = (const float4 *)records;
 #define EVK_IWE_LAUNCH(M)                                                                                          \
     do {                                                                                                           \
-        if (fixed) k_iwe_tiled<M, true><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
-        else k_iwe_tiled<M, false><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
+        if (pack32) k_iwe_tiled<M, 2><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
+        else if (fixed) k_iwe_tiled<M, 1><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
+        else k_iwe_tiled<M, 0><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);      \
     } while (0)
     if (mode == 0) {
         EVK_IWE_LAUNCH(0);
@@ -923,21 +1037,21 @@ extern "C" int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bu
                                         int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
                                         double t_first, double t_ref, double vx, double vy, double bounds_w,
                                         double bounds_h, int canvas_h, int canvas_w, uint32_t flags, double p_scale,
-                                        double acc_bound, void *staging, int64_t staging_bytes, float *iwe,
+                                        double p_bound, double dt_bound, void *staging, int64_t staging_bytes, float *iwe,
                                         float *diwe, void *stream) {
     return launch_iwe_tiled((flags & EVK_IWE_GRADIENT) ? 1 : 0, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2,
                             slices, win_w, win_h, t_first, t_ref, &vx, &vy, bounds_w, bounds_h, canvas_h, canvas_w,
-                            flags, p_scale, acc_bound, staging, staging_bytes, iwe, diwe, stream);
+                            flags, p_scale, p_bound, dt_bound, staging, staging_bytes, iwe, diwe, stream);
 }
 
 extern "C" int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
                                                int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
                                                double t_first, double t_ref, const double *host_vx,
                                                const double *host_vy, double bounds_w, double bounds_h, int canvas_h,
-                                               int canvas_w, uint32_t flags, double p_scale, double acc_bound,
+                                               int canvas_w, uint32_t flags, double p_scale, double p_bound, double dt_bound,
                                                void *staging, int64_t staging_bytes, float *iwe3, void *stream) {
     if (!host_vx || !host_vy || !iwe3 || (flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
     return launch_iwe_tiled(2, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
-                            t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, acc_bound,
+                            t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, p_bound, dt_bound,
                             staging, staging_bytes, iwe3, iwe3 + (size_t)canvas_h * canvas_w, stream);
 }

@@ -316,11 +316,17 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
         flow = (D.host_ptr(keep[0]), D.host_ptr(keep[1]))
     # bound of any accumulator cell: every event in one pixel, weight |p| * p_scale (* |dt| for the derivative planes);
     # lets the kernel accumulate in 64-bit fixed point (EVK_IWE_FIXED=0 keeps float64 accumulation)
-    acc_bound = 0.0
-    if os.environ.get("EVK_IWE_FIXED", "1") != "0":
-        acc_bound = float(len(ev)) * ev.p_absmax() * abs(float(ev.p_scale)) * max(1.0, span)
+    # EVK_IWE_FIXED: "0" float64 accumulation, "64" (default) 64-bit fixed-point cells, "32" packed 32-bit pairs for the
+    # gradient / three-flow modes (include/evk.h; measured: -10 % at 50 M events / 720p, +7 % at 10 M / VGA -- the
+    # returning atomics its overflow check needs cost what the halved atomic count saves)
+    p_bound, dt_bound, fixed = 0.0, 0.0, os.environ.get("EVK_IWE_FIXED", "64")
+    if fixed != "0":
+        p_bound = ev.p_absmax() * abs(float(ev.p_scale))
+        dt_bound = max(span, abs(ev.t_at(-1) - t_ref))
+        if fixed == "32":
+            flags = flags | _lib.EVK_IWE_PACK32
     head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
-        flow + (bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale), acc_bound)
+        flow + (bounds_w, bounds_h, ch, cw, flags, float(ev.p_scale), p_bound, dt_bound)
     return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk, "keep": keep}
 
 

@@ -333,16 +333,21 @@ int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, con
  * iwe / diwe.  Events falling outside their window use a global atomic (correct for any flow; slices / win_* only
  * tune speed).  t_first = earliest event time (bounds the window shifts).  Same per-event arithmetic as
  * evk_iwe_linvel_f32.
- * acc_bound: an upper bound of |sum| any accumulator cell can reach (e.g. n * max|p * p_scale| * max(1, |t_first-t_ref|)),
- * or 0.  With a bound the LDS windows accumulate in 64-bit FIXED POINT (value * 2^k, k = min(40, 61 - ceil(log2(bound))),
- * used when k >= 26): ds_add_u64 is 1.5x faster than ds_add_f64 on gfx950 and this kernel is LDS-atomic bound; the
- * quantisation (<= 2^-(k+1) per event) is far below the float32 rounding of the result and the sums become
- * order-independent.  0 = float64 accumulation. */
+ * p_bound / dt_bound: upper bounds of |p * p_scale| and of |t - t_ref| over the events (0 / negative = unknown).  With
+ * bounds the LDS windows accumulate in FIXED POINT -- this kernel is LDS-atomic bound, ds_add_u64 is 1.5x faster than
+ * ds_add_f64 on gfx950, and integer sums are order-independent (bit-reproducible):
+ *   - 64-bit cells, value * 2^k with k = min(40, 61 - ceil(log2(n * p_bound * max(1, dt_bound)))), used when k >= 26;
+ *   - with EVK_IWE_PACK32 (gradient and three-flow modes), two 32-bit accumulators per 64-bit word so that a PAIR of
+ *     neighbouring cells takes one atomic (4 / 6 atomics per event instead of 8 / 12): contributions scaled to < 2^20
+ *     (quantisation 2^-21 of the bound); a field that passes 2^30 (a pixel hotter than ~1000 full-weight events within one
+ *     workgroup) is drained into the image with global atomics, so nothing overflows.
+ * Quantisation <= 2^-(k+1) per contribution for the 64-bit cells.  Without bounds: float64 accumulation. */
+#define EVK_IWE_PACK32 8u
 int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h);
 int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                              int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
                              double vx, double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
-                             uint32_t flags, double p_scale, double acc_bound, void *staging, int64_t staging_bytes,
+                             uint32_t flags, double p_scale, double p_bound, double dt_bound, void *staging, int64_t staging_bytes,
                              float *iwe, float *diwe, void *stream);
 
 /* variance_objective.evaluate_function / evaluate_gradient (objectives.py:211-264) in ONE call on bucketed records:
@@ -353,7 +358,7 @@ int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index,
 int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                                 int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
                                 double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
-                                uint32_t iwe_flags, double p_scale, double acc_bound, const double *host_weights,
+                                uint32_t iwe_flags, double p_scale, double p_bound, double dt_bound, const double *host_weights,
                                 int radius, uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf,
                                 double *out, void *scratch, int64_t scratch_bytes, void *stream);
 
@@ -367,7 +372,8 @@ int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket
                                     int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
                                     double t_ref, const double *host_vx, const double *host_vy, double bounds_w,
                                     double bounds_h, int canvas_h, int canvas_w, uint32_t flags, double p_scale,
-                                    double acc_bound, void *staging, int64_t staging_bytes, float *iwe3, void *stream);
+                                    double p_bound, double dt_bound, void *staging, int64_t staging_bytes, float *iwe3,
+                                    void *stream);
 /* evk_objective_variance_f32 for nplanes stacked images: out = nplanes x 4 doubles. */
 int evk_objective_variance_planes_f32(const float *imgs, int nplanes, int h, int w, const double *host_weights,
                                       int radius, double *out, void *scratch, int64_t scratch_bytes, void *stream);
@@ -376,7 +382,7 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,
                                        double t_first, double t_ref, const double *host_vx, const double *host_vy,
                                        double bounds_w, double bounds_h, int canvas_h, int canvas_w, uint32_t iwe_flags,
-                                       double p_scale, double acc_bound, const double *host_weights, int radius,
+                                       double p_scale, double p_bound, double dt_bound, const double *host_weights, int radius,
                                        void *staging, int64_t staging_bytes, float *iwe3, double *out12, void *scratch,
                                        int64_t scratch_bytes, void *stream);
 

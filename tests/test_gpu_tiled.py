@@ -236,6 +236,37 @@ def test_iwe_hot_tiles(E):
         close(iwe, ri); close(diwe, rd)
 
 
+@pytest.mark.parametrize("fixed", ["32", "64", "0"])
+def test_iwe_accumulator_modes_and_hot_pixel_drain(E, monkeypatch, fixed):
+    """The three LDS accumulator modes of the tiled IWE kernel (packed 32-bit pairs, 64-bit fixed point, float64) against
+    the oracle -- on uniform events and on a scene whose events all carry the same sign and pile up on a few pixels, so
+    that the packed fields pass 2^30 again and again and are drained into the image (k_iwe_tiled, add_pair)."""
+    monkeypatch.setenv("EVK_IWE_FIXED", fixed)
+    H, W, n = 180, 240, 400_000
+    x, y, t, p = _events(77, n, H, W, real=True)
+    rng = np.random.default_rng(8)
+    hot = rng.random(n) < 0.9
+    x[hot] = (100.25 + 1.5 * rng.random(hot.sum())).astype(np.float32)
+    y[hot] = (60.5 + 1.5 * rng.random(hot.sum())).astype(np.float32)
+    p_same = np.abs(p) * np.float32(3.0)                  # every event adds with the same sign: sums of ~1e5 per pixel
+    for pol, prm in ((p_same, np.array([0., 0.])), (p_same, np.array([12., -7.])), (p, np.array([30., -20.]))):
+        ri, rd = R.get_iwe(prm, f64(x), f64(y), f64(t), f64(pol), R.linvel_warp(), (H, W), compute_gradient=True,
+                           sensor_size=(H, W), accum="f64")
+        iwe, diwe = E.get_iwe(prm, x, y, t, pol, E.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W))
+        close(iwe, ri); close(diwe, rd)
+    # three flows in one pass (the numeric-gradient path) on the same hot scene
+    obj, robj = E.variance_objective(), R.variance_objective()
+    obj.sensor_size = robj.sensor_size = (H, W)
+    robj.accum = "f64"
+    prm = np.array([12., -7.])
+    g = obj.evaluate_numeric_gradient(prm, x, y, t, p_same, E.linvel_warp(), (H, W), 1.0)
+    d = [f64(a) for a in (x, y, t, p_same)]
+    f0 = float(robj.evaluate_function(prm, *d, R.linvel_warp(), (H, W), 1.0))
+    fr = [float(robj.evaluate_function(prm + e, *d, R.linvel_warp(), (H, W), 1.0)) for e in (np.array([1., 0.]), np.array([0., 1.]))]
+    gr = np.array([fr[0] - f0, fr[1] - f0])
+    assert np.abs(g - gr).max() <= 2e-5 * abs(f0), (g, gr, f0)   # differences of two values each good to 1e-5
+
+
 def test_batch3_numeric_gradient_matches_single_evaluations(E, golden):
     """f(v), f(v+e1), f(v+e2) from ONE pass over the events == three separate evaluations; the batched
     forward-difference gradient == the one assembled from separate evaluations."""

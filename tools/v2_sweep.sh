@@ -2,8 +2,10 @@
 mkdir -p gpurun_out
 out=gpurun_out/v2_sweep.txt
 : > $out
-for st in 0 1 2 3 4 6; do
-    echo "STAGGER=$st" >> $out
-    EVK_V2_STAGGER=$st timeout 300 python tools/v2_sweep.py --big --v2only >> $out 2>&1
+for l in "" ${LIBS}; do
+  for part in ${PARTS:-512x32 1024x16}; do
+    lp=""; [ -n "$l" ] && lp=$PWD/tools/ablate/$l
+    EVK_LIB_PATH=$lp EVK_V2_PART=$part timeout 300 python tools/v2_sweep.py --big --v2only ${CHECK} >> $out 2>&1
+  done
 done
 grep -v amdgpu.ids $out
