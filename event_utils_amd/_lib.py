@@ -44,14 +44,14 @@ SIGNATURES = {
     "evk_objective_variance_grad_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_cmax_variance_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                     c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, c_double, P, c_int,
-                                    c_uint32, P, c_int64, P, P, P, c_int64, P],
+                                    c_uint32, P, c_int64, P, P, P, c_int64, P, c_int, P, P],
     "evk_iwe_linvel_tiled_batch3_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                         c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
                                         c_double, P, c_int64, P, P],
     "evk_objective_variance_planes_f32": [P, c_int, c_int, c_int, P, c_int, P, P, c_int64, P],
     "evk_cmax_variance_batch3_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                            c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
-                                           c_double, P, c_int, P, c_int64, P, P, P, c_int64, P],
+                                           c_double, P, c_int, P, c_int64, P, P, P, c_int64, P, c_int, P, P],
     "evk_objective_stats_f32": [P, c_int, c_int, P, c_int, c_double, c_double, P, P, c_int64, P],
     "evk_objective_variance_fg_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_objective_gradsums_f32": [P, P, c_int, c_int, P, c_int, c_uint32, c_int, c_double, P, P, c_int64, P],

@@ -228,10 +228,11 @@ class objective_function(ABC):
         w, radius = _blur_kernel(blur_sigma)
         buf = tiled._buf("iwe_buf", (3 if grad else 1) * ch * cw * 4, dev)
         out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+        res = np.empty(4, dtype=np.float64)      # filled by the call itself (it synchronises the stream)
         ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
                                  float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
-                                 impl=self.impl)
-        return out.cpu().numpy() if ok else None
+                                 impl=self.impl, host_out=res)
+        return res if ok else None
 
     def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):
         fused = uses_fused_linvel(warpfunc)
@@ -296,10 +297,10 @@ class variance_objective(objective_function):
         buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
         scratch, nbytes = D.reduce_scratch(dev)
 
-        def launch(trio, out12, img_size):
+        def launch(trio, out12, img_size, host_out=None):
             return tiled.cmax_variance_batch3(ev, float(t_ref), [float(q[0]) for q in trio], [float(q[1]) for q in trio],
                                               float(img_size[1]), float(img_size[0]), ch, cw, flags, w, radius, buf,
-                                              out12, scratch, nbytes, impl=self.impl)
+                                              out12, scratch, nbytes, impl=self.impl, host_out=host_out)
         return ev, float(t_ref), launch
 
     def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
@@ -320,8 +321,9 @@ class variance_objective(objective_function):
         setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur_sigma) if len(x0) == 2 else None
         if setup is not None:
             out = D.out4(setup[0].device, 12)
-            if setup[2](pts, out, img_size):
-                res = out.cpu().numpy().reshape(3, 4)
+            res = np.empty(12, dtype=np.float64)
+            if setup[2](pts, out, img_size, res):
+                res = res.reshape(3, 4)
                 fs = [np.float32(-res[k, 1]) for k in range(3)]
         if fs is None:
             fs = [self.evaluate_function(q, xs, ys, ts, ps, warpfunc, img_size, blur_sigma) for q in pts]

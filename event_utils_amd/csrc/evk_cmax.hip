@@ -1,7 +1,33 @@
-// One-call objective evaluation: memset -> tiled IWE (+dIWE) -> gather -> fused blur + reductions -> finalise, all
-// enqueued back to back from C so that the host (Python) pays for one call instead of four and the GPU never waits
-// for the interpreter between the kernels of one evaluation.
+// One-call objective evaluation: tiled IWE (+dIWE) -> gather -> fused blur + reductions -> finalise, all enqueued back
+// to back from C so that the host (Python) pays for one call and the GPU never waits for the interpreter between the
+// kernels of one evaluation.  With a spill pair (two zeroed (planes, ch, cw) images the caller keeps between calls) there is
+// no memset: the rare out-of-window atomics of k_iwe_tiled go to spill[parity], the gather WRITES spill + windows and
+// zeroes what the previous call left in spill[parity ^ 1].  host_out (4 / 12 doubles, host memory) makes the call
+// synchronous: the results are copied through a pinned slot and the stream is synchronised inside the call.
+// (Fusing the gather into the post-pass as well -- one kernel gathering a 40x40 halo patch per 32x32 tile -- measured
+// 35.6 us against 8.1 + 9.2 us for the two kernels at 640x480: every halo pixel is gathered 1.6 times from a window
+// list five times longer.  Removed.)
 #include "evk_common.h"
+
+int evk_iwe_tiled_spill(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                        int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
+                        const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                        uint32_t flags, double p_scale, double p_bound, double dt_bound, void *staging, int64_t staging_bytes,
+                        float *iwe_buf, const float *spill, float *spill_clean, void *stream);
+
+static int fetch_results(const double *out, int count, double *host_out, void *stream) {
+    if (!host_out) return EVK_OK;
+    static thread_local double *pinned = nullptr;
+    if (!pinned && hipHostMalloc((void **)&pinned, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        pinned = nullptr;
+        return EVK_EINVAL;
+    }
+    hipError_t e = hipMemcpyAsync(pinned, out, count * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < count; ++k) host_out[k] = pinned[k];
+    return EVK_OK;
+}
 
 extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_start, int64_t n, int dom_h, int dom_w,
                                            int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first,
@@ -9,25 +35,37 @@ extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t 
                                            int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale,
                                            double p_bound, double dt_bound, const double *host_weights, int radius, uint32_t post_flags, void *staging,
                                            int64_t staging_bytes, float *iwe_buf, double *out, void *scratch,
-                                           int64_t scratch_bytes, void *stream) {
+                                           int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
+                                           void *stream) {
     if (!iwe_buf || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
     const bool grad = iwe_flags & EVK_IWE_GRADIENT;
     const size_t plane = (size_t)canvas_h * canvas_w;
-    hipError_t e = hipMemsetAsync(iwe_buf, 0, (grad ? 3 : 1) * plane * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    int rc;
     float *diwe = grad ? iwe_buf + plane : nullptr;
-    int rc = evk_iwe_linvel_tiled_f32(records, bucket_start, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h,
+    if (spill_pair) {
+        const size_t img = (grad ? 3 : 1) * plane;
+        rc = evk_iwe_tiled_spill(grad ? 1 : 0, records, bucket_start, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h,
+                                 t_first, t_ref, &vx, &vy, bounds_w, bounds_h, canvas_h, canvas_w, iwe_flags, p_scale, p_bound,
+                                 dt_bound, staging, staging_bytes, iwe_buf, spill_pair + (parity & 1) * img,
+                                 spill_pair + ((parity & 1) ^ 1) * img, stream);
+    } else {
+        hipError_t e = hipMemsetAsync(iwe_buf, 0, (grad ? 3 : 1) * plane * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        rc = evk_iwe_linvel_tiled_f32(records, bucket_start, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h,
                                       t_first, t_ref, vx, vy, bounds_w, bounds_h, canvas_h, canvas_w, iwe_flags, p_scale,
                                       p_bound, dt_bound, staging, staging_bytes, iwe_buf, diwe, stream);
+    }
     if (rc != EVK_OK) return rc;
     if (grad && (post_flags & EVK_POST_VALUE))
-        return evk_objective_variance_fg_f32(iwe_buf, diwe, canvas_h, canvas_w, host_weights, radius,
-                                             post_flags & ~EVK_POST_VALUE, out, scratch, scratch_bytes, stream);
-    if (grad)
-        return evk_objective_variance_grad_f32(iwe_buf, diwe, canvas_h, canvas_w, host_weights, radius, post_flags, out,
-                                               scratch, scratch_bytes, stream);
-    return evk_objective_variance_f32(iwe_buf, canvas_h, canvas_w, host_weights, radius, out, scratch, scratch_bytes,
-                                      stream);
+        rc = evk_objective_variance_fg_f32(iwe_buf, diwe, canvas_h, canvas_w, host_weights, radius,
+                                           post_flags & ~EVK_POST_VALUE, out, scratch, scratch_bytes, stream);
+    else if (grad)
+        rc = evk_objective_variance_grad_f32(iwe_buf, diwe, canvas_h, canvas_w, host_weights, radius, post_flags, out,
+                                             scratch, scratch_bytes, stream);
+    else
+        rc = evk_objective_variance_f32(iwe_buf, canvas_h, canvas_w, host_weights, radius, out, scratch, scratch_bytes,
+                                        stream);
+    return rc != EVK_OK ? rc : fetch_results(out, 4, host_out, stream);
 }
 
 extern "C" int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n,
@@ -37,15 +75,25 @@ extern "C" int evk_cmax_variance_batch3_tiled_f32(const float *records, const ui
                                                   int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale,
                                                   double p_bound, double dt_bound, const double *host_weights, int radius, void *staging,
                                                   int64_t staging_bytes, float *iwe3, double *out12, void *scratch,
-                                                  int64_t scratch_bytes, void *stream) {
-    if (!iwe3 || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
+                                                  int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
+                                                  void *stream) {
+    if (!iwe3 || canvas_h <= 1 || canvas_w <= 1 || !host_vx || !host_vy || (iwe_flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
     const size_t plane = (size_t)canvas_h * canvas_w;
-    hipError_t e = hipMemsetAsync(iwe3, 0, 3 * plane * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    int rc = evk_iwe_linvel_tiled_batch3_f32(records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w,
+    int rc;
+    if (spill_pair) {
+        rc = evk_iwe_tiled_spill(2, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
+                                 t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, iwe_flags, p_scale, p_bound,
+                                 dt_bound, staging, staging_bytes, iwe3, spill_pair + (parity & 1) * 3 * plane,
+                                 spill_pair + ((parity & 1) ^ 1) * 3 * plane, stream);
+    } else {
+        hipError_t e = hipMemsetAsync(iwe3, 0, 3 * plane * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        rc = evk_iwe_linvel_tiled_batch3_f32(records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w,
                                              win_h, t_first, t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h,
                                              canvas_w, iwe_flags, p_scale, p_bound, dt_bound, staging, staging_bytes, iwe3, stream);
+    }
     if (rc != EVK_OK) return rc;
-    return evk_objective_variance_planes_f32(iwe3, 3, canvas_h, canvas_w, host_weights, radius, out12, scratch,
-                                             scratch_bytes, stream);
+    rc = evk_objective_variance_planes_f32(iwe3, 3, canvas_h, canvas_w, host_weights, radius, out12, scratch,
+                                           scratch_bytes, stream);
+    return rc != EVK_OK ? rc : fetch_results(out12, 12, host_out, stream);
 }

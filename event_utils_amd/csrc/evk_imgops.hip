@@ -1,16 +1,9 @@
 // Image-sized kernels of the contrast-maximisation objective: separable Gaussian blur with scipy's 'reflect'
 // boundary (objectives.py:233,253) and the variance / gradient reductions (objectives.py:234,256-264).
 // The images are <= a few MB (L2 / MALL resident); these kernels are latency-, not bandwidth-, bound.
-#include "evk_common.h"
+#include "evk_img.h"
 
 namespace evk {
-
-#define EVK_MAX_RADIUS 32
-
-struct BlurWeights {
-    double w[2 * EVK_MAX_RADIUS + 1];
-    int radius;
-};
 
 // One axis of scipy.ndimage.correlate1d(mode='reflect') on an array viewed as (outer, len, inner), filtered along
 // `len`.  Evaluated in float64 with the symmetric-kernel summation order of scipy's NI_Correlate1D
@@ -42,32 +35,6 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_blur_axis(const float *__restrict
 // deterministic two-stage reductions (per-block partials in fixed order, then one block)
 // ---------------------------------------------------------------------------------------------------------
 
-#define EVK_REDUCE_MAX_BLOCKS 4096
-#define EVK_REDUCE_K 7
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-template <int K>
-__device__ __forceinline__ void block_sum(double (&acc)[K], double *partial_out) {
-    __shared__ double lds[EVK_BLOCK / EVK_WAVE][K];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane == 0) lds[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < K) {
-        double s = 0.0;
-        for (int w = 0; w < EVK_BLOCK / EVK_WAVE; ++w) s += lds[w][threadIdx.x];
-        partial_out[threadIdx.x] = s;
-    }
-}
-
 // MODE 0: sum(a), sum(a^2).   MODE 1: sum(a), sum(d0), sum(d1), sum(a*d0), sum(a*d1)
 template <int MODE>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_partial(const float *__restrict__ a,
@@ -91,95 +58,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_partial(const float *__res
     block_sum<EVK_REDUCE_K>(acc, partials + (int64_t)blockIdx.x * EVK_REDUCE_K);
 }
 
-// WIDE: additionally out[4..7] = the raw sums tot[1..4] (generic objectives); stride of `out` per plane stays 4 or 8.
-template <int MODE, bool WIDE = false>
-__global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
-                                                            int64_t n, double *__restrict__ out) {
-    double acc[EVK_REDUCE_K] = {};
-    partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
-    out += (WIDE ? 8 : 4) * blockIdx.x;
-    for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
-#pragma unroll
-        for (int k = 0; k < EVK_REDUCE_K; ++k) acc[k] += partials[(int64_t)b * EVK_REDUCE_K + k];
-    __shared__ double tot[EVK_REDUCE_K];
-    block_sum<EVK_REDUCE_K>(acc, tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double inv = 1.0 / (double)n;
-        const double mean = tot[0] * inv;
-        if constexpr (MODE == 0) {
-            out[0] = mean;
-            out[1] = tot[1] * inv - mean * mean;
-            out[2] = tot[0];
-            out[3] = tot[1];
-        } else {
-            // mean(2*(a-mean)*d_i) = 2/n * (sum(a*d_i) - mean*sum(d_i))
-            out[0] = 2.0 * inv * (tot[3] - mean * tot[1]);
-            out[1] = 2.0 * inv * (tot[4] - mean * tot[2]);
-            out[2] = mean;
-            out[3] = tot[0];
-            if constexpr (MODE == 3) {  // value + gradient: [g0, g1, mean v, var v] of the blurred image v
-                const double mv = tot[5] * inv;
-                out[2] = mv;
-                out[3] = tot[6] * inv - mv * mv;
-            }
-        }
-        if constexpr (WIDE && MODE == 0) {  // stats: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
-            out[4] = tot[2], out[5] = tot[3], out[6] = tot[4], out[7] = 0.0;
-        }
-        if constexpr (WIDE && MODE == 1) {  // gradient sums: [.., .., mean, sum g, sum d0, sum d1, sum g d0, sum g d1]
-            out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
 // fused objective post-pass: [channel mix ->] blur axis 0 -> blur axis 1 -> per-block partial sums, one launch.
 // Arithmetic and summation order are those of k_blur_axis (bit-identical blurred values); the blurred images are
 // never written to memory.  MODE 0: variance of blur(iwe).  MODE 1: gradient sums with blur3d(diwe).
 // ---------------------------------------------------------------------------------------------------------
-#define EVK_POST_T 32
-#define EVK_POST_MIX 1u       // scipy's 3-D gaussian_filter on (2, H, W): also filter across the channel axis (Q4)
-#define EVK_POST_BLUR_IWE 2u  // gradient: use the blurred IWE (reference_exact=False); default is the raw IWE (Q5)
-
-__device__ __forceinline__ int reflect_idx(int q, int len) {
-    const int period = 2 * len;
-    int m = q % period;
-    if (m < 0) m += period;
-    return m >= len ? period - 1 - m : m;
-}
-
-// Blurs one plane over this block's 32x32 output tile; LOAD(gy, gx) returns the (already reflected) source pixel.
-template <typename LOAD>
-__device__ __forceinline__ void blur_tile(float *patch, float *inter, const BlurWeights &bw, int y0, int x0, int ch,
-                                          int cw, LOAD load, float (&res)[4]) {
-    const int r = bw.radius, PW = EVK_POST_T + 2 * r, PH = PW;
-    for (int i = threadIdx.x; i < PH * PW; i += EVK_BLOCK) {
-        const int py = i / PW, px = i - py * PW;
-        patch[i] = load(reflect_idx(y0 - r + py, ch), reflect_idx(x0 - r + px, cw));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < EVK_POST_T * PW; i += EVK_BLOCK) {  // axis 0 (rows)
-        const int y = i / PW, xx = i - y * PW;
-        const float *col = patch + (y + r) * PW + xx;
-        double acc = (double)col[0] * bw.w[r];
-        for (int j = r; j >= 1; --j) acc += ((double)col[-j * PW] + (double)col[j * PW]) * bw.w[r - j];
-        inter[i] = (float)acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {  // axis 1 (columns)
-        const int o = threadIdx.x + k * EVK_BLOCK;
-        const int y = o / EVK_POST_T, x = o - y * EVK_POST_T;
-        const float *row = inter + y * PW + x + r;
-        double acc = (double)row[0] * bw.w[r];
-        for (int j = r; j >= 1; --j) acc += ((double)row[-j] + (double)row[j]) * bw.w[r - j];
-        res[k] = (float)acc;
-    }
-    __syncthreads();
-}
-
 // weight function g(a) of the generic gradient sums  sum_pix g(a) * blur(d_iwe)[i]
 #define EVK_G_IDENT 0   // a                 (variance, sos)
 #define EVK_G_EXP 1     // exp(a)            (soe)

@@ -9,6 +9,7 @@
 //   3. the tile is flushed with plain, coalesced stores: voxel tiles are owned exclusively; IWE windows (tile + halo,
 //      shifted by the flow) go to a staging area and a gather kernel sums the (<= a few) windows covering each pixel.
 // No global atomics remain on the hot path (only the rare event that lands outside its block's window uses one).
+#include "evk_img.h"
 #include "evk_tiles.h"
 
 namespace evk {
@@ -703,7 +704,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
                                                           const uint32_t *__restrict__ index, TileGrid g, int slices,
                                                           int win_w, int win_h, int ch, int cw, int sx_lo, int sx_hi,
                                                           int sy_lo, int sy_hi, float *__restrict__ iwe,
-                                                          float *__restrict__ diwe) {
+                                                          float *__restrict__ diwe, const float *__restrict__ spill,
+                                                          float *__restrict__ spill_clean) {
     constexpr int PLANES = GRAD ? 3 : 1;
     __shared__ int list_w[EVK_GATHER_CAP], list_x[EVK_GATHER_CAP], list_y[EVK_GATHER_CAP];
     __shared__ int count;
@@ -778,10 +780,21 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
     }
     if (inside) {
         const int64_t pix = (int64_t)Y * cw + X;
-        iwe[pix] += s0;
-        if constexpr (GRAD) {
-            diwe[pix] += s1;
-            diwe[plane + pix] += s2;
+        if (spill) {  // out = spill + windows: the output needs no memset; the OTHER spill image is zeroed for the next call
+            iwe[pix] = spill[pix] + s0;
+            if (spill_clean[pix] != 0.0f) spill_clean[pix] = 0.0f;
+            if constexpr (GRAD) {
+                diwe[pix] = spill[plane + pix] + s1;
+                diwe[plane + pix] = spill[2 * plane + pix] + s2;
+                if (spill_clean[plane + pix] != 0.0f) spill_clean[plane + pix] = 0.0f;
+                if (spill_clean[2 * plane + pix] != 0.0f) spill_clean[2 * plane + pix] = 0.0f;
+            }
+        } else {
+            iwe[pix] += s0;
+            if constexpr (GRAD) {
+                diwe[pix] += s1;
+                diwe[plane + pix] += s2;
+            }
         }
     }
 }
@@ -949,7 +962,8 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
                             int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
                             const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h,
                             int canvas_w, uint32_t flags, double p_scale, double p_bound, double dt_bound, void *staging,
-                            int64_t staging_bytes, float *iwe, float *diwe, void *stream) {
+                            int64_t staging_bytes, float *iwe, float *diwe, void *stream, const float *spill = nullptr,
+                            float *spill_clean = nullptr) {
     TileGrid g;
     if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || !records || !bucket_index || !iwe || !staging)
         return EVK_EINVAL;
@@ -1013,6 +1027,13 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     hipStream_t s = (hipStream_t)stream;
     const int ggrid = ((canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX) * ((canvas_h + EVK_GATHER_PY - 1) / EVK_GATHER_PY);
     const float4 *rec = (const float4 *)records;
+    // spill pair: the kernel's global atomics (events outside their window) go to `spill` and the gather WRITES
+    // out = spill + windows (no memset of the output), zeroing what the previous call left in `spill_clean`
+    float *out_iwe = iwe, *out_diwe = diwe;
+    if (spill) {
+        iwe = const_cast<float *>(spill);
+        diwe = iwe + (size_t)canvas_h * canvas_w;
+    }
 #define EVK_IWE_LAUNCH(M)                                                                                          \
     do {                                                                                                           \
         if (pack32) k_iwe_tiled<M, 2><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
@@ -1022,12 +1043,14 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     if (mode == 0) {
         EVK_IWE_LAUNCH(0);
         k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
-                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
+                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
+                                                       spill, spill_clean);
     } else {
         if (mode == 1) EVK_IWE_LAUNCH(1);
         else EVK_IWE_LAUNCH(2);
         k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
-                                                      canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, iwe, diwe);
+                                                      canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
+                                                      spill, spill_clean);
     }
 #undef EVK_IWE_LAUNCH
     return launch_status();
@@ -1054,4 +1077,15 @@ extern "C" int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint3
     return launch_iwe_tiled(2, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
                             t_ref, host_vx, host_vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, p_bound, dt_bound,
                             staging, staging_bytes, iwe3, iwe3 + (size_t)canvas_h * canvas_w, stream);
+}
+
+// evk_cmax.hip: the tiled IWE with a spill pair (no memset; see launch_iwe_tiled)
+int evk_iwe_tiled_spill(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                        int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,
+                        const double *vx, const double *vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
+                        uint32_t flags, double p_scale, double p_bound, double dt_bound, void *staging, int64_t staging_bytes,
+                        float *iwe_buf, const float *spill, float *spill_clean, void *stream) {
+    return launch_iwe_tiled(mode, records, bucket_index, n, dom_h, dom_w, tw_log2, th_log2, slices, win_w, win_h, t_first,
+                            t_ref, vx, vy, bounds_w, bounds_h, canvas_h, canvas_w, flags, p_scale, p_bound, dt_bound, staging,
+                            staging_bytes, iwe_buf, iwe_buf + (size_t)canvas_h * canvas_w, stream, spill, spill_clean);
 }

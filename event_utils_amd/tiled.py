@@ -343,29 +343,53 @@ def iwe_linvel(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, iwe, diwe, 
               flags, float(ev.p_scale), D.ptr(iwe), D.ptr(diwe), D.stream())
 
 
+_spill = {}
+
+
+def _spill_pair(device, planes, ch, cw):
+    """The pair of spill images of the fused evaluation (include/evk.h, evk_cmax_variance_tiled_f32): zeroed once, kept
+    per stream and image shape, with the parity that alternates from call to call -> (tensor, parity for THIS call)."""
+    import torch
+    key = (device.index, D.stream_id(device), planes, ch, cw)
+    st = _spill.get(key)
+    if st is None:
+        st = _spill[key] = [torch.zeros(2 * planes * ch * cw, dtype=torch.float32, device=device), 0]
+    st[1] ^= 1
+    return st[0], st[1]
+
+
+def spill_enabled():
+    """EVK_CMAX_SPILL=0 restores the memset of the IWE buffer ahead of every evaluation (round 1)."""
+    return os.environ.get("EVK_CMAX_SPILL", "1") != "0"
+
+
 def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights, radius, post_flags, buf, out, scratch,
-                  scratch_bytes, impl=None):
+                  scratch_bytes, impl=None, host_out=None):
     """One-call objective evaluation (evk_cmax_variance_tiled_f32) into `out` (4 doubles); returns False when the
-    tiled plan is not applicable (the caller then composes the direct kernels)."""
+    tiled plan is not applicable (the caller then composes the direct kernels).  host_out = numpy float64[4]: the call
+    also brings the results to the host and synchronises itself."""
     plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
     if plan is None:
         return False
+    spill, parity = _spill_pair(buf.device, 3 if flags & _lib.EVK_IWE_GRADIENT else 1, ch, cw) if spill_enabled() \
+        else (None, 0)
     _lib.call("evk_cmax_variance_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
               post_flags, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
-              scratch_bytes, D.stream())
+              scratch_bytes, D.ptr(spill), parity, D.host_ptr(host_out) if host_out is not None else None, D.stream())
     return True
 
 
 def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags, weights, radius, buf, out12, scratch,
-                         scratch_bytes, impl=None):
+                         scratch_bytes, impl=None, host_out=None):
     """f at three nearby flows in one pass over the events (evk_cmax_variance_batch3_tiled_f32) -> out12 (3 x 4
     doubles); False when the tiled plan is not applicable."""
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
         return False
+    spill, parity = _spill_pair(buf.device, 3, ch, cw) if spill_enabled() else (None, 0)
     _lib.call("evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None,
               radius, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch),
-              scratch_bytes, D.stream())
+              scratch_bytes, D.ptr(spill), parity, D.host_ptr(host_out) if host_out is not None else None, D.stream())
     return True
 
 

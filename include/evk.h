@@ -354,13 +354,19 @@ int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index,
  * memset(iwe_buf) -> evk_iwe_linvel_tiled_f32 -> evk_objective_variance[_grad]_f32.  iwe_buf is (1, ch, cw) or, with
  * EVK_IWE_GRADIENT, (3, ch, cw) float32 = IWE followed by the two dIWE planes (left filled, un-blurred).
  * out: as evk_objective_variance_f32 / evk_objective_variance_grad_f32 / (post_flags & EVK_POST_VALUE)
- * evk_objective_variance_fg_f32. */
+ * evk_objective_variance_fg_f32.
+ * spill_pair (optional): 2 x (1 | 3, ch, cw) float32, ZEROED ONCE by the caller and kept between calls, with `parity`
+ * alternating 0 / 1 from call to call on one stream.  The evaluation then needs no memset: the rare events outside their
+ * LDS window go to spill[parity], the gather writes iwe_buf = spill[parity] + windows and zeroes what the previous call
+ * left in spill[parity ^ 1].
+ * host_out (optional, HOST pointer to 4 doubles): the call copies `out` there and synchronises the stream itself. */
 int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                                 int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
                                 double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
                                 uint32_t iwe_flags, double p_scale, double p_bound, double dt_bound, const double *host_weights,
                                 int radius, uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf,
-                                double *out, void *scratch, int64_t scratch_bytes, void *stream);
+                                double *out, void *scratch, int64_t scratch_bytes, float *spill_pair, int parity,
+                                double *host_out, void *stream);
 
 /* ---- batched evaluation: three NEARBY flows in one pass over the events ----------------
  * The reference's default optimiser path (numeric_grads=True, events_cmax.py:343) lets scipy estimate the gradient by
@@ -384,7 +390,8 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        double bounds_w, double bounds_h, int canvas_h, int canvas_w, uint32_t iwe_flags,
                                        double p_scale, double p_bound, double dt_bound, const double *host_weights, int radius,
                                        void *staging, int64_t staging_bytes, float *iwe3, double *out12, void *scratch,
-                                       int64_t scratch_bytes, void *stream);
+                                       int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
+                                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,9 @@ wts, radius = _blur_kernel(1.0)
 buf = tiled._buf("iwe_buf", ch * cw * 4, dev); out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
 def launch():
     return tiled.cmax_variance(ev, 0.1, 30.0, -20.0, float(W), float(H), ch, cw, 0, wts, radius, 0, buf, out, scratch, nbytes)
+host = np.empty(4)
+def launch_sync():
+    return tiled.cmax_variance(ev, 0.1, 30.0, -20.0, float(W), float(H), ch, cw, 0, wts, radius, 0, buf, out, scratch, nbytes, host_out=host)
 N = 200
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(N): launch()
@@ -35,3 +38,11 @@ print("evaluate_function: %.1f us" % ((time.perf_counter() - t0) / N * 1e6))
 t0 = time.perf_counter()
 for _ in range(N): tiled.iwe_plan(ev, 0.1, 30.0, -20.0, float(W), float(H), ch, cw, 0)
 print("iwe_plan only (host): %.1f us" % ((time.perf_counter() - t0) / N * 1e6))
+t0 = time.perf_counter()
+for _ in range(N): launch_sync()
+print("launch with host_out (self-synchronising): %.1f us" % ((time.perf_counter() - t0) / N * 1e6))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(300): obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0)
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(12)
