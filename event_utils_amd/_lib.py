@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
 EVK_IWE_PACK32 = 8
-EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE = 1, 2, 4
+EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE, EVK_POST_NONE = 1, 2, 4, 8
 EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
 EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
 
@@ -65,6 +65,11 @@ SIGNATURES = {
                        P, P],
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
                               c_float, c_int, c_int, P, P, P, c_int64, P, P],
+    "evk_comm_unique_id": [P],
+    "evk_comm_init": [P, c_int, c_int, P],
+    "evk_comm_destroy": [P],
+    "evk_allreduce_f32": [P, c_int64, P, P],
+    "evk_allreduce_i32": [P, c_int64, P, P],
     "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double, c_double, P, c_int64,
                                  P, P, P],
@@ -78,6 +83,7 @@ _SPECIAL = {
     "evk_voxel_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
     "evk_bucket_index_len": ([c_int, c_int64], c_int64),
     "evk_bucket_max_items": ([c_int, c_int64], c_int),
+    "evk_comm_unique_id_bytes": ([], c_int),
     "evk_voxel2_max_tiles": ([], c_int),
     "evk_voxel2_index_len": ([c_int, c_int64], c_int64),
     "evk_voxel2_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),

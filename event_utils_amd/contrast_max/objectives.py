@@ -85,8 +85,8 @@ def iwe_device(params, ev, img_size, compute_gradient=False, use_polarity=True, 
         tiled.iwe_linvel(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
                          float(img_size[0]), ch, cw, flags, iwe, diwe, impl=impl)
     if distributed or process_group is not None:
-        import torch.distributed as dist
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+        from .. import distributed as DD
+        DD.all_reduce_sum_(buf, process_group, force=True)
     return iwe, diwe
 
 
@@ -214,11 +214,15 @@ class objective_function(ABC):
 
     def _one_call(self, params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, grad, post_flags):
         """Whole evaluation in ONE library call (tiled.cmax_variance) -> 4 doubles on the host, or None when that
-        path does not apply (plugin warp, event-sharded run, direct-kernel fallback)."""
-        if not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None:
+        path does not apply (plugin warp, direct-kernel fallback).
+        Event-sharded run (distributed.shard_objective): the same call stops after the gather (EVK_POST_NONE), the
+        persistent (1 | 3, H+1, W+1) buffer is all-reduced in place over the ranks, then one fused blur + reduction call
+        finishes -- no allocation per evaluation, and every rank holds the same scalars."""
+        if not uses_fused_linvel(warpfunc):
             return None
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
-        if len(ev) == 0:
+        sharded = self.distributed or self.process_group is not None
+        if len(ev) == 0 and not sharded:
             return None
         dev = ev.device
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
@@ -226,13 +230,42 @@ class objective_function(ABC):
         flags = (0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if grad else 0)
         t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
         w, radius = _blur_kernel(blur_sigma)
-        buf = tiled._buf("iwe_buf", (3 if grad else 1) * ch * cw * 4, dev)
+        planes = 3 if grad else 1
+        buf = tiled._buf("iwe_buf", planes * ch * cw * 4, dev)
         out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
         res = np.empty(4, dtype=np.float64)      # filled by the call itself (it synchronises the stream)
-        ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
-                                 float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
-                                 impl=self.impl, host_out=res)
-        return res if ok else None
+        if not sharded:
+            ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
+                                     float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
+                                     impl=self.impl, host_out=res)
+            return res if ok else None
+        from .. import distributed as DD
+        img = buf[:planes * ch * cw * 4].view(torch.float32).view(planes, ch, cw)
+
+        def local_iwe():
+            ok = len(ev) > 0 and tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]),
+                                                     float(img_size[1]), float(img_size[0]), ch, cw, flags, w, radius,
+                                                     _lib.EVK_POST_NONE, buf, out, scratch, nbytes, impl=self.impl)
+            if not ok:  # empty shard, or the direct kernels had to take over on this rank: same buffer, same collective
+                img.zero_()
+                if len(ev):
+                    tiled.iwe_linvel(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
+                                     float(img_size[0]), ch, cw, flags, img[0], img[1:3] if grad else None, impl=self.impl)
+            return img
+
+        def finish(img):
+            wp = D.host_ptr(w) if w is not None else None
+            if grad and (post_flags & _lib.EVK_POST_VALUE):
+                _lib.call("evk_objective_variance_fg_f32", D.ptr(img), D.ptr(img[1:]), ch, cw, wp, radius,
+                          post_flags & ~_lib.EVK_POST_VALUE, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+            elif grad:
+                _lib.call("evk_objective_variance_grad_f32", D.ptr(img), D.ptr(img[1:]), ch, cw, wp, radius, post_flags,
+                          D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+            else:
+                _lib.call("evk_objective_variance_f32", D.ptr(img), ch, cw, wp, radius, D.ptr(out), D.ptr(scratch),
+                          nbytes, D.stream())
+            return out.cpu().numpy()
+        return DD.sharded_evaluate(local_iwe, finish, self.process_group)
 
     def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):
         fused = uses_fused_linvel(warpfunc)

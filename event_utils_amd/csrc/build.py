@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libevk.so")
 # -ffp-contract=off : per-event values must round exactly like the reference's separate numpy/torch ops
 # -munsafe-fp-atomics: hardware float atomics (outputs live in ordinary device memory)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-ldl"]
 
 
 def sources():

@@ -55,7 +55,7 @@ extern "C" int evk_cmax_variance_tiled_f32(const float *records, const uint32_t 
                                       t_first, t_ref, vx, vy, bounds_w, bounds_h, canvas_h, canvas_w, iwe_flags, p_scale,
                                       p_bound, dt_bound, staging, staging_bytes, iwe_buf, diwe, stream);
     }
-    if (rc != EVK_OK) return rc;
+    if (rc != EVK_OK || (post_flags & EVK_POST_NONE)) return rc;
     if (grad && (post_flags & EVK_POST_VALUE))
         rc = evk_objective_variance_fg_f32(iwe_buf, diwe, canvas_h, canvas_w, host_weights, radius,
                                            post_flags & ~EVK_POST_VALUE, out, scratch, scratch_bytes, stream);

@@ -546,6 +546,7 @@ extern "C" const char *evk_error_string(int code) {
         case EVK_EINVAL: return "invalid argument";
         case EVK_ESCRATCH: return "scratch buffer too small";
         case EVK_EALIGN: return "pointer not sufficiently aligned";
+        case EVK_ECOMM: return "RCCL unavailable or collective failed";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown evk error";
     }
 }

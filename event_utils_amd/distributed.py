@@ -8,6 +8,10 @@ the output grid (18.4 MB for a 5x720x1280 voxel grid, 11 MB for IWE+dIWE) -- not
 The two scalars every rank must agree on BEFORE its pass (ts[0], ts[-1] of the whole stream: t_norm of the voxel grid,
 reference time of the warp) are exchanged once with two scalar all-reduces.
 """
+import ctypes
+import os
+
+import numpy as np
 import torch
 
 
@@ -28,49 +32,171 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _collective_device(group=None):
+    """Tensors handed to a collective must live where the backend works: the GPU for nccl (= RCCL), the host for gloo."""
+    dist = _dist()
+    if dist.get_backend(group) == "nccl":
+        from . import _device as D
+        return D.require_gpu()
+    return torch.device("cpu")
+
+
+# ---- the C-ABI collective (include/evk.h: evk_comm_*, evk_allreduce_*) -------------------------------------------------
+_comms = {}
+
+
+def collective():
+    """'torch' (default): torch.distributed's all_reduce (backend nccl = RCCL).  'evk': libevk.so's own RCCL binding,
+    the entry points a caller without torch uses (EVK_COLLECTIVE=evk); torch.distributed then only ships the 128-byte
+    communicator id to the ranks once."""
+    return os.environ.get("EVK_COLLECTIVE", "torch")
+
+
+def evk_comm(group=None):
+    """libevk communicator of `group` (created on first use: rank 0 makes the id, it is broadcast, every rank joins)."""
+    from . import _lib
+    key = id(group) if group is not None else 0
+    c = _comms.get(key)
+    if c is None:
+        dist = _dist()
+        L = _lib.lib()
+        nbytes = L.evk_comm_unique_id_bytes()
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            rank, world = 0, 1
+        box = [None]
+        if rank == 0:
+            raw = ctypes.create_string_buffer(nbytes)
+            _lib.call("evk_comm_unique_id", raw)
+            box[0] = raw.raw
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        handle = ctypes.c_void_p()
+        _lib.call("evk_comm_init", ctypes.create_string_buffer(box[0], nbytes), rank, world, ctypes.byref(handle))
+        c = _comms[key] = handle
+    return c
+
+
+def evk_comm_destroy(group=None):
+    from . import _lib
+    c = _comms.pop(id(group) if group is not None else 0, None)
+    if c is not None:
+        _lib.call("evk_comm_destroy", c)
+
+
 def global_time_range(t_first_local, t_last_local, group=None, device=None):
     """(min over ranks of t_first, max over ranks of t_last): the ts[0] / ts[-1] of the whole stream
-    (voxel_grid.py:133-134; objectives.py:186).  An empty shard passes (+inf, -inf)."""
+    (voxel_grid.py:133-134; objectives.py:186).  An empty shard passes (+inf, -inf).  ONE collective: MAX of
+    (-t_first, t_last)."""
     if not is_distributed(group):
         return float(t_first_local), float(t_last_local)
     dist = _dist()
-    lo = torch.tensor([float(t_first_local)], dtype=torch.float64, device=device)
-    hi = torch.tensor([float(t_last_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    return float(lo.item()), float(hi.item())
+    v = torch.tensor([-float(t_first_local), float(t_last_local)], dtype=torch.float64, device=_collective_device(group))
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    lo, hi = v.tolist()
+    return -float(lo), float(hi)
 
 
-def all_reduce_sum_(grid, group=None):
-    """In-place SUM all-reduce of an output grid (no-op for a single process)."""
-    if is_distributed(group):
-        dist = _dist()
-        dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=group)
+def all_reduce_sum_(grid, group=None, force=False):
+    """In-place SUM all-reduce of an output grid (no-op for a single process unless force=True)."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or not (force or is_distributed(group)):
+        return grid
+    if collective() == "evk" and grid.is_cuda and grid.is_contiguous() and grid.dtype in (torch.float32, torch.int32):
+        from . import _device as D
+        from . import _lib
+        fn = "evk_allreduce_f32" if grid.dtype == torch.float32 else "evk_allreduce_i32"
+        _lib.call(fn, D.ptr(grid), grid.numel(), evk_comm(group), D.stream())
+        return grid
+    dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=group)
     return grid
 
 
-def _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last):
+def _raise_everywhere(oob_state, exc_type, msg, group):
+    """A data-dependent error must surface on EVERY rank (a rank that raised alone would leave the others waiting in the
+    next collective): the per-rank counts of dropped events are summed over the ranks and all of them raise."""
+    cnt = (oob_state.counter.to(torch.int64) - oob_state.seen).reshape(1)
+    local = int(cnt.item())
+    oob_state.seen = (oob_state.seen + local) & 0xFFFFFFFF
+    total = cnt.to(_collective_device(group)) if is_distributed(group) else cnt
+    if is_distributed(group):
+        _dist().all_reduce(total, op=_dist().ReduceOp.SUM, group=group)
+    total = int(total.item())
+    if total:
+        raise exc_type("%s (%d offending events over all ranks, %d on this one)" % (msg, total, local))
+
+
+def _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob=None):
     from . import _device as D
-    from .representations.voxel_grid import _voxel_f32_device
+    from . import tiled
     dev = D.require_gpu()
+    H, W = int(sensor_size[0]), int(sensor_size[1])
     cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
     if cols[0].shape[0] == 0:
-        return torch.zeros((B, int(sensor_size[0]), int(sensor_size[1])), dtype=torch.float32, device=dev)
-    return _voxel_f32_device(*cols, B, sensor_size, t_first, t_last)
+        return torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    return tiled.voxel_f32(*cols, float(t_first), float(t_last), B, H, W, out, oob, fresh=True)
 
 
 def events_to_voxel_torch_sharded(xs, ys, ts, ps, B, sensor_size=(180, 240), group=None, local_fn=None):
     """events_to_voxel_torch over an event stream sharded across ranks: `xs, ys, ts, ps` are THIS rank's slice.
     Returns the full (B, H, W) grid on every rank.  `local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last)`
-    computes one shard's partial grid (default: the HIP kernels; the CPU tests inject the oracle)."""
+    computes one shard's partial grid (default: the HIP kernels; the CPU tests inject the oracle).  Out-of-range
+    coordinates raise IndexError on every rank, after the collectives."""
     n = len(xs)
     inf = float("inf")
     t0 = float(ts[0]) if n else inf
     t1 = float(ts[-1]) if n else -inf
-    dev = xs.device if isinstance(xs, torch.Tensor) else None
-    t_first, t_last = global_time_range(t0, t1, group, device=dev)
-    part = (local_fn or _local_voxel)(xs, ys, ts, ps, B, sensor_size, t_first, t_last)
-    return all_reduce_sum_(part, group)
+    t_first, t_last = global_time_range(t0, t1, group)
+    if local_fn is not None:
+        return all_reduce_sum_(local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last), group)
+    from . import _device as D
+    oob = D.OobCounter(D.require_gpu())
+    part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
+    out = all_reduce_sum_(part, group)
+    _raise_everywhere(oob.state, IndexError, "index out of range for voxel grid of size %s"
+                      % ((B, int(sensor_size[0]), int(sensor_size[1])),), group)
+    return out
+
+
+def events_to_image_sharded(xs, ys, ps, sensor_size=(180, 240), group=None, local_fn=None):
+    """events_to_image (nearest pixel, integer weights; image.py:28-44) over an event stream sharded across ranks: every
+    rank accumulates ITS events on the (H+1, W+1) int32 canvas, ONE int32 all-reduce sums the canvases -- integer
+    arithmetic, so the result is bit-identical to the single-process image whatever the sharding -- and the cropped
+    float64 (H, W) image is returned on every rank.  `local_fn(xs, ys, ps, canvas_shape) -> int32 tensor` replaces the
+    HIP kernel in the CPU tests."""
+    xs, ys, ps = np.asarray(xs), np.asarray(ys), np.asarray(ps)
+    if not (np.issubdtype(xs.dtype, np.integer) and np.issubdtype(ys.dtype, np.integer)):
+        raise TypeError("only int indices permitted")
+    if not (np.issubdtype(ps.dtype, np.integer) or ps.dtype == np.bool_):
+        raise TypeError("the sharded event image accumulates integer weights (bit-exact int32 all-reduce)")
+    shape = (int(sensor_size[0]) + 1, int(sensor_size[1]) + 1)
+    if local_fn is not None:
+        canvas = local_fn(xs, ys, ps, shape)
+        all_reduce_sum_(canvas, group)
+    else:
+        from . import _device as D
+        from . import _lib
+        dev = D.require_gpu()
+        canvas = torch.zeros(shape, dtype=torch.int32, device=dev)
+        oob = D.OobCounter(dev)
+        if xs.shape[0]:
+            xd, yd, wd = (D.to_device(a, torch.int32) for a in (xs, ys, ps))
+            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd), xs.shape[0], shape[0], shape[1],
+                      D.ptr(canvas), oob.ptr, D.stream())
+        all_reduce_sum_(canvas, group)
+        _raise_everywhere(oob.state, ValueError, "events outside the (H+1, W+1) canvas %s" % (shape,), group)
+    return canvas.cpu().numpy().astype(np.float64)[0:int(sensor_size[0]), 0:int(sensor_size[1])]
+
+
+def sharded_evaluate(local_iwe, finish, group=None):
+    """One event-sharded objective evaluation: `local_iwe()` -> this rank's (1 | 3, H+1, W+1) IWE [+ dIWE] at the GLOBAL
+    reference time, ONE in-place all-reduce, `finish(buffer)` -> the scalars (blur + reductions, replicated: identical on
+    every rank).  objective_function._one_call runs it with the HIP kernels, the CPU tests with the oracle."""
+    img = local_iwe()
+    all_reduce_sum_(img, group, force=True)
+    return finish(img)
 
 
 def shard_objective(objective, t_last_global, group=None):

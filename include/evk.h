@@ -30,6 +30,7 @@ extern "C" {
 #define EVK_EINVAL (-1)   /* bad size / null pointer / unsupported parameter            */
 #define EVK_ESCRATCH (-2) /* caller-provided scratch too small                           */
 #define EVK_EALIGN (-3)   /* pointer not aligned as documented                            */
+#define EVK_ECOMM (-4)    /* RCCL not available / collective failed                       */
 
 /* flags for evk_iwe_* */
 #define EVK_IWE_ABS_POLARITY 1u /* get_iwe(use_polarity=False): ps = |ps|  (objectives.py:184-185)   */
@@ -187,6 +188,8 @@ int evk_objective_variance_f32(const float *iwe, int h, int w, const double *hos
 #define EVK_POST_BLUR_IWE 2u /* use the blurred IWE in the gradient (reference_exact=False); default raw (Q5)    */
 #define EVK_POST_VALUE 4u    /* evk_cmax_variance_tiled_f32 with EVK_IWE_GRADIENT: also the function value (out as
                                 evk_objective_variance_fg_f32)                                                   */
+#define EVK_POST_NONE 8u     /* evk_cmax_variance_tiled_f32: stop after the gather -- iwe_buf holds the raw IWE [, dIWE] of
+                                this rank's events, ready for the all-reduce of an event-sharded run; `out` untouched  */
 /* evaluate_gradient (objectives.py:252-264): out as evk_variance_grad_f32 with diwe replaced by its blurred version. */
 int evk_objective_variance_grad_f32(const float *iwe, const float *diwe, int h, int w, const double *host_weights,
                                     int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes,
@@ -392,6 +395,23 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        void *staging, int64_t staging_bytes, float *iwe3, double *out12, void *scratch,
                                        int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
                                        void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Event-sharded data parallelism: the path's only exchange step
+ * Every accumulator is a sum over events (image.py:95,111-114,132-135: index_put_(accumulate=True); image.py:37:
+ * np.bincount), so ranks holding disjoint event shards compute partial grids and ONE in-place SUM all-reduce of the grid
+ * (voxel grid, IWE + dIWE buffer, integer event image) gives every rank the result.  These entry points wrap RCCL
+ * (xGMI inside a node), bound at run time with dlopen: a process that already has an RCCL loaded (PyTorch) uses that
+ * copy.  One process per GPU; rank 0 creates the id (evk_comm_unique_id_bytes() bytes), the application ships it to
+ * the other ranks by whatever means it has (MPI, a file, torch.distributed), every rank calls evk_comm_init.
+ * ---------------------------------------------------------------------------------------------------------- */
+int evk_comm_unique_id_bytes(void);
+int evk_comm_unique_id(void *host_id);
+int evk_comm_init(const void *host_id, int rank, int world, void **comm_out);
+int evk_comm_destroy(void *comm);
+/* buf (device) <- sum over ranks of buf, enqueued on `stream`; int32 for the bit-exact integer event image */
+int evk_allreduce_f32(float *buf, int64_t count, void *comm, void *stream);
+int evk_allreduce_i32(int32_t *buf, int64_t count, void *comm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,42 @@ def _worker(rank, world, port, n, out_dir):
     buf = torch.from_numpy(np.concatenate([iwe[None], d]))
     DD.all_reduce_sum_(buf)
     err2 = np.abs(buf.numpy() - np.concatenate([iwe_full[None], d_full])).max()
-    np.save(os.path.join(out_dir, "err%d.npy" % rank), np.array([err, np.abs(ref).max(), err2, np.abs(d_full).max()]))
+    # the composition objective_function._one_call runs under shard_objective (distributed.sharded_evaluate): local IWE at
+    # the global reference time -> one all-reduce -> blur + variance / gradient, here with oracle closures
+    d64 = [a.astype(np.float64) for a in (x, y, t, p)]
+    robj = R.variance_objective(); robj.sensor_size = (H, W); robj.accum = "f64"
+    prm = np.array([30., -20.])
+    f_full = float(robj.evaluate_function(prm, *d64, R.linvel_warp(), (H, W), 1.0))
+    g_full = np.asarray(robj.evaluate_gradient(prm, *d64, R.linvel_warp(), (H, W), 1.0), dtype=np.float64)
+
+    def local_iwe():
+        if hi == lo:
+            return torch.zeros((3, H + 1, W + 1), dtype=torch.float64)
+        i2, d2 = R.get_iwe(prm, *(a[lo:hi] for a in d64), shard_warp(), (H, W), compute_gradient=True, sensor_size=(H, W),
+                           accum="f64")
+        return torch.from_numpy(np.concatenate([i2[None], d2]).astype(np.float64))
+
+    def finish(img):
+        a = img.numpy()
+        return (float(robj.evaluate_function(iwe=a[0].astype(np.float32), blur_sigma=1.0)),
+                np.asarray(robj.evaluate_gradient(iwe=a[0].astype(np.float32), d_iwe=a[1:].astype(np.float32), blur_sigma=1.0),
+                           dtype=np.float64))
+    f_sh, g_sh = DD.sharded_evaluate(local_iwe, finish)
+    err3 = max(abs(f_sh - f_full) / abs(f_full), np.abs(g_sh - g_full).max() / np.abs(g_full).max())
+    both = torch.tensor([f_sh, -f_sh], dtype=torch.float64)           # identical scalars on every rank
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    same = float(both[0]) == f_sh and float(both[1]) == -f_sh
+    # sharded integer event image: int32 all-reduce, bit-exact
+    xi, yi, pi = x.astype(np.int64), y.astype(np.int64), p.astype(np.int64)
+
+    def local_img(xs, ys, ps, shape):
+        c = np.bincount(np.ravel_multi_index((ys, xs), shape), weights=ps, minlength=shape[0] * shape[1]) if len(xs) else \
+            np.zeros(shape[0] * shape[1])
+        return torch.from_numpy(c.reshape(shape).astype(np.int32))
+    img = DD.events_to_image_sharded(xi[lo:hi], yi[lo:hi], pi[lo:hi], (H, W), local_fn=local_img)
+    exact = bool(np.array_equal(img, R.events_to_image(xi, yi, pi, sensor_size=(H, W))))
+    np.save(os.path.join(out_dir, "err%d.npy" % rank), np.array([err, np.abs(ref).max(), err2, np.abs(d_full).max(), err3,
+                                                               float(same), float(exact)]))
     dist.destroy_process_group()
 
 
@@ -67,8 +102,9 @@ def test_event_sharded_voxel_and_iwe_world2_gloo(tmp_path, n):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
-        err, scale, err2, scale2 = np.load(tmp_path / ("err%d.npy" % r))
+        err, scale, err2, scale2, err3, same, exact = np.load(tmp_path / ("err%d.npy" % r))
         assert err <= 1e-5 * scale and err2 <= 1e-5 * scale2
+        assert err3 <= 1e-5 and same == 1.0 and exact == 1.0
 
 
 def test_shard_bounds_partition():

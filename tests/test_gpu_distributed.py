@@ -61,6 +61,41 @@ def test_sharded_voxel_and_objective_with_rccl_group(pg):
     assert abs(f - fr) <= 1e-5 * abs(fr) and np.abs(g - gr).max() <= 1e-5 * np.abs(gr).max() + 1e-9
 
 
+def test_c_abi_collective_and_sharded_integer_image(pg, monkeypatch):
+    """libevk's own RCCL binding (evk_comm_*, evk_allreduce_f32 / _i32: what a caller without torch uses) on a 1-rank
+    communicator, the sharded integer event image and the sharded voxel grid through it."""
+    import event_utils_amd as E
+    from event_utils_amd import distributed as DD
+    monkeypatch.setenv("EVK_COLLECTIVE", "evk")
+    g = torch.arange(5000, dtype=torch.float32, device="cuda") * 0.25
+    gi = torch.arange(5000, dtype=torch.int32, device="cuda") - 77
+    rf, ri = g.clone(), gi.clone()
+    DD.all_reduce_sum_(g, pg.group.WORLD, force=True)
+    DD.all_reduce_sum_(gi, pg.group.WORLD, force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(g, rf) and torch.equal(gi, ri)          # one rank: the sum is the identity
+    assert DD._comms                                            # ... and it went through libevk's communicator
+    H, W, B, n = 90, 120, 4, 200_000
+    rng = np.random.default_rng(3)
+    xi, yi = rng.integers(0, W, n), rng.integers(0, H, n)
+    pi = rng.integers(0, 2, n) * 2 - 1
+    img = DD.events_to_image_sharded(xi, yi, pi, (H, W), group=pg.group.WORLD)
+    assert np.array_equal(img, R.events_to_image(xi, yi, pi, sensor_size=(H, W)))
+    assert np.array_equal(img, E.events_to_image(xi, yi, pi, sensor_size=(H, W)))
+    with pytest.raises(ValueError):
+        DD.events_to_image_sharded(np.array([1, W + 5]), np.array([1, 1]), np.array([1, 1]), (H, W), group=pg.group.WORLD)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    cols = [torch.from_numpy(a).cuda() for a in (xi.astype(np.float32), yi.astype(np.float32), t, pi.astype(np.float32))]
+    vox = DD.events_to_voxel_torch_sharded(*cols, B, (H, W), group=pg.group.WORLD)
+    ref = R.events_to_voxel_torch(xi.astype(np.float32), yi.astype(np.float32), t, pi.astype(np.float32), B,
+                                  sensor_size=(H, W), accum="f64")
+    assert np.abs(vox.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    cols[0][7] = W + 3.0
+    with pytest.raises(IndexError):                             # raised on every rank, after the collectives
+        DD.events_to_voxel_torch_sharded(*cols, B, (H, W), group=pg.group.WORLD)
+    DD.evk_comm_destroy(pg.group.WORLD)
+
+
 def test_two_emulated_ranks_are_additive():
     """rank 0 and rank 1 evaluated one after the other on the same GPU: summing their IWE / dIWE / voxel grids gives the
     single-rank result (what the all-reduce computes), with every rank warping to the GLOBAL reference time."""

@@ -220,3 +220,35 @@ def test_random_get_iwe_variants_equal_the_oracle(seed):
             assert np.max(np.abs(diwe.astype(np.float64) - rd)) <= 1e-5 * max(np.max(np.abs(rd)), 1e-30), impl
         else:
             assert diwe is None
+
+
+def test_optimize_at_configs3_size_converges_and_matches_the_direct_kernels():
+    """configs[3]: 50 M events, 1280x720, the full optimize() loop -- both gradient modes reach the scene's true flow
+    (40, -25) px/s, and at that size the reference-exact function value / gradient of the tiled path equal the direct
+    (global-atomic) kernels'."""
+    import warnings
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast
+    from event_utils_amd.events import DeviceEvents
+    H, W, n = 720, 1280, 50_000_000
+    x, y, t, p = bench.structured_scene(3, n, H, W)
+    ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    del x, y, t, p
+    w = E.linvel_warp()
+    for numeric, exact in ((True, True), (False, False)):      # the reference's default path; the consistent analytic gradient
+        obj = E.variance_objective()
+        obj.sensor_size, obj.reference_exact = (H, W), exact
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            argmax = optimize_contrast(ev, None, None, None, w, obj, numeric_grads=numeric, blur_sigma=1.0, img_size=(H, W))
+        assert np.abs(np.asarray(argmax, dtype=float) - np.array([40.0, -25.0])).max() <= 0.7, argmax
+    prm = np.array([38.0, -23.5])
+    vals = {}
+    for impl in ("tiled", "direct"):
+        obj = E.variance_objective()
+        obj.sensor_size, obj.impl = (H, W), impl
+        vals[impl] = (float(obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0)),
+                      np.asarray(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0), dtype=np.float64))
+    assert abs(vals["tiled"][0] - vals["direct"][0]) <= 1e-5 * abs(vals["direct"][0])
+    assert np.abs(vals["tiled"][1] - vals["direct"][1]).max() <= 1e-5 * np.abs(vals["direct"][1]).max()
