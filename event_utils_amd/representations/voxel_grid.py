@@ -150,15 +150,26 @@ def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
     H, W = int(sensor_size[0]), int(sensor_size[1])
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    seg = torch.as_tensor(np.asarray(bounds, dtype=np.int64), device=dev)
-    out = torch.zeros((nseg, B, H, W), dtype=torch.float32, device=dev)
-    oob = D.OobCounter(dev)
-    max_len = int(np.max(np.diff(np.asarray(bounds, dtype=np.int64))))
-    _lib.call("evk_voxel_segments_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), D.ptr(seg), nseg, max_len, B, H, W,
-              D.ptr(out), oob.ptr, D.stream())
-    oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
-    out = out.to(device)
-    return [out[k] for k in range(nseg)]
+    # one launch per chunk of windows: blockIdx.y holds at most 65535 of them, and a chunk's grids are bounded in memory
+    # (they move to xs.device before the next chunk is built, as the reference's per-window list would)
+    bounds = np.asarray(bounds, dtype=np.int64)
+    per_chunk = int(max(1, min(65535, _WINDOW_CHUNK_BYTES // (B * H * W * 4))))
+    grids = []
+    for c0 in range(0, nseg, per_chunk):
+        c1 = min(c0 + per_chunk, nseg)
+        seg = torch.as_tensor(bounds[c0:c1 + 1], device=dev)
+        out = torch.zeros((c1 - c0, B, H, W), dtype=torch.float32, device=dev)
+        oob = D.OobCounter(dev)
+        max_len = int(np.max(np.diff(bounds[c0:c1 + 1])))
+        _lib.call("evk_voxel_segments_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), D.ptr(seg), c1 - c0, max_len, B, H, W,
+                  D.ptr(out), oob.ptr, D.stream())
+        oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+        out = out.to(device)
+        grids.extend(out[k] for k in range(c1 - c0))
+    return grids
+
+
+_WINDOW_CHUNK_BYTES = 8 << 30
 
 
 def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temporal_bilinear=True):

@@ -467,7 +467,7 @@ def test_value_and_gradient_in_one_pass_equal_the_separate_calls(E, golden, exac
 
 
 # ------------------------------------------------------------------------------------------------ windowed voxels
-def test_voxel_windows_fixed_n_and_fixed_t(E):
+def test_voxel_windows_fixed_n_and_fixed_t(E, monkeypatch):
     """voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch (voxel_grid.py:37-80): all windows in one launch must
     equal the reference's per-window calls (each window normalises time with its own first / last event)."""
     from event_utils_amd.representations import voxel_grid as V
@@ -499,6 +499,11 @@ def test_voxel_windows_fixed_n_and_fixed_t(E):
     close(vp.numpy(), R.events_to_voxel_torch(x, y, t, (p > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
     close(vn.numpy(), R.events_to_voxel_torch(x, y, t, (p <= 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"))
     assert V.voxel_grids_fixed_n_torch(tx[:10], ty[:10], tt[:10], tp[:10], B, 10, sensor_size=(H, W)) == []
+    # many short windows in bounded chunks (one launch holds <= 65535 windows and a bounded amount of memory)
+    whole = V.voxel_grids_fixed_n_torch(tx, ty, tt, tp, B, 900, sensor_size=(H, W))
+    monkeypatch.setattr(V, "_WINDOW_CHUNK_BYTES", 3 * B * H * W * 4)          # 3 windows per launch
+    chunked = V.voxel_grids_fixed_n_torch(tx, ty, tt, tp, B, 900, sensor_size=(H, W))
+    assert len(whole) == len(chunked) == 55 and all(torch.equal(a, b) for a, b in zip(whole, chunked))
 
 
 # ------------------------------------------------------------------------------------------------ F11 next rows
@@ -579,6 +584,23 @@ def test_f13_dense_flow_warp(E, golden):
     ref = R.events_to_image_torch(xw.cpu().numpy(), yw.cpu().numpy(), np.ones(len(xo), np.float32), sensor_size=(60, 80),
                                   interpolation='bilinear', accum="f64")
     close(img.numpy(), ref)
+
+
+def test_motion_compensate_is_the_composition_of_its_two_kernels(E, golden):
+    """draw_flow.py:15-26 without the cv2 I/O: dense-flow warp (pinned by f13) + bilinear event image (pinned by f4) +
+    flip, min-max normalisation and crop, against the same composition of the oracle's functions."""
+    from event_utils_amd.lib.visualization.draw_flow import motion_compensate
+    g = golden("f13_flow_warp")
+    xs, ys, ts, flow = g["xs"], g["ys"], g["ts"], g["flow"]
+    ps = np.where(np.arange(len(xs)) % 3 == 0, -1.0, 1.0).astype(np.float32)
+    img = motion_compensate(xs, ys, ts, ps, flow, crop=(2, 40, 3, 50))
+    xw, yw = R.warp_events_flow_torch(xs, ys, ts, None, flow)
+    H, W = flow.shape[-2:]
+    ref = R.events_to_image_torch(xw.astype(np.float32), yw.astype(np.float32), ps, sensor_size=(H, W), interpolation='bilinear')
+    ref = np.flip(np.flip(ref, axis=0), axis=1)
+    ref = ((ref - ref.min()) * (255.0 / (ref.max() - ref.min())))[2:40, 3:50]
+    assert img.dtype == np.float32 and img.shape == ref.shape
+    assert np.abs(img - ref).max() <= 1e-4 * 255.0
 
 
 @pytest.mark.parametrize("impl", ["auto", "tiled"])
