@@ -329,11 +329,21 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
     __shared__ unsigned short cseg[NW][V2_CHUNK_CAP];
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
-    if (blockIdx.x >= part_start[ntiles]) return;
+    const uint32_t nitems = part_start[ntiles];
+    if (blockIdx.x >= nitems) return;
+    // XCD-aware work-item order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), and the segments of NEIGHBOURING
+    // tiles are neighbours in every run (and their table entries share a cache line), so XCD k takes a contiguous
+    // range of the tile-ordered work items: the 128-byte lines two adjacent tiles share are then fetched into ONE L2
+    // once instead of into two L2s
+    uint32_t item = blockIdx.x;
+    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER)) {
+        const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, q8 = nitems >> 3, r8 = nitems & 7u;
+        item = k * q8 + (k < r8 ? k : r8) + j;
+    }
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
-    const int tile = (int)item_tile[blockIdx.x];
+    const int tile = (int)item_tile[item];
     const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
-    const uint32_t part_id = blockIdx.x - first_item;
+    const uint32_t part_id = item - first_item;
     const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
     for (int i = threadIdx.x; i < NB * tpix; i += WG) acc[i] = 0.0;
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
@@ -458,7 +468,7 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
     }
     // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
     const int cells = NB * tpix;
-    float *mine = staging + (int64_t)blockIdx.x * cells;
+    float *mine = staging + (int64_t)item * cells;
     for (int c = threadIdx.x; c < cells; c += WG) mine[c] = (float)acc[c];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -590,7 +600,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
                   void *stream) {
     TileGrid g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
-                      EVK_VOXEL2_TILES_ONLY;
+                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER;
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
         n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > 10)
         return EVK_EINVAL;
@@ -621,7 +631,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int items = bucket_max_items(n, ntiles);
-        const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY);
+        const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
 #define V2_LAUNCH(WG, U)                                                                                           \
     k_voxel_tiles2<WG, U><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging)
 #define V2_LAUNCH_U(WG)                    \

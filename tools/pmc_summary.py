@@ -1,13 +1,16 @@
-"""Summarise rocprofv3 --pmc counter_collection CSVs into per-kernel HBM bytes per launch.
-  python tools/pmc_summary.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> > profiles/rNN_pmc_traffic.json
+"""Summarise the rocprofv3 --pmc passes of tools/profile_round.sh into per-kernel HBM bytes per launch.
+  python tools/pmc_summary.py <dir holding pmc_fetch_<tag>/ and pmc_write_<tag>/ for tag in c2, c5_share>
 hbm bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of a wide coalesced
-streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.  Both are in KiB."""
+streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.  Both are in KiB.  FETCH_SIZE and
+WRITE_SIZE come from SEPARATE passes (they do not fit one pass, same section)."""
 import csv
 import glob
 import json
 import os
 import re
 import sys
+
+ALG = {"c2": 16 * 10_000_000 + 5 * 480 * 640 * 4, "c5_share": 16 * 50_000_000 + 5 * 720 * 1280 * 4}
 
 
 def collect(d, counter):
@@ -25,20 +28,27 @@ def collect(d, counter):
 
 
 def main():
-    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --no-cpu "
-                   "--no-cmax`; hbm bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half "
-                   "of a wide coalesced streaming read, MI355X_MICROARCH.md HBM section; WRITE_SIZE as reported). "
-                   "Summarised by tools/pmc_summary.py.",
-           "kernels": {}}
-    for name in sorted(set(fetch) | set(write)):
-        if "evk::" not in name:
-            continue
-        f, w = fetch.get(name, [0.0, 0]), write.get(name, [0.0, 0])
-        fa, wa = (f[0] / f[1] if f[1] else 0.0), (w[0] / w[1] if w[1] else 0.0)
-        out["kernels"][name] = {"FETCH_SIZE_KB_avg": round(fa, 1), "WRITE_SIZE_KB_avg": round(wa, 1),
-                                "calls": max(f[1], w[1]),
-                                "hbm_bytes_per_launch_corrected": int(round((2 * fa + wa) * 1024))}
+    root = sys.argv[1]
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py <tag> "
+                   "(8 calls of the voxel path alone); hbm bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
+                   "FETCH_SIZE reports half of a wide coalesced streaming read, MI355X_MICROARCH.md HBM section; WRITE_SIZE "
+                   "as reported).  whole_call_bytes = sum over the kernels of one call; algorithmic_bytes = 16 B/event + "
+                   "the grid (SURVEY.md 8(d)).  Summarised by tools/pmc_summary.py."}
+    for tag in ("c2", "c5_share"):
+        fetch = collect(os.path.join(root, "pmc_fetch_" + tag), "FETCH_SIZE")
+        write = collect(os.path.join(root, "pmc_write_" + tag), "WRITE_SIZE")
+        ks, total = {}, 0
+        for name in sorted(set(fetch) | set(write)):
+            if "evk::" not in name:
+                continue
+            f, w = fetch.get(name, [0.0, 0]), write.get(name, [0.0, 0])
+            fa, wa = (f[0] / f[1] if f[1] else 0.0), (w[0] / w[1] if w[1] else 0.0)
+            b = int(round((2 * fa + wa) * 1024))
+            ks[name] = {"FETCH_SIZE_KB_avg": round(fa, 1), "WRITE_SIZE_KB_avg": round(wa, 1), "calls": max(f[1], w[1]),
+                        "hbm_bytes_per_launch_corrected": b}
+            total += b
+        out[tag] = {"kernels": ks, "whole_call_bytes": total, "algorithmic_bytes": ALG[tag],
+                    "amplification": round(total / ALG[tag], 3) if total else None}
     json.dump(out, sys.stdout, indent=1)
 
 

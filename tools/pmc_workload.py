@@ -1,0 +1,27 @@
+"""The voxel call of one bench workload, alone, for the rocprofv3 PMC passes (tools/profile_round.sh):
+    python tools/pmc_workload.py c2        10 M events, 640x480x5   (configs[1], the headline)
+    python tools/pmc_workload.py c5_share  50 M events, 1280x720x5  (one rank's share of configs[4])
+Runs the internal entry point (resident grid, no per-call checks) 8 times so that the counters see exactly the kernels
+of the call: k_part_sorted and k_voxel_tiles2."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from event_utils_amd.representations.voxel_grid import _voxel_f32_device  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "c2"
+n, H, W, B = (10_000_000, 480, 640, 5) if tag == "c2" else (50_000_000, 720, 1280, 5)
+rng = np.random.default_rng(1 if tag == "c2" else 40)
+x = rng.integers(0, W, n).astype(np.float32)
+y = rng.integers(0, H, n).astype(np.float32)
+t = np.sort(rng.uniform(0.0, 0.1, n)).astype(np.float32)
+p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+for _ in range(8):
+    _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), out=out, check=False, fresh=True)
+torch.cuda.synchronize()
+print("done", tag)

@@ -1,16 +1,23 @@
 #!/bin/bash
-# Round-end profile refresh on the GPU box (run through gpurun): kernel-trace stats and the two PMC passes of the
-# default bench command, summarised into gpurun_out/ (copy the results into profiles/ afterwards).
+# Round-end profile refresh on the GPU box (run through gpurun): the bench line, rocprofv3 kernel-trace stats of the same
+# command, and the PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, MI355X_MICROARCH.md) of the two voxel
+# workloads, summarised into gpurun_out/prof (copy the results into profiles/ afterwards).
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
+R=${ROUND:-r02}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-timeout -s KILL 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -s KILL 500 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --no-cpu > $OUT/stats.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 5 --no-cpu --no-cmax > $OUT/pmc_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 5 --no-cpu --no-cmax > $OUT/pmc_write.log 2>&1
-python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json
-find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/stats
-tail -c 600 $OUT/bench.json; echo; head -c 1500 $OUT/pmc_traffic.json
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_bench_kernel_stats.csv \;
+rm -rf $OUT/stats
+for tag in c2 c5_share; do
+  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_fetch_$tag.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_write_$tag.log 2>&1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$tag -- python tools/pmc_workload.py $tag > $OUT/st_$tag.log 2>&1
+  find $OUT/st_$tag -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_voxel_${tag}_kernel_stats.csv \;
+done
+python tools/pmc_summary.py $OUT > $OUT/${R}_pmc_traffic.json
+rm -rf $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/st_*
+tail -c 400 $OUT/${R}_bench.json; echo; cat $OUT/${R}_pmc_traffic.json | head -60
