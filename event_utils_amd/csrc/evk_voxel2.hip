@@ -498,28 +498,40 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
 struct V2Config {
     int threads, ept, blocks_per_cu, wg, u;
 };
-static const V2Config &v2_config() {
-    static V2Config cfg = [] {
-        V2Config c{512, 32, 1, 512, 2};
-        // partition geometries (threads x events per thread, blocks per CU): "1024x16" S = 16 K, 1 block;
-        // "512x32" the same with 8 waves and 256 registers; "1024x8", "512x16", "768x12" S = 8-9 K, 2 blocks per CU
+static V2Config v2_config_env() {
+        V2Config c{1024, 8, 1, 512, 2};
+        // partition geometries (EVK_V2_PART = threads x events per thread): default "1024x8s": sub-chunks of 8 K events, one
+        // workgroup per CU, 128 registers per thread without spills -- 50 us at 10 M events, and it leaves LDS and
+        // registers for another kernel's workgroups (profiles/r02_cu_contention_probe.txt).  Measured alternatives:
+        // "512x32" / "1024x16" (16 K events: longer segments for the tile kernel, but 67 / 74 us and the whole CU taken),
+        // "1024x8" / "512x16" / "768x12" (two workgroups per CU: spills, 75-150 us)
         const char *geo = getenv("EVK_V2_PART");
         if (geo && !strcmp(geo, "512x32")) c.threads = 512, c.ept = 32, c.blocks_per_cu = 1;
         else if (geo && !strcmp(geo, "1024x8")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 2;
         else if (geo && !strcmp(geo, "512x16")) c.threads = 512, c.ept = 16, c.blocks_per_cu = 2;
         else if (geo && !strcmp(geo, "768x12")) c.threads = 768, c.ept = 12, c.blocks_per_cu = 2;
         else if (geo && !strcmp(geo, "1024x16")) c.threads = 1024, c.ept = 16, c.blocks_per_cu = 1;
-        else c.threads = 512, c.ept = 32, c.blocks_per_cu = 1;
+        else if (geo && !strcmp(geo, "1024x8s")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
+        else c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
         if (const char *s = getenv("EVK_V2_WG")) c.wg = atoi(s) == 512 ? 512 : (atoi(s) == 1024 ? 1024 : 256);
         if (const char *s = getenv("EVK_V2_U")) c.u = atoi(s) == 2 ? 2 : (atoi(s) == 8 ? 8 : 4);
         return c;
+}
+// share = leave LDS for the workgroups of ANOTHER kernel on every CU (an overlapped RCCL collective): sub-chunks of 8 K
+// events (64 KB of sorted records instead of 128 KB), still one partition workgroup per CU
+static const V2Config &v2_config(bool share = false) {
+    static const V2Config base = v2_config_env();
+    static const V2Config shared = [] {
+        V2Config c = base;
+        c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
+        return c;
     }();
-    return cfg;
+    return share ? shared : base;
 }
 #define V2_MIN_SUBCHUNK 8192
 
-static Part2 v2_geometry(int64_t n, int ntiles) {
-    const V2Config &c = v2_config();
+static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
+    const V2Config &c = v2_config(share);
     const int64_t smax = (int64_t)c.threads * c.ept;
     int64_t nblk = (n + V2_MIN_SUBCHUNK - 1) / V2_MIN_SUBCHUNK;
     const int64_t maxblk = (int64_t)EVK_NUM_CU * c.blocks_per_cu;
@@ -542,8 +554,8 @@ static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 struct V2Layout {
     int64_t table, rec, pw, staging, total;
 };
-static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
-    const Part2 q = v2_geometry(n, ntiles);
+static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw_log2, int th_log2, bool share = false) {
+    const Part2 q = v2_geometry(n, ntiles, share);
     const int64_t slots = (int64_t)q.nsc * q.S;
     V2Layout L;
     L.table = 0;
@@ -565,7 +577,9 @@ extern "C" int64_t evk_voxel2_index_len(int ntiles, int64_t n) {
 
 extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
     if (ntiles <= 0 || n < 0 || planes <= 0) return 0;
-    return v2_layout(ntiles, n, planes, tw_log2, th_log2).total;
+    const int64_t a = v2_layout(ntiles, n, planes, tw_log2, th_log2, false).total;
+    const int64_t b = v2_layout(ntiles, n, planes, tw_log2, th_log2, true).total;
+    return a > b ? a : b;
 }
 
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
@@ -600,7 +614,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
                   void *stream) {
     TileGrid g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
-                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER;
+                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU;
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
         n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > 10)
         return EVK_EINVAL;
@@ -609,21 +623,23 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) << (tw_log2 + th_log2);
     if (lds_acc > 64 * 1024) return EVK_EINVAL;
-    const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2);
+    const bool share = flags & EVK_VOXEL2_SHARE_CU;
+    const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2, share);
     if (scratch_bytes < L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
-    const Part2 q = v2_geometry(n, ntiles);
+    const Part2 q = v2_geometry(n, ntiles, share);
     char *sb = (char *)scratch;
     uint32_t *table = (uint32_t *)(sb + L.table);
     uint2 *rec = (uint2 *)(sb + L.rec);
     float *pw = (float *)(sb + L.pw);
     float *staging = (float *)(sb + L.staging);
     hipStream_t s = (hipStream_t)stream;
-    const V2Config &cfg = v2_config();
+    const V2Config &cfg = v2_config(share);
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
         if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else if (cfg.threads == 1024 && cfg.ept == 8 && cfg.blocks_per_cu == 1) launch_part<1024, 8, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 768) launch_part<768, 12, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);

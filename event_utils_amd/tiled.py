@@ -165,6 +165,8 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     index = _zbuf("voxel2_index", sizes[0], dev)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
     flags = (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | (_lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0) | stage
+    if share_cu():
+        flags |= 128         # EVK_VOXEL2_SHARE_CU
     if os.environ.get("EVK_V2_XCD_ORDER", "1") == "0":
         flags |= 64          # EVK_VOXEL2_NO_XCD_ORDER (A/B measurement)
     if t_first is None:

@@ -318,6 +318,8 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 #define EVK_VOXEL_T_FROM_EVENTS 4
 #define EVK_VOXEL2_PARTITION_ONLY 16
 #define EVK_VOXEL2_TILES_ONLY 32
+#define EVK_VOXEL2_SHARE_CU 128    /* partition with 64 KB of LDS per CU instead of 128 KB, so that workgroups of another,
+                                      concurrently running kernel (an overlapped RCCL collective) still fit on every CU */
 #define EVK_VOXEL2_NO_XCD_ORDER 64 /* A/B switch: tile kernel work items in plain order instead of one contiguous range per XCD */
 int evk_voxel2_max_tiles(void);
 int64_t evk_voxel2_index_len(int ntiles, int64_t n);
