@@ -407,7 +407,10 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
         for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = (unsigned short)(lane | (k << 6));
         __syncthreads();
         const uint32_t wbase = (uint32_t)(base + wave * 64);  // sub-chunk of lane 0's entry
-        // chunk rounds: U loads per lane in flight, then accumulated (double-buffering them measured slower: 60 vs 46 us)
+        // chunk rounds: U loads per lane in flight, then accumulated (double-buffering them measured slower: 60 vs 46 us).
+        // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
+        // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
+        // while its 600 segments are pulled
         auto issue = [&](uint32_t j0, uint4(&v)[U], uint32_t(&pos)[U], uint32_t(&beg)[U], uint32_t(&end)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -499,10 +502,12 @@ struct V2Config {
     int threads, ept, blocks_per_cu, wg, u;
 };
 static V2Config v2_config_env() {
-        V2Config c{1024, 8, 1, 512, 2};
-        // partition geometries (EVK_V2_PART = threads x events per thread): default "1024x8s": sub-chunks of 8 K events, one
-        // workgroup per CU, 128 registers per thread without spills -- 50 us at 10 M events, and it leaves LDS and
-        // registers for another kernel's workgroups (profiles/r02_cu_contention_probe.txt).  Measured alternatives:
+        V2Config c{1024, 12, 1, 512, 2};
+        // partition geometries (EVK_V2_PART = threads x events per thread), one workgroup per CU.  Default "1024x12s":
+        // sub-chunks of 12 K events, 53 us at 10 M events and the longer segments make the tile kernel 11 % faster than
+        // with "1024x8s" (8 K events, 51 us, 105 registers, no spills) -- which is what a multi-rank job gets
+        // (EVK_VOXEL2_SHARE_CU) because it leaves LDS AND registers for another kernel's workgroups
+        // (profiles/r02_cu_contention_probe.txt).  Measured alternatives:
         // "512x32" / "1024x16" (16 K events: longer segments for the tile kernel, but 67 / 74 us and the whole CU taken),
         // "1024x8" / "512x16" / "768x12" (two workgroups per CU: spills, 75-150 us)
         const char *geo = getenv("EVK_V2_PART");
@@ -512,7 +517,8 @@ static V2Config v2_config_env() {
         else if (geo && !strcmp(geo, "768x12")) c.threads = 768, c.ept = 12, c.blocks_per_cu = 2;
         else if (geo && !strcmp(geo, "1024x16")) c.threads = 1024, c.ept = 16, c.blocks_per_cu = 1;
         else if (geo && !strcmp(geo, "1024x8s")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
-        else c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
+        else if (geo && !strcmp(geo, "1024x12s")) c.threads = 1024, c.ept = 12, c.blocks_per_cu = 1;
+        else c.threads = 1024, c.ept = 12, c.blocks_per_cu = 1;
         if (const char *s = getenv("EVK_V2_WG")) c.wg = atoi(s) == 512 ? 512 : (atoi(s) == 1024 ? 1024 : 256);
         if (const char *s = getenv("EVK_V2_U")) c.u = atoi(s) == 2 ? 2 : (atoi(s) == 8 ? 8 : 4);
         return c;
@@ -639,6 +645,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
         if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        else if (cfg.threads == 1024 && cfg.ept == 12) launch_part<1024, 12, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 1024 && cfg.ept == 8 && cfg.blocks_per_cu == 1) launch_part<1024, 8, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
         else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
