@@ -233,12 +233,12 @@ class objective_function(ABC):
         planes = 3 if grad else 1
         buf = tiled._buf("iwe_buf", planes * ch * cw * 4, dev)
         out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
-        res = np.empty(4, dtype=np.float64)      # filled by the call itself (it synchronises the stream)
+        res = self.__dict__.setdefault("_res4", np.empty(4, dtype=np.float64))   # filled by the call itself
         if not sharded:
             ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
                                      float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
                                      impl=self.impl, host_out=res)
-            return res if ok else None
+            return res.copy() if ok else None
         from .. import distributed as DD
         img = buf[:planes * ch * cw * 4].view(torch.float32).view(planes, ch, cw)
 

@@ -371,15 +371,46 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
                   scratch_bytes, impl=None, host_out=None):
     """One-call objective evaluation (evk_cmax_variance_tiled_f32) into `out` (4 doubles); returns False when the
     tiled plan is not applicable (the caller then composes the direct kernels).  host_out = numpy float64[4]: the call
-    also brings the results to the host and synchronises itself."""
+    also brings the results to the host and synchronises itself.
+    The ~36 marshalled arguments of the call are cached on `ev` per (geometry, buffers): a BFGS loop evaluates the same
+    events hundreds of times and only vx, vy and the spill parity change, which takes ~10 us of Python off every
+    evaluation (84 -> 74 us at 10 M events)."""
+    import math
+    ckey = (t_ref, bounds_w, bounds_h, ch, cw, flags, radius, post_flags, impl or default_impl(), spill_enabled(),
+            os.environ.get("EVK_IWE_FIXED", "64"), ev.p_scale)
+    cache = ev.__dict__.setdefault("_cmax_calls", {})
+    c = cache.get(ckey)
+    if c is not None and c["buf"] is buf and c["out"] is out and c["scratch"] is scratch and c["weights"] is weights \
+            and c["host_out"] is host_out and math.isfinite(vx) and math.isfinite(vy):
+        span, tw, th, planes = c["geo"]
+        S, win_w, win_h = _iwe_window(0.0, 1.0, abs(vx) * span, abs(vy) * span, 1 << tw, 1 << th, planes)
+        if (S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]:
+            args = c["args"]
+            args[12], args[13] = vx, vy
+            st = c["spill"]
+            if st is not None:
+                st[1] ^= 1
+                args[c["i_parity"]] = st[1]
+            args[-1] = D.stream()
+            _lib.check(c["fn"](*args), "evk_cmax_variance_tiled_f32")
+            return True
     plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
     if plan is None:
         return False
-    spill, parity = _spill_pair(buf.device, 3 if flags & _lib.EVK_IWE_GRADIENT else 1, ch, cw) if spill_enabled() \
-        else (None, 0)
-    _lib.call("evk_cmax_variance_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
-              post_flags, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
-              scratch_bytes, D.ptr(spill), parity, D.host_ptr(host_out) if host_out is not None else None, D.stream())
+    planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
+    spill, parity = _spill_pair(buf.device, planes, ch, cw) if spill_enabled() else (None, 0)
+    args = list(plan["head"]) + [D.host_ptr(weights) if weights is not None else None, radius, post_flags,
+                                 D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
+                                 scratch_bytes, D.ptr(spill), parity,
+                                 D.host_ptr(host_out) if host_out is not None else None, D.stream()]
+    fn = getattr(_lib.lib(), "evk_cmax_variance_tiled_f32")
+    _lib.check(fn(*args), "evk_cmax_variance_tiled_f32")
+    head = plan["head"]
+    cache[ckey] = {"fn": fn, "args": args, "buf": buf, "out": out, "scratch": scratch, "weights": weights,
+                   "host_out": host_out, "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
+                   "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6], planes),
+                   "spill": _spill.get((buf.device.index, D.stream_id(buf.device), planes, ch, cw)) if spill is not None else None,
+                   "i_parity": len(args) - 3, "keep": (plan, spill)}
     return True
 
 

@@ -503,7 +503,9 @@ def test_voxel_windows_fixed_n_and_fixed_t(E, monkeypatch):
     whole = V.voxel_grids_fixed_n_torch(tx, ty, tt, tp, B, 900, sensor_size=(H, W))
     monkeypatch.setattr(V, "_WINDOW_CHUNK_BYTES", 3 * B * H * W * 4)          # 3 windows per launch
     chunked = V.voxel_grids_fixed_n_torch(tx, ty, tt, tp, B, 900, sensor_size=(H, W))
-    assert len(whole) == len(chunked) == 55 and all(torch.equal(a, b) for a, b in zip(whole, chunked))
+    assert len(whole) == len(chunked) == 55        # (float atomics: the same sums, not necessarily the same bits)
+    for a, b in zip(whole, chunked):
+        close(a.numpy(), b.numpy())
 
 
 # ------------------------------------------------------------------------------------------------ F11 next rows
