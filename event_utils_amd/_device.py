@@ -87,14 +87,20 @@ def error_mode():
 
 
 class _ErrorState:
-    """Per (device, stream): ONE cumulative device counter of dropped events (never reset, so no memset per call) and
-    a ring of pinned host slots it is copied to asynchronously."""
+    """Per (device, stream): ONE cumulative device counter of dropped events (never reset, so no memset per call).
+    Deferred reports reach the host without a copy or an event on the stream: the kernels of a call write
+    {call sequence number, counter} into a pinned, device-visible slot when their last workgroup finishes
+    (evk_voxel2_f32, `host_report`); calls whose kernels cannot do that copy the counter into a ring of pinned slots
+    asynchronously and record an event."""
     RING = 64
 
     def __init__(self, device):
         from collections import deque
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.host = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+        self.report = torch.zeros(2, dtype=torch.int32).pin_memory()      # [sequence number, counter], written by the GPU
+        self.report_np = self.report.numpy()
+        self.seq = 0
         self.seen = 0
         self.slot = 0
         self.pending = deque()
@@ -107,6 +113,15 @@ class _ErrorState:
     def poll(self, wait=False):
         while self.pending:
             ev, k, exc_type, msg = self.pending[0]
+            if ev is None:                       # reported by the kernels: k = the call's sequence number
+                if wait:
+                    torch.cuda.synchronize()
+                done, value = int(self.report_np[0]), int(self.report_np[1])
+                if ((done - k) & 0xFFFFFFFF) >= 0x80000000:      # that call has not finished yet
+                    return
+                self.pending.popleft()
+                self._raise(value & 0xFFFFFFFF, exc_type, msg)
+                continue
             if wait:
                 ev.synchronize()
             elif not ev.query():
@@ -118,9 +133,16 @@ class _ErrorState:
         self.poll(wait=True)
         self._raise(int(self.counter.item()), exc_type, msg)      # synchronises; the reference is synchronous too
 
-    def defer(self, exc_type, msg):
+    def next_seq(self):
+        self.seq = (self.seq + 1) & 0x7FFFFFFF
+        return self.seq
+
+    def defer(self, exc_type, msg, seq=None):
         if len(self.pending) >= self.RING - 1:
             self.poll(wait=True)
+        if seq is not None:
+            self.pending.append((None, seq, exc_type, msg))
+            return
         k, self.slot = self.slot, (self.slot + 1) % self.RING
         self.host[k:k + 1].copy_(self.counter, non_blocking=True)
         ev = torch.cuda.Event()
@@ -152,6 +174,12 @@ class OobCounter:
     def __init__(self, device=None):
         self.state = _error_state(device or require_gpu())
         self.state.poll()                      # surface what earlier deferred calls on this stream left behind
+        self.seq = None                        # set by a call whose kernels report {seq, counter} to the host themselves
+
+    def report_args(self):
+        """(pinned slot pointer, sequence number) for kernels that report the counter to the host themselves."""
+        self.seq = self.state.next_seq()
+        return ctypes.c_void_p(self.state.report.data_ptr()), self.seq
 
     @property
     def ptr(self):
@@ -159,7 +187,7 @@ class OobCounter:
 
     def raise_if_set(self, exc_type, msg, deferrable=False):
         if deferrable and error_mode() == "deferred":
-            self.state.defer(exc_type, msg)
+            self.state.defer(exc_type, msg, self.seq)
         else:
             self.state.strict(exc_type, msg)
 

@@ -62,9 +62,9 @@ SIGNATURES = {
     "evk_native_to_columns_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, P, P, P, P, P],
     "evk_voxel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, c_int64, P],
     "evk_voxel2_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, c_int64,
-                       P, P],
+                       P, P, c_uint32, P],
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
-                              c_float, c_int, c_int, P, P, P, c_int64, P, P],
+                              c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
                                                             float t_first, float t_last, float bm1, int t_from_events,
                                                             uint2 *__restrict__ rec, float *__restrict__ pw,
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
-                                                            uint32_t cap, uint32_t *oob) {
+                                                            uint32_t cap, uint32_t *oob, uint32_t *host_report, uint32_t seq) {
     constexpr int NQ = EPT / 4;
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -306,6 +306,12 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
     if (tid == 0) {
         part_start[ntiles] = total_parts;
         __hip_atomic_store(gidx + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
+                            // in pinned memory, so that a deferred error check costs no copy and no event on the stream
+            const uint32_t cnt = oob ? __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            __hip_atomic_store(host_report + 1, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_report, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -599,7 +605,7 @@ extern "C" int evk_voxel2_max_tiles(void) {
 template <int THREADS, int EPT, int BPC, typename C>
 static void launch_part(const C &c, int64_t n, const TileGrid &g, int ntiles, const Part2 &q, float t_first, float t_last,
                         float bm1, int t_from_events, uint2 *rec, float *pw, uint32_t *table, uint32_t *index,
-                        uint32_t *oob, hipStream_t s) {
+                        uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
     const size_t lds = (size_t)THREADS * EPT * 8 + 16 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
     static uint64_t attr_set = 0;
     int dev = 0;
@@ -611,13 +617,14 @@ static void launch_part(const C &c, int64_t n, const TileGrid &g, int ntiles, co
         attr_set |= (uint64_t)1 << (dev & 63);
     }
     k_part_sorted<THREADS, EPT, BPC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
-                                                                    rec, pw, table, index, (uint32_t)bucket_cap(n, ntiles), oob);
+                                                                    rec, pw, table, index, (uint32_t)bucket_cap(n, ntiles), oob,
+                                                                    host_report, seq);
 }
 
 template <typename C>
 static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first, float t_last, int B,
                   int flags, float *vox, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
-                  void *stream) {
+                  uint32_t *host_report, uint32_t seq, void *stream) {
     TileGrid g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU;
@@ -644,13 +651,13 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
-        if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else if (cfg.threads == 1024 && cfg.ept == 12) launch_part<1024, 12, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else if (cfg.threads == 1024 && cfg.ept == 8 && cfg.blocks_per_cu == 1) launch_part<1024, 8, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else if (cfg.threads == 768) launch_part<768, 12, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
-        else launch_part<1024, 16, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, s);
+        if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else if (cfg.threads == 1024 && cfg.ept == 12) launch_part<1024, 12, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else if (cfg.threads == 1024 && cfg.ept == 8 && cfg.blocks_per_cu == 1) launch_part<1024, 8, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else if (cfg.threads == 768) launch_part<768, 12, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        else launch_part<1024, 16, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int items = bucket_max_items(n, ntiles);
@@ -674,21 +681,24 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
 
 extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
                               int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
-                              uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, void *stream) {
+                              uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                              uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
     const ColsF32 c{x, y, t, p};
-    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, stream);
+    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+                  seq, stream);
 }
 
 extern "C" int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
                                      double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2,
                                      int th_log2, float t_first, float t_last, int B, int flags, float *vox,
                                      uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
-                                     void *stream) {
+                                     uint32_t *host_report, uint32_t seq, void *stream) {
     ColsNative c;
     const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
     if (rc != EVK_OK) return rc;
     if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
-    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, stream);
+    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+                  seq, stream);
 }

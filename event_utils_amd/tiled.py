@@ -172,8 +172,9 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     if t_first is None:
         flags |= _lib.EVK_VOXEL_T_FROM_EVENTS
         t_first = t_last = 0.0
+    report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
     tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
-            oob.ptr if oob is not None else None, D.stream())
+            oob.ptr if oob is not None else None, report, seq, D.stream())
     if native is None:
         _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, *tail)
     else:

@@ -310,6 +310,10 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  *   index    evk_voxel2_index_len(ntiles, n) uint32, ZEROED ONCE by the caller when it is allocated; the library
  *            leaves its counters at zero after every call (persistent across calls on one stream)
  *   scratch  evk_voxel2_scratch_bytes(...) bytes, 16-byte aligned, uninitialised
+ *   host_report  optional: two uint32 in PINNED host memory the device can write (hipHostMalloc).  When the partition
+ *            kernel's last workgroup finishes it stores {seq, *oob} there (system scope), so a caller that checks for
+ *            dropped events lazily needs neither a device-to-host copy nor an event on the stream: the call numbered
+ *            `seq` has counted all its events once host_report[0] == seq (sequence numbers grow by one per call).
  *   flags    EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY as evk_voxel_tiled_f32;
  *            EVK_VOXEL_T_FROM_EVENTS: t_first / t_last are read on the device from t[0] / t[n-1] (voxel_grid.py:133-134
  *            takes them from the same column), so the caller needs no device-to-host transfer before the launch;
@@ -326,12 +330,13 @@ int64_t evk_voxel2_index_len(int ntiles, int64_t n);
 int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2);
 int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
                    int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
-                   uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, void *stream);
+                   uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                   uint32_t seq, void *stream);
 /* the same from the reference's on-disk dtypes (see evk_bucket_events_native_f32) */
 int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind, double t_offset,
                           const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first,
                           float t_last, int B, int flags, float *vox, uint32_t *index, void *scratch,
-                          int64_t scratch_bytes, uint32_t *oob, void *stream);
+                          int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
 
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
  * one workgroup per (work item, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted
