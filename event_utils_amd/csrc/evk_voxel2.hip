@@ -322,15 +322,16 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 // whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 64
 // records (clustered scenes) are streamed by the whole wave instead.
 #define V2_CHUNK_CAP 512  // 64 segments x <= 8 chunks
-template <int WG, int U>
+template <int WG, int U, bool SPLIT>
 __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGrid g, Part2 q, int B, int flags, float *__restrict__ vox,
                                                      float *__restrict__ staging) {
     constexpr int NW = WG / 64;
     const int overwrite = flags & EVK_VOXEL_OVERWRITE;
-    const bool split = flags & EVK_VOXEL_SPLIT_POLARITY;
+    constexpr bool split = SPLIT;
     const int NB = split ? 2 * B : B;
+    const float bm1 = (float)(B - 1);
     extern __shared__ __attribute__((aligned(16))) acc_t acc[];
     __shared__ unsigned short cseg[NW][V2_CHUNK_CAP];
     const int ntiles = g.tiles_x * g.tiles_y;
@@ -363,7 +364,22 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
-        if (!split) {
+        if (tn >= 0.0f && tn <= bm1) {
+            // the common case, straight-line: t inside [ts[0], ts[-1]].  Bins b0 = floor(t_norm) and b0 + 1 with the
+            // weights of voxel_grid.py:138 -- 1 - |t_norm - b| evaluated exactly as there (for b0 the absolute value is
+            // the identity; max(0, .) cannot bind for these two bins)
+            acc_t *a = acc + local;
+            float w = p;
+            if constexpr (split) {
+                if (!(p > 0.0f) && !(p <= 0.0f)) return;  // a NaN polarity is in neither grid
+                a += p > 0.0f ? 0 : B * tpix;
+                w = 1.0f;
+            }
+            const int b0 = (int)tn;
+            const float v0 = w * (1.0f - (tn - (float)b0)), v1 = w * (1.0f - fabsf(tn - (float)(b0 + 1)));
+            if (v0 != 0.0f) lds_add(a + b0 * tpix, v0);
+            if (b0 + 1 < B && v1 != 0.0f) lds_add(a + (b0 + 1) * tpix, v1);
+        } else if (!split) {
             voxel_bins_lds(acc, tpix, local, B, tn, p);
         } else if (tn != tn) {
             voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
@@ -663,7 +679,12 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
         const int items = bucket_max_items(n, ntiles);
         const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
 #define V2_LAUNCH(WG, U)                                                                                           \
-    k_voxel_tiles2<WG, U><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging)
+    do {                                                                                                           \
+        if (kf & EVK_VOXEL_SPLIT_POLARITY)                                                                         \
+            k_voxel_tiles2<WG, U, true><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);   \
+        else                                                                                                       \
+            k_voxel_tiles2<WG, U, false><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);  \
+    } while (0)
 #define V2_LAUNCH_U(WG)                    \
     do {                                   \
         if (cfg.u == 2) V2_LAUNCH(WG, 2);  \

@@ -3,5 +3,4 @@ mkdir -p gpurun_out
 out=gpurun_out/v2_sweep.txt
 : > $out
 timeout 300 python tools/v2_sweep.py --big --v2only --check >> $out 2>&1
-EVK_V2_PART=1024x8s timeout 300 python tools/v2_sweep.py --big --v2only --check >> $out 2>&1
 grep -v amdgpu.ids $out
