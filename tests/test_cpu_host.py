@@ -259,3 +259,23 @@ int main(int argc, char **argv) {
     subprocess.run(cmd, check=True, capture_output=True)
     out = subprocess.run([str(exe), lib], check=True, capture_output=True, text=True).stdout.strip().split("|")
     assert int(out[0]) >= 100 and out[1] and int(out[2]) == 20 * 30
+
+
+def test_bench_with_more_gpus_than_the_box_has_fails_loudly():
+    """`python bench.py --gpus 2` launches its own two ranks (torch.distributed.run); on a box without two GPUs it must
+    die with a non-zero exit status instead of printing a one-GPU number under a two-GPU label."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--no-cmax"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    # the rank / world bookkeeping: a WORLD_SIZE that disagrees with --gpus is refused before any GPU work
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
