@@ -29,7 +29,12 @@ namespace evk {
 #define V2_PART (V2_HDR + V2_MAX_TILES)            // part_start[T + 1]
 #define V2_COUNTER(T) (V2_PART + (T) + 1)          // counters[T]   (split-tile combine)
 #define V2_ITEM(T) (V2_PART + 2 * (T) + 1)         // item_tile[max_items]
-#define V2_WIDE 0x400u
+#ifndef V2_LB
+#define V2_LB 10  // bits of the pixel-in-tile field (tiles of <= 2^V2_LB pixels); the polarity keeps 32 - V2_LB - 1 bits
+#endif
+#define V2_LOCAL_MASK ((1u << V2_LB) - 1u)
+#define V2_WIDE (1u << V2_LB)
+#define V2_P_MASK (~((2u << V2_LB) - 1u))
 // ablation builds (tools/v2_ablate.sh): stop the partition kernel's per-sub-chunk work after stage A (0 loads, 1 ranks,
 // 2 scan + table, 3 placement, 4 = everything) / the tile kernel's after stage B (0 table entries, 1 record loads,
 // 2 decode, 3 = everything).  Results are wrong below the last stage; timing only.
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
             for (int e = 0; e < 4; ++e) {
                 uint32_t local = 0;
                 const int key = e < nv ? key_local(xv[k].v[e], yv[k].v[e], g, local) : -1;
-                kl[4 * k + e] = key >= 0 ? (((uint32_t)key << 10) | local) : 0xFFFFFFFFu;
+                kl[4 * k + e] = key >= 0 ? (((uint32_t)key << V2_LB) | local) : 0xFFFFFFFFu;
                 dropped += (key < 0 && e < nv) ? 1u : 0u;
             }
         }
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2)
             if (kl[s2] != 0xFFFFFFFFu)
-                __hip_atomic_fetch_add(&hist[kl[s2] >> 10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&hist[kl[s2] >> V2_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();  // histogram complete
         if (V2_ABLATE_A < 2) {
             uint32_t sink = 0;
@@ -228,11 +233,11 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 #pragma unroll
         for (int s = 0; s < EPT; ++s) {
             if (kl[s] != 0xFFFFFFFFu) {
-                const uint32_t pos = atomicAdd(&hist[kl[s] >> 10], 1u);
+                const uint32_t pos = atomicAdd(&hist[kl[s] >> V2_LB], 1u);
                 const float tn = tv[s >> 2].v[s & 3];
                 const uint32_t pbits = __float_as_uint(pv[s >> 2].v[s & 3]);
-                const bool wide = (pbits & 0x7FFu) != 0u;
-                sorted[pos] = make_uint2(__float_as_uint(tn), (wide ? V2_WIDE : (pbits & 0xFFFFF800u)) | (kl[s] & 0x3FFu));
+                const bool wide = (pbits & ~V2_P_MASK) != 0u;
+                sorted[pos] = make_uint2(__float_as_uint(tn), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s] & V2_LOCAL_MASK));
                 if (wide) wide_mask |= 1u << s, kl[s] = pos;   // kl is dead from here on: keep the slot instead
             }
         }
@@ -357,8 +362,8 @@ __global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ r
     const uint32_t *col = table + tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, grp = lane >> 2;
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
-        const int local = (int)(hi_w & 0x3FFu);
-        const float p = (hi_w & V2_WIDE) ? pw[ridx] : __uint_as_float(hi_w & 0xFFFFF800u);
+        const int local = (int)(hi_w & V2_LOCAL_MASK);
+        const float p = (hi_w & V2_WIDE) ? pw[ridx] : __uint_as_float(hi_w & V2_P_MASK);
         const float tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
         if (V2_ABLATE_B < 3) {
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
@@ -645,13 +650,13 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU;
     if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
-        n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > 10)
+        n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > V2_LB)
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) << (tw_log2 + th_log2);
-    if (lds_acc > 64 * 1024) return EVK_EINVAL;
+    if (lds_acc > 140 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2, share);
     if (scratch_bytes < L.total) return EVK_ESCRATCH;
@@ -680,6 +685,10 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
         const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
 #define V2_LAUNCH(WG, U)                                                                                           \
     do {                                                                                                           \
+        if (lds_acc > 64 * 1024) {                                                                                 \
+            (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);  \
+            (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); \
+        }                                                                                                          \
         if (kf & EVK_VOXEL_SPLIT_POLARITY)                                                                         \
             k_voxel_tiles2<WG, U, true><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);   \
         else                                                                                                       \

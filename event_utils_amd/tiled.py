@@ -145,7 +145,8 @@ def voxel2_shape(H, W, planes):
     L = _lib.lib()
     tw, th = voxel_tile_shape(H, W, planes)
     for a, b in ((tw, th), (5, 5)):
-        if a + b <= 10 and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= L.evk_voxel2_max_tiles() and planes * 8 << (a + b) <= 65536:
+        lb = int(os.environ.get("EVK_V2_LB", "10"))        # experiment: builds with -DV2_LB=11 take 2048-pixel tiles
+        if a + b <= lb and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= L.evk_voxel2_max_tiles() and planes * 8 << (a + b) <= (65536 if lb == 10 else 153600):
             return a, b
     return None
 
