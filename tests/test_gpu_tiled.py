@@ -74,6 +74,22 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
     close(v.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("knobs", [{"EVK_SHARE_CU": "1"}, {"EVK_V2_XCD_ORDER": "0"}, {"EVK_VOXEL_PATH": "v1"},
+                                   {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}])
+def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
+    """The voxel fast path under its run-time switches: the partition geometry a multi-rank job gets (8 K-event
+    sub-chunks, room for a collective's workgroups), plain work-item order, and the round-1 three-pass path."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for (n, H, W, B, seed) in ((700_001, 480, 640, 5, 3), (90_000, 100, 130, 3, 4)):
+        x, y, t, p = _events(seed, n, H, W)
+        x[: n // 3] = 7; y[: n // 3] = 9                          # a hot pixel: split tiles
+        ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+        v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W))
+        close(v.cpu().numpy(), ref)
+    E.check_errors()
+
+
 def test_voxel_tiled_errors_and_wrap(E, monkeypatch):
     n, H, W = 2000, 40, 60
     x, y, t, p = _events(1, n, H, W)
