@@ -550,21 +550,27 @@ static V2Config v2_config_env() {
         if (const char *s = getenv("EVK_V2_U")) c.u = atoi(s) == 2 ? 2 : (atoi(s) == 8 ? 8 : 4);
         return c;
 }
-// share = leave LDS for the workgroups of ANOTHER kernel on every CU (an overlapped RCCL collective): sub-chunks of 8 K
-// events (64 KB of sorted records instead of 128 KB), still one partition workgroup per CU
-static const V2Config &v2_config(bool share = false) {
+// Geometry of one call.  Without EVK_V2_PART: sub-chunks of 8 K events ("1024x8s": 51 us at 10 M events, 105 registers:
+// LDS and registers left for the workgroups of another kernel, e.g. an overlapped RCCL collective) unless the tile kernel
+// would then pull segments shorter than ~12 records -- more than 680 tiles, e.g. 1280x720 -- and the call does not have
+// to share its CUs (`share`, EVK_VOXEL2_SHARE_CU: multi-rank jobs): then 12 K events ("1024x12s").  Measured, 10 M events
+// 640x480 (600 tiles): 0.092 ms with 8 K vs 0.095 with 12 K; 50 M events 1280x720 (920 tiles): 0.464 vs 0.443 ms.
+static const V2Config &v2_config(bool share = false, int ntiles = 0) {
+    static const bool forced = getenv("EVK_V2_PART") != nullptr;
     static const V2Config base = v2_config_env();
-    static const V2Config shared = [] {
+    static const V2Config small = [] {
         V2Config c = base;
         c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
         return c;
     }();
-    return share ? shared : base;
+    if (share) return small;
+    if (forced) return base;
+    return ntiles > 680 ? base : small;
 }
 #define V2_MIN_SUBCHUNK 8192
 
 static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
-    const V2Config &c = v2_config(share);
+    const V2Config &c = v2_config(share, ntiles);
     const int64_t smax = (int64_t)c.threads * c.ept;
     int64_t nblk = (n + V2_MIN_SUBCHUNK - 1) / V2_MIN_SUBCHUNK;
     const int64_t maxblk = (int64_t)EVK_NUM_CU * c.blocks_per_cu;
@@ -668,7 +674,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     float *pw = (float *)(sb + L.pw);
     float *staging = (float *)(sb + L.staging);
     hipStream_t s = (hipStream_t)stream;
-    const V2Config &cfg = v2_config(share);
+    const V2Config &cfg = v2_config(share, ntiles);
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
