@@ -38,6 +38,9 @@ namespace evk {
 // ablation builds (tools/v2_ablate.sh): stop the partition kernel's per-sub-chunk work after stage A (0 loads, 1 ranks,
 // 2 scan + table, 3 placement, 4 = everything) / the tile kernel's after stage B (0 table entries, 1 record loads,
 // 2 decode, 3 = everything).  Results are wrong below the last stage; timing only.
+#ifndef V2_TILES_MIN_WAVES
+#define V2_TILES_MIN_WAVES 6  // waves per SIMD the tile kernel must fit (<= 80 registers): 3 workgroups of 8 waves per CU
+#endif
 #ifndef V2_XY_PREFETCH
 #define V2_XY_PREFETCH 1   // load x, y of sub-chunk j + 1 before the placement of j (else at the top of j + 1)
 #endif
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 // records (clustered scenes) are streamed by the whole wave instead.
 #define V2_CHUNK_CAP 512  // 64 segments x <= 8 chunks
 template <int WG, int U, bool SPLIT>
-__global__ void __launch_bounds__(WG) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
+__global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGrid g, Part2 q, int B, int flags, float *__restrict__ vox,
                                                      float *__restrict__ staging) {
