@@ -341,7 +341,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     const int NB = split ? 2 * B : B;
     const float bm1 = (float)(B - 1);
     extern __shared__ __attribute__((aligned(16))) acc_t acc[];
-    __shared__ unsigned short cseg[NW][V2_CHUNK_CAP];
+    // chunk list of every wave: {first record of the chunk (even) | 1 if that record lies before the segment, end of the
+    // segment}: ONE LDS read gives a lane group everything it needs for its load (a 2-byte (segment, chunk) entry followed
+    // by a ds_bpermute of the table entry put two dependent LDS round trips, queued behind other waves' atomics, in front
+    // of every load)
+    __shared__ uint2 cseg[NW][V2_CHUNK_CAP];
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
     const uint32_t nitems = part_start[ntiles];
@@ -434,9 +438,12 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         }
         const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
         __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
-        for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = (unsigned short)(lane | (k << 6));
-        __syncthreads();
         const uint32_t wbase = (uint32_t)(base + wave * 64);  // sub-chunk of lane 0's entry
+        {
+            const uint32_t rb = (wbase + lane) * (uint32_t)q.S, p0 = rb + (start & ~1u), e0 = rb + start + cnt;
+            for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
+        }
+        __syncthreads();
         // chunk rounds: U loads per lane in flight, then accumulated (double-buffering them measured slower: 60 vs 46 us).
         // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
         // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
@@ -445,14 +452,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t j = j0 + 16u * u + grp;
-                const uint32_t cs = j < total ? cseg[wave][j] : 0u;
-                const int s = cs & 63u;
-                const uint32_t e2 = __shfl(ent, s, 64);
-                const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
-                const uint32_t rb = (wbase + s) * (uint32_t)q.S;
-                beg[u] = rb + st;
-                end[u] = j < total ? beg[u] + cn : 0u;
-                pos[u] = rb + (st & ~1u) + 8u * (cs >> 6) + 2u * sub;
+                const uint2 cs = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
+                pos[u] = (cs.x & ~1u) + 2u * sub;
+                beg[u] = (cs.x & ~1u) + (cs.x & 1u);   // == the segment's first record when it lies inside this chunk
+                end[u] = cs.y;
                 if (pos[u] < end[u]) v[u] = *reinterpret_cast<const uint4 *>(rec + pos[u]);
             }
         };
