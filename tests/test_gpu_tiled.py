@@ -359,3 +359,45 @@ def test_neg_pos_voxel_edge_cases(E):
     x[11] = W + 2.0
     with pytest.raises(IndexError):
         V.events_to_neg_pos_voxel_torch(*cols(), B, sensor_size=(H, W))
+
+
+def test_objective_at_1080p_and_three_planes(E):
+    """1080p canvases have more 32x32 blur tiles x planes than the reduction scratch has slots (34 * 61 * 3 = 6222 > 4096):
+    the fused post-pass strides over the tiles instead of refusing the launch.  The three-flow pass of the numeric gradient
+    must equal three separate evaluations, and the single evaluation the oracle."""
+    H, W, n = 1080, 1920, 600_000
+    x, y, t, p = _events(5, n, H, W, real=True)
+    obj = E.variance_objective()
+    obj.sensor_size = (H, W)
+    w, prm = E.linvel_warp(), np.array([25.0, -40.0])
+    f0, g = obj.evaluate_function_and_numeric_gradient(prm, x, y, t, p, w, (H, W), 1.0)
+    fs = [float(obj.evaluate_function(prm + d, x, y, t, p, w, (H, W), 1.0)) for d in (np.zeros(2), np.array([1., 0.]), np.array([0., 1.]))]
+    assert abs(float(f0) - fs[0]) <= 2e-6 * abs(fs[0])
+    assert np.abs(np.asarray(g) - np.array([fs[1] - fs[0], fs[2] - fs[0]])).max() <= 2e-5 * abs(fs[0])
+    robj = R.variance_objective(); robj.sensor_size = (H, W); robj.accum = "f64"
+    fr = float(robj.evaluate_function(prm, *(f64(a) for a in (x, y, t, p)), R.linvel_warp(), (H, W), 1.0))
+    assert abs(fs[0] - fr) <= 1e-5 * abs(fr)
+
+
+def test_a_subclass_that_overrides_warp_is_called(E):
+    """The fused linear-flow kernels replace linvel_warp.warp only for that very method: a plugin that subclasses
+    linvel_warp and overrides warp() goes through the generic path with ITS warp."""
+    H, W, n = 120, 160, 200_000
+    x, y, t, p = _events(9, n, H, W, real=True)
+    calls = []
+
+    class doubled(E.linvel_warp):
+        def warp(self, xs, ys, ts, ps, t0, params, compute_grad=False):
+            calls.append(1)
+            return super().warp(xs, ys, ts, ps, t0, 2.0 * np.asarray(params), compute_grad)
+
+    class renamed(E.linvel_warp):      # no override: still the fused kernels
+        pass
+    prm = np.array([20.0, -10.0])
+    d = [f64(a) for a in (x, y, t, p)]
+    iwe, _ = E.get_iwe(prm, *d, doubled(), (H, W), sensor_size=(H, W))
+    ref, _ = R.get_iwe(2.0 * prm, *d, R.linvel_warp(), (H, W), sensor_size=(H, W), accum="f64")
+    assert calls and np.abs(f64(iwe) - ref).max() <= 1e-5 * np.abs(ref).max()
+    iwe2, _ = E.get_iwe(prm, *d, renamed(), (H, W), sensor_size=(H, W))
+    ref2, _ = R.get_iwe(prm, *d, R.linvel_warp(), (H, W), sensor_size=(H, W), accum="f64")
+    assert np.abs(f64(iwe2) - ref2).max() <= 1e-5 * np.abs(ref2).max()
