@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
 EVK_IWE_PACK32 = 8
+EVK_IWE_COMPACT = 16
 EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE, EVK_POST_NONE = 1, 2, 4, 8
 EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
 EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
@@ -68,6 +69,7 @@ SIGNATURES = {
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],
+    "evk_compact_records_f32": [P, c_int64, c_int, c_int, c_int, c_int, P, P, P],
     "evk_allreduce_f32": [P, c_int64, P, P],
     "evk_allreduce_i32": [P, c_int64, P, P],
     "evk_iwe_linvel_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_double,
@@ -79,6 +81,7 @@ _SPECIAL = {
     "evk_error_string": ([c_int], c_char_p),
     "evk_reduce_scratch_bytes": ([], c_int64),
     "evk_bucket_scratch_bytes": ([c_int], c_int64),
+    "evk_compact_records_bytes": ([c_int64], c_int64),
     "evk_iwe_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int, c_int], c_int64),
     "evk_voxel_tiled_staging_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
     "evk_bucket_index_len": ([c_int, c_int64], c_int64),

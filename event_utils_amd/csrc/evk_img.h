@@ -40,9 +40,18 @@ __device__ __forceinline__ void block_sum(double (&acc)[K], double *partial_out)
 }
 
 // WIDE: additionally out[4..7] = the raw sums tot[1..4] (generic objectives); stride of `out` per plane stays 4 or 8.
+// host_slot / host_flag (optional, pinned host memory): the block also stores its 4 results at host_slot[4 * plane ..] and
+// then `seq` at host_flag[plane] (system-scope release), so that a host thread polling the flag has the results without
+// a copy command or a stream synchronisation (evk_cmax.hip).
+struct HostPublish {
+    double *slot;
+    uint32_t *flag;
+    uint32_t seq;
+};
 template <int MODE, bool WIDE = false>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
-                                                            int64_t n, double *__restrict__ out) {
+                                                            int64_t n, double *__restrict__ out,
+                                                            HostPublish pub = HostPublish{nullptr, nullptr, 0u}) {
     double acc[EVK_REDUCE_K] = {};
     partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
     out += (WIDE ? 8 : 4) * blockIdx.x;
@@ -77,6 +86,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
         }
         if constexpr (WIDE && MODE == 1) {  // gradient sums: [.., .., mean, sum g, sum d0, sum d1, sum g d0, sum g d1]
             out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
+        }
+        if (pub.slot) {
+            for (int k = 0; k < 4; ++k)
+                __hip_atomic_store(pub.slot + 4 * blockIdx.x + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub.flag + blockIdx.x, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

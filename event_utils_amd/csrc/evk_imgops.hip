@@ -228,9 +228,10 @@ extern "C" int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_
 template <int MODE>
 static int launch_post(const float *iwe, const float *diwe, int h, int w, const double *host_weights, int radius,
                        uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream,
-                       int nplanes = 1) {
+                       int nplanes = 1, const HostPublish *pub = nullptr, bool *published = nullptr) {
     if (!iwe || h <= 0 || w <= 0 || !out || !scratch || (MODE == 1 && !diwe) || nplanes < 1 || nplanes > 8)
         return EVK_EINVAL;
+    if (published) *published = false;
     if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
     static const double identity[1] = {1.0};
     if (MODE == 3 && radius < 0) host_weights = identity, radius = 0, flags &= ~EVK_POST_MIX;  // no blur = 1-tap kernel
@@ -254,8 +255,26 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     PostParams pp;
     pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr;
     k_post_fused<MODE><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
-    k_reduce_final<MODE><<<nplanes, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out);
+    const bool publish = pub && pub->slot && pub->flag && nplanes <= 3;
+    k_reduce_final<MODE><<<nplanes, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out,
+                                                      publish ? *pub : HostPublish{nullptr, nullptr, 0u});
+    if (published) *published = publish;
     return launch_status();
+}
+
+// evk_cmax.hip: the post-pass of the one-call evaluation; mode 0 value (nplanes images), 1 gradient, 3 value + gradient.
+// *published tells whether the finalise kernel also delivers the results to pub (it does on the blurred path).
+int evk_post_variance_publish(int mode, const float *iwe, const float *diwe, int h, int w, const double *host_weights,
+                              int radius, uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream,
+                              int nplanes, const HostPublish *pub, bool *published) {
+    if (mode == 0)
+        return launch_post<0>(iwe, nullptr, h, w, host_weights, radius, 0u, out, scratch, scratch_bytes, stream, nplanes, pub,
+                              published);
+    if (mode == 1)
+        return launch_post<1>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream, 1, pub, published);
+    if (mode == 3)
+        return launch_post<3>(iwe, diwe, h, w, host_weights, radius, flags, out, scratch, scratch_bytes, stream, 1, pub, published);
+    return EVK_EINVAL;
 }
 
 extern "C" int evk_objective_variance_f32(const float *iwe, int h, int w, const double *host_weights, int radius,

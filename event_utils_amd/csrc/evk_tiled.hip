@@ -331,6 +331,57 @@ __device__ __forceinline__ void stream_records(const float4 *__restrict__ rec, u
     for (; i < hi; i += EVK_BLOCK) f(rec[i]);
 }
 
+// COMPACT records (8 bytes, evk_compact_records_f32): {t (float32 bits), polarity bits [31:11] | pixel in tile [9:0]}.
+// Events whose x, y are integers inside the domain (sensor pixels) and whose polarity has its low 11 mantissa bits zero
+// (+-1, 0, small integers, halves ...) lose nothing: x, y come back from the tile origin, which the work item knows.
+#define EVK_REC_LOCAL_MASK 0x3FFu
+#define EVK_REC_P_MASK 0xFFFFF800u
+// Streams compact records [lo, hi): a lane takes PAIRS (one 16-byte load = records 2j, 2j + 1), 4 loads in flight; the
+// pair straddling lo / hi is loaded whole (the buffer is padded to an even count) and the outsiders skipped.
+template <typename F>
+__device__ __forceinline__ void stream_records8(const uint2 *__restrict__ rec, uint32_t lo, uint32_t hi, F f) {
+    const uint4 *pairs = reinterpret_cast<const uint4 *>(rec);
+    const uint32_t jend = (hi + 1u) >> 1;
+    auto two = [&](const uint4 &v, uint32_t j) {
+        const uint32_t pos = 2u * j;
+        if (pos >= lo) f(make_uint2(v.x, v.y));
+        if (pos + 1u < hi) f(make_uint2(v.z, v.w));
+    };
+    uint32_t j = (lo >> 1) + threadIdx.x;
+    if (hi <= lo) return;
+    for (; j + 3 * EVK_BLOCK < jend; j += 4 * EVK_BLOCK) {
+        const uint4 r0 = pairs[j], r1 = pairs[j + EVK_BLOCK], r2 = pairs[j + 2 * EVK_BLOCK], r3 = pairs[j + 3 * EVK_BLOCK];
+        two(r0, j), two(r1, j + EVK_BLOCK), two(r2, j + 2 * EVK_BLOCK), two(r3, j + 3 * EVK_BLOCK);
+    }
+    for (; j < jend; j += EVK_BLOCK) two(pairs[j], j);
+}
+
+// float4 records -> compact records, same order (record i -> compact record i); *not_compact |= 1 when some record is
+// not representable (non-integer or out-of-domain coordinates, a polarity with low mantissa bits): the caller then
+// keeps the 16-byte records.
+__global__ void __launch_bounds__(EVK_BLOCK) k_compact_records(const float4 *__restrict__ rec, int64_t n, TileGrid g,
+                                                               uint2 *__restrict__ out, uint32_t *__restrict__ not_compact) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    auto conv = [&](const float4 &r) -> uint2 {
+        const float fx = floorf(r.x), fy = floorf(r.y);
+        const uint32_t pb = __float_as_uint(r.w);
+        if (!(fx == r.x && fy == r.y && fx >= 0.0f && fy >= 0.0f && fx <= (float)(g.dom_w - 1) && fy <= (float)(g.dom_h - 1)) ||
+            (pb & ~EVK_REC_P_MASK))
+            bad = true;
+        const int xi = (int)fx, yi = (int)fy;
+        const uint32_t local = (uint32_t)(((yi & ((1 << g.th_log2) - 1)) << g.tw_log2) | (xi & ((1 << g.tw_log2) - 1)));
+        return make_uint2(__float_as_uint(r.z), (pb & EVK_REC_P_MASK) | (local & EVK_REC_LOCAL_MASK));
+    };
+    const int64_t npairs = (n + 1) >> 1;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npairs; j += stride) {
+        const uint2 a = conv(rec[2 * j]);
+        const uint2 b = 2 * j + 1 < n ? conv(rec[2 * j + 1]) : make_uint2(0u, 0u);
+        reinterpret_cast<uint4 *>(out)[j] = make_uint4(a.x, a.y, b.x, b.y);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(not_compact, 1u);
+}
+
 // flags: EVK_VOXEL_OVERWRITE; EVK_VOXEL_SPLIT_POLARITY: two grids in one pass, vox = (2, B, h, w): [0] counts the
 // events with p > 0, [1] those with p <= 0, each with weight 1 (events_to_neg_pos_voxel_torch, voxel_grid.py:172-180).
 __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restrict__ rec, uint32_t *__restrict__ index,
@@ -485,6 +536,9 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
 // 2^10 concurrent adds cannot carry a field from 2^30 past 2^31); only such hot pixels lose run-to-run bit
 // reproducibility.
 #define EVK_PAIR_SHIFT 20
+#ifndef EVK_PACK_F
+#define EVK_PACK_F 0  // experiment: packed pairs for the function-only mode too
+#endif
 struct PairOverflow {  // where the two cells of a word live in the output image, for the rare drain
     float *lo_minus, *lo_plus, *hi_minus, *hi_plus;  // value is added to *_plus and subtracted from *_minus (nullptr: skip)
 };
@@ -520,7 +574,7 @@ __device__ __forceinline__ long long pair_cell(const unsigned long long *line, i
 #ifndef IWE_ABLATE
 #define IWE_ABLATE 99  // ablation builds (timing only): 0 record loads only, 1 + per-event arithmetic without LDS atomics
 #endif
-template <int MODE, int FIXED>
+template <int MODE, int FIXED, bool COMPACT>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restrict__ rec,
                                                          const uint32_t *__restrict__ index, TileGrid g,
                                                          IweParams q, float *__restrict__ staging,
@@ -547,7 +601,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
     int wx0 = 0, wy0 = 0;
     if (hi > lo) {
-        const double ta = (double)rec[lo].z - q.t_ref, tb = (double)rec[hi - 1].z - q.t_ref;
+        const uint2 *rec8 = reinterpret_cast<const uint2 *>(rec);
+        const double ta = (double)(COMPACT ? __uint_as_float(rec8[lo].x) : rec[lo].z) - q.t_ref;
+        const double tb = (double)(COMPACT ? __uint_as_float(rec8[hi - 1].x) : rec[hi - 1].z) - q.t_ref;
         double dxm = fmin(-ta * q.vx, -tb * q.vx), dym = fmin(-ta * q.vy, -tb * q.vy);
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -658,7 +714,17 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             splat(r, q.vxb[1], q.vyb[1], win + 2 * wcells, diwe + plane);
         }
     };
-    stream_records(rec, lo, hi, one);
+    if constexpr (COMPACT) {
+        const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+        const uint32_t twm = (1u << g.tw_log2) - 1u;
+        stream_records8(reinterpret_cast<const uint2 *>(rec), lo, hi, [&](const uint2 &c) {
+            const uint32_t local = c.y & EVK_REC_LOCAL_MASK;
+            one(make_float4((float)(tx0 + (int)(local & twm)), (float)(ty0 + (int)(local >> g.tw_log2)), __uint_as_float(c.x),
+                            __uint_as_float(c.y & EVK_REC_P_MASK)));
+        });
+    } else {
+        stream_records(rec, lo, hi, one);
+    }
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
     // cell value / difference of two cells as float (exact integer difference on the fixed-point path)
@@ -931,6 +997,21 @@ extern "C" int evk_bucket_events_native_f32(const int16_t *x, const int16_t *y, 
                          stages, stream);
 }
 
+extern "C" int64_t evk_compact_records_bytes(int64_t n) { return n < 0 ? 0 : ((n + 1) & ~(int64_t)1) * 8; }
+
+extern "C" int evk_compact_records_f32(const float *records, int64_t n, int dom_h, int dom_w, int tw_log2, int th_log2,
+                                       void *compact, uint32_t *not_compact, void *stream) {
+    TileGrid g;
+    if (make_grid(g, dom_h, dom_w, tw_log2, th_log2) != EVK_OK || n < 0 || !not_compact || (n > 0 && (!records || !compact)))
+        return EVK_EINVAL;
+    if ((1 << (tw_log2 + th_log2)) > (int)EVK_REC_LOCAL_MASK + 1) return EVK_EINVAL;
+    if (!aligned16(records) || !aligned16(compact)) return EVK_EALIGN;
+    if (n == 0) return EVK_OK;
+    k_compact_records<<<stream_grid((n + 1) >> 1), EVK_BLOCK, 0, (hipStream_t)stream>>>(
+        (const float4 *)records, n, g, (uint2 *)compact, not_compact);
+    return launch_status();
+}
+
 // native columns -> four float32 SoA columns (any alignment): the direct kernels' input, 13 B read + 16 B written
 __global__ void __launch_bounds__(EVK_BLOCK) k_native_to_columns(const ColsNative c, int64_t n, float *__restrict__ x,
                                                                  float *__restrict__ y, float *__restrict__ t,
@@ -1018,7 +1099,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     const double acc_bound = (p_bound > 0.0 && dt_bound >= 0.0) ? (double)n * p_bound * fmax(1.0, dt_bound) : 0.0;
     bool pack32 = false;
     q.pair_sI = q.pair_sE = q.pair_invI = q.pair_invE = 1.0f;
-    if ((flags & EVK_IWE_PACK32) && mode != 0 && acc_bound > 0.0 && acc_bound < 1e300 && win_w % 2 == 0 && win_h % 2 == 0) {
+    if ((flags & EVK_IWE_PACK32) && (mode != 0 || EVK_PACK_F) && acc_bound > 0.0 && acc_bound < 1e300 && win_w % 2 == 0 && win_h % 2 == 0) {
         int eI, eE;
         (void)frexp(p_bound * 1.0000002, &eI);                          // p_bound < 2^eI
         (void)frexp(fmax(p_bound * dt_bound, 1e-30) * 1.0000002, &eE);
@@ -1048,6 +1129,8 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     hipStream_t s = (hipStream_t)stream;
     const int ggrid = ((canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX) * ((canvas_h + EVK_GATHER_PY - 1) / EVK_GATHER_PY);
     const float4 *rec = (const float4 *)records;
+    const bool compact = (flags & EVK_IWE_COMPACT) != 0;  // `records` are 8-byte compact records
+    if (compact && ((1 << (tw_log2 + th_log2)) > (int)EVK_REC_LOCAL_MASK + 1 || !aligned16(records))) return EVK_EINVAL;
     // spill pair: the kernel's global atomics (events outside their window) go to `spill` and the gather WRITES
     // out = spill + windows (no memset of the output), zeroing what the previous call left in `spill_clean`
     float *out_iwe = iwe, *out_diwe = diwe;
@@ -1055,11 +1138,16 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
         iwe = const_cast<float *>(spill);
         diwe = iwe + (size_t)canvas_h * canvas_w;
     }
+#define EVK_IWE_LAUNCH_C(M, C)                                                                                     \
+    do {                                                                                                           \
+        if (pack32) k_iwe_tiled<M, 2, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
+        else if (fixed) k_iwe_tiled<M, 1, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
+        else k_iwe_tiled<M, 0, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
+    } while (0)
 #define EVK_IWE_LAUNCH(M)                                                                                          \
     do {                                                                                                           \
-        if (pack32) k_iwe_tiled<M, 2><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
-        else if (fixed) k_iwe_tiled<M, 1><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
-        else k_iwe_tiled<M, 0><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);      \
+        if (compact) EVK_IWE_LAUNCH_C(M, true);                                                                    \
+        else EVK_IWE_LAUNCH_C(M, false);                                                                           \
     } while (0)
     if (mode == 0) {
         EVK_IWE_LAUNCH(0);
@@ -1074,6 +1162,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
                                                       spill, spill_clean);
     }
 #undef EVK_IWE_LAUNCH
+#undef EVK_IWE_LAUNCH_C
     return launch_status();
 }
 

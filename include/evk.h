@@ -354,6 +354,18 @@ int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, con
  *     workgroup) is drained into the image with global atomics, so nothing overflows.
  * Quantisation <= 2^-(k+1) per contribution for the 64-bit cells.  Without bounds: float64 accumulation. */
 #define EVK_IWE_PACK32 8u
+/* COMPACT RECORDS.  The evaluation kernels stream the bucketed records once per evaluation, and an optimisation evaluates
+ * ~10^2 times, so the record stream is what the function evaluation is bound by.  Sensor events have integer pixel
+ * coordinates and +-1 polarities: evk_compact_records_f32 rewrites the (x, y, t, p) float32 records of a bucketing
+ * (EVK_KEY_FLOOR_CLAMP, tiles of <= 1024 pixels) as 8-byte records {t, polarity bits [31:11] | pixel in tile [9:0]} in the
+ * same order, and ORs 1 into *not_compact if some record does not survive that exactly (non-integer or out-of-domain
+ * x / y, a polarity with any of its low 11 mantissa bits set).  When *not_compact stays 0 the tiled IWE entry points take
+ * the compact buffer as `records` with EVK_IWE_COMPACT in `flags`: x, y are rebuilt from the tile origin, every
+ * result is bit-identical to the 16-byte records'.  `compact` holds evk_compact_records_bytes(n) bytes, 16-byte aligned. */
+#define EVK_IWE_COMPACT 16u
+int64_t evk_compact_records_bytes(int64_t n);
+int evk_compact_records_f32(const float *records, int64_t n, int dom_h, int dom_w, int tw_log2, int th_log2,
+                            void *compact, uint32_t *not_compact, void *stream);
 int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h);
 int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                              int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref,

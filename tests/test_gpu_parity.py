@@ -455,7 +455,9 @@ def test_value_and_gradient_in_one_pass_equal_the_separate_calls(E, golden, exac
             f1 = obj.evaluate_function(np.array(prm), ev, None, None, None, w, (H, W), s)
             g1 = obj.evaluate_gradient(np.array(prm), ev, None, None, None, w, (H, W), s)
             assert abs(float(fv) - float(f1)) <= 2e-6 * abs(float(f1))
-            assert np.max(np.abs(f64(gv) - f64(g1))) <= 2e-6 * np.max(np.abs(f64(g1))) + 1e-12
+            # (floor: a gradient of ~1e-6 is the rounding residue of sums of O(1e-2) terms, and below the tiled crossover
+            # the float atomics of the direct kernel make two evaluations differ in the last bits)
+            assert np.max(np.abs(f64(gv) - f64(g1))) <= 2e-6 * np.max(np.abs(f64(g1))) + 1e-10
     if exact and n == 30_000:
         g8 = golden("f8_objective")
         xs, ys, ts, ps = f64(g8["xs"]), f64(g8["ys"]), f64(g8["ts"]), f64(g8["ps"])

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import reference_np as R
+from event_utils_amd import _lib
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -401,3 +402,57 @@ def test_a_subclass_that_overrides_warp_is_called(E):
     iwe2, _ = E.get_iwe(prm, *d, renamed(), (H, W), sensor_size=(H, W))
     ref2, _ = R.get_iwe(prm, *d, R.linvel_warp(), (H, W), sensor_size=(H, W), accum="f64")
     assert np.abs(f64(iwe2) - ref2).max() <= 1e-5 * np.abs(ref2).max()
+
+
+@pytest.mark.parametrize("sensor", [(180, 240), (720, 1280)])
+def test_compact_records_are_bit_identical(E, sensor, monkeypatch):
+    """EVK_IWE_COMPACT: sensor events (integer pixels, +-1 polarity) bucketed into 8-byte records give the same IWE, dIWE
+    and three-flow images as the 16-byte records, bit for bit (x, y are rebuilt from the tile origin)."""
+    H, W = sensor
+    n = 700_001
+    rng = np.random.default_rng(31)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    x[: n // 3] = 7 + x[: n // 3] % 5         # a hot spot: split tiles, odd record ranges
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = rng.choice(np.array([-1.0, 1.0, 0.5, 0.0, -3.0], dtype=np.float32), n)
+    out = {}
+    for mode in ("full", "compact"):
+        monkeypatch.setenv("EVK_IWE_RECORDS", mode)
+        ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+        obj = E.variance_objective(); obj.sensor_size = (H, W); obj.impl = "tiled"
+        prm = np.array([55.0, -35.0])
+        iwe, d = E.get_iwe(prm, ev, None, None, None, E.linvel_warp(), (H, W), sensor_size=(H, W), compute_gradient=True)
+        fg = obj.evaluate_function_and_numeric_gradient(prm, ev, None, None, None, E.linvel_warp(), (H, W), 1.0)
+        flags = [b.iwe_flag for b in ev._buckets.values()]
+        assert flags and all(f == (_lib.EVK_IWE_COMPACT if mode == "compact" else 0) for f in flags)
+        out[mode] = (np.asarray(iwe), np.asarray(d), float(fg[0]), np.asarray(fg[1]))
+    a, b = out["full"], out["compact"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    ref, _ = R.get_iwe(np.array([55.0, -35.0]), *(f64(v) for v in (x, y, t, p)), R.linvel_warp(), (H, W), sensor_size=(H, W),
+                       accum="f64")
+    assert np.abs(f64(b[0]) - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("spoil", ["subpixel", "outside", "polarity"])
+def test_events_that_do_not_compact_keep_their_records(E, spoil, monkeypatch):
+    """One event with a sub-pixel coordinate, a coordinate outside the domain or a polarity with low mantissa bits: the
+    bucketing keeps the 16-byte records (the verdict of evk_compact_records_f32), results as before."""
+    monkeypatch.setenv("EVK_IWE_RECORDS", "compact")
+    H, W, n = 180, 240, 300_000
+    rng = np.random.default_rng(33)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    if spoil == "subpixel":
+        y[12345] += 0.25
+    elif spoil == "outside":
+        x[777] = W + 3.0
+    else:
+        p[n - 1] = np.float32(0.1)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    iwe, _ = E.get_iwe(np.array([40.0, 10.0]), ev, None, None, None, E.linvel_warp(), (H, W), sensor_size=(H, W))
+    assert [b.iwe_flag for b in ev._buckets.values()] == [0]
+    ref, _ = R.get_iwe(np.array([40.0, 10.0]), *(f64(v) for v in (x, y, t, p)), R.linvel_warp(), (H, W), sensor_size=(H, W),
+                       accum="f64")
+    assert np.abs(f64(np.asarray(iwe)) - ref).max() <= 1e-5 * np.abs(ref).max()
