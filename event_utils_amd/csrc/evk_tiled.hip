@@ -119,14 +119,14 @@ __global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__
 #define IDX_ITEM(T) (3 * (T) + 2)
 
 __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__restrict__ totals, int ntiles,
-                                                           uint32_t cap, uint32_t *__restrict__ index) {
+                                                           uint32_t cap, uint32_t budget, uint32_t *__restrict__ index) {
     __shared__ uint32_t part[1024];
     uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *counters = index + IDX_COUNTER(ntiles),
              *item_tile = index + IDX_ITEM(ntiles);
     const int per = (ntiles + 1023) / 1024;
     const int i0 = threadIdx.x * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto block_exclusive = [&](uint32_t mine) -> uint32_t {  // wave shuffle scans + one scan of the 16 wave totals
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         uint32_t incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -149,11 +149,51 @@ __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__res
         __syncthreads();
         return ex;
     };
-    uint32_t s = 0, np = 0;
+    auto block_reduce = [&](uint32_t v, bool take_max) -> uint32_t {  // sum or max over the workgroup, to every thread
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = __shfl_xor(v, off, 64);
+            v = take_max ? (o > v ? o : v) : v + o;
+        }
+        if (lane == 0) part[wave] = v;
+        __syncthreads();
+        uint32_t r = part[0];
+        for (int k = 1; k < 16; ++k) r = take_max ? (part[k] > r ? part[k] : r) : r + part[k];
+        __syncthreads();
+        return r;
+    };
+    uint32_t s = 0, mx = 0;
     for (int i = i0; i < i1; ++i) {
         s += totals[i];
-        np += totals[i] > cap ? (totals[i] + cap - 1) / cap : 1u;
+        mx = totals[i] > mx ? totals[i] : mx;
     }
+    // ---- balance (see bucket_item_budget): a non-uniform scene gets the smallest split threshold the budget allows
+    const uint32_t total = block_reduce(s, false), fullest = block_reduce(mx, true);
+    const uint32_t mean = total / (uint32_t)ntiles;
+    if (budget && (uint64_t)fullest * 4u > (uint64_t)mean * 5u) {
+        auto items_at = [&](uint32_t c) -> uint32_t {
+            uint32_t np = 0;
+            for (int i = i0; i < i1; ++i) np += totals[i] > c ? (totals[i] + c - 1) / c : 1u;
+            return block_reduce(np, false);
+        };
+        uint32_t lo = mean / 8u * 5u;
+        lo = lo > 4096u ? lo : 4096u;
+        if (lo < cap) {
+            if (items_at(lo) <= budget) {
+                cap = lo;
+            } else {
+                uint32_t hi = cap;  // items_at(cap) <= ntiles + ntiles / 4 <= budget
+                while (hi - lo > 64u) {
+                    const uint32_t mid = lo + (hi - lo) / 2u;
+                    if (items_at(mid) <= budget) hi = mid;
+                    else lo = mid;
+                }
+                cap = hi;
+            }
+        }
+    }
+    uint32_t np = 0;
+    for (int i = i0; i < i1; ++i) np += totals[i] > cap ? (totals[i] + cap - 1) / cap : 1u;
     uint32_t run = block_exclusive(s);
     for (int i = i0; i < i1; ++i) {
         bucket_start[i] = run;
@@ -899,10 +939,10 @@ extern "C" int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_lo
 
 extern "C" int64_t evk_bucket_index_len(int ntiles, int64_t n) {
     if (ntiles <= 0 || n < 0) return 0;
-    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items(n, ntiles);
+    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles);
 }
 
-extern "C" int evk_bucket_max_items(int ntiles, int64_t n) { return ntiles > 0 && n >= 0 ? bucket_max_items(n, ntiles) : 0; }
+extern "C" int evk_bucket_max_items(int ntiles, int64_t n) { return ntiles > 0 && n >= 0 ? bucket_max_items_balanced(n, ntiles) : 0; }
 
 extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
     if (ntiles <= 0) return 0;
@@ -945,9 +985,11 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     const size_t lds = (size_t)ntiles * sizeof(uint32_t);
     if (stages & EVK_STAGE_HIST)
         k_tile_hist<C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob);
+    static const bool balance = !(getenv("EVK_BUCKET_BALANCE") && atoi(getenv("EVK_BUCKET_BALANCE")) == 0);  // A/B switch
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
-        k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles), bucket_start);
+        k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles),
+                                              balance ? (uint32_t)bucket_item_budget(ntiles) : 0u, bucket_start);
     }
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
@@ -1034,7 +1076,7 @@ extern "C" int evk_native_to_columns_f32(const int16_t *x, const int16_t *y, int
 }
 
 extern "C" int64_t evk_voxel_tiled_staging_bytes(int ntiles, int64_t n, int B, int tw_log2, int th_log2) {
-    return (int64_t)bucket_max_items(n, ntiles) * ((int64_t)B << (tw_log2 + th_log2)) * (int64_t)sizeof(float);
+    return (int64_t)bucket_max_items_balanced(n, ntiles) * ((int64_t)B << (tw_log2 + th_log2)) * (int64_t)sizeof(float);
 }
 
 extern "C" int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n, int h, int wd, int tw_log2,
@@ -1050,13 +1092,13 @@ extern "C" int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index,
     if (lds > 64 * 1024) return EVK_EINVAL;
     if (staging_bytes < evk_voxel_tiled_staging_bytes(ntiles, n, planes, tw_log2, th_log2)) return EVK_ESCRATCH;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
-    k_voxel_tiled<<<bucket_max_items(n, ntiles), EVK_BLOCK, lds, (hipStream_t)stream>>>(
+    k_voxel_tiled<<<bucket_max_items_balanced(n, ntiles), EVK_BLOCK, lds, (hipStream_t)stream>>>(
         (const float4 *)records, bucket_index, g, t_first, dt, bm1, B, flags, vox, (float *)staging);
     return launch_status();
 }
 
 extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h) {
-    return (int64_t)bucket_max_items(n, ntiles) * slices *
+    return (int64_t)bucket_max_items_balanced(n, ntiles) * slices *
            ((int64_t)planes * win_w * win_h * (int64_t)sizeof(float) + (int64_t)sizeof(int4));
 }
 
@@ -1123,7 +1165,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     const bool fixed = k >= 26;
     q.fx_scale = fixed ? ldexp(1.0, k) : 0.0;
     q.fx_inv = fixed ? ldexp(1.0, -k) : 0.0;
-    const int nwin = bucket_max_items(n, ntiles) * slices;
+    const int nwin = bucket_max_items_balanced(n, ntiles) * slices;
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;

@@ -169,6 +169,15 @@ __host__ __device__ inline int64_t bucket_cap(int64_t n, int ntiles) {
 __host__ __device__ inline int bucket_max_items(int64_t n, int ntiles) {
     return ntiles + (int)(n / bucket_cap(n, ntiles)) + 1;
 }
+// Work-item budget of the three-pass bucketing (evk_tiled.hip), whose plan BALANCES non-uniform scenes: the tile kernels
+// run one workgroup per item, all of them resident at once, so a launch lasts as long as its largest item.  When the
+// fullest tile holds more than 1.25 x the mean, k_tile_scan_totals lowers the split threshold (by bisection, not below
+// max(4096, 5/8 of the mean)) as far as this budget of 2 items per tile allows.
+__host__ __device__ inline int bucket_item_budget(int ntiles) { return 2 * ntiles; }
+__host__ __device__ inline int bucket_max_items_balanced(int64_t n, int ntiles) {
+    const int a = bucket_max_items(n, ntiles), b = bucket_item_budget(ntiles) + 1;
+    return a > b ? a : b;
+}
 static inline int make_grid(TileGrid &g, int dom_h, int dom_w, int tw_log2, int th_log2) {
     if (dom_h <= 0 || dom_w <= 0 || tw_log2 < 2 || tw_log2 > 8 || th_log2 < 2 || th_log2 > 8) return EVK_EINVAL;
     g.tw_log2 = tw_log2;

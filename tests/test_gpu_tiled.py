@@ -404,15 +404,19 @@ def test_a_subclass_that_overrides_warp_is_called(E):
     assert np.abs(f64(iwe2) - ref2).max() <= 1e-5 * np.abs(ref2).max()
 
 
+@pytest.mark.parametrize("hot", [False, True])
 @pytest.mark.parametrize("sensor", [(180, 240), (720, 1280)])
-def test_compact_records_are_bit_identical(E, sensor, monkeypatch):
+def test_compact_records_are_bit_identical(E, sensor, hot, monkeypatch):
     """EVK_IWE_COMPACT: sensor events (integer pixels, +-1 polarity) bucketed into 8-byte records give the same IWE, dIWE
-    and three-flow images as the 16-byte records, bit for bit (x, y are rebuilt from the tile origin)."""
+    and three-flow images as the 16-byte records, bit for bit (x, y are rebuilt from the tile origin).  With a hot spot the
+    plan splits tiles into parts (odd record ranges) whose tight windows a few events leave -- those take float atomics in
+    either mode, so two runs agree to rounding only."""
     H, W = sensor
     n = 700_001
     rng = np.random.default_rng(31)
     x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
-    x[: n // 3] = 7 + x[: n // 3] % 5         # a hot spot: split tiles, odd record ranges
+    if hot:
+        x[: n // 3] = 7 + x[: n // 3] % 5
     t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
     p = rng.choice(np.array([-1.0, 1.0, 0.5, 0.0, -3.0], dtype=np.float32), n)
     out = {}
@@ -427,8 +431,14 @@ def test_compact_records_are_bit_identical(E, sensor, monkeypatch):
         assert flags and all(f == (_lib.EVK_IWE_COMPACT if mode == "compact" else 0) for f in flags)
         out[mode] = (np.asarray(iwe), np.asarray(d), float(fg[0]), np.asarray(fg[1]))
     a, b = out["full"], out["compact"]
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    if hot:
+        for k in (0, 1):
+            assert np.abs(f64(a[k]) - f64(b[k])).max() <= 2e-6 * np.abs(f64(a[k])).max()
+        assert abs(a[2] - b[2]) <= 2e-6 * abs(a[2])
+        assert np.abs(a[3] - b[3]).max() <= 4e-6 * abs(a[2])   # forward differences of f
+    else:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[2] == b[2] and np.array_equal(a[3], b[3])
     ref, _ = R.get_iwe(np.array([55.0, -35.0]), *(f64(v) for v in (x, y, t, p)), R.linvel_warp(), (H, W), sensor_size=(H, W),
                        accum="f64")
     assert np.abs(f64(b[0]) - ref).max() <= 1e-5 * np.abs(ref).max()
