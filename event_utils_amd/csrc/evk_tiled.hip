@@ -113,13 +113,17 @@ __global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__
 //                                  max(1, ceil(count_k / cap)) parts -- a tile hotter than `cap` events is split over
 //                                  several workgroups so that clustered (real) event data cannot serialise on one CU
 //   [2T+2 .. 3T+1]  counters     : per-tile arrival counters of the split-tile combine (self-resetting)
-//   [3T+2 ..]       item_tile    : tile of every work item
+//   [3T+2 ..]       item_tile    : tile of every work item (bucket_max_items_balanced entries)
+//   [last]          scene        : 1 when the fullest tile holds more than 1.25 x the mean (a structured scene: the plan
+//                                  was balanced, and the host picks the accumulators that suffer least from the
+//                                  same-address LDS conflicts of such scenes), else 0
 #define IDX_PART(T) ((T) + 1)
 #define IDX_COUNTER(T) (2 * (T) + 2)
 #define IDX_ITEM(T) (3 * (T) + 2)
 
 __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__restrict__ totals, int ntiles,
-                                                           uint32_t cap, uint32_t budget, uint32_t *__restrict__ index) {
+                                                           uint32_t cap, uint32_t budget, uint32_t *__restrict__ index,
+                                                           uint32_t *__restrict__ scene) {
     __shared__ uint32_t part[1024];
     uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *counters = index + IDX_COUNTER(ntiles),
              *item_tile = index + IDX_ITEM(ntiles);
@@ -170,7 +174,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__res
     // ---- balance (see bucket_item_budget): a non-uniform scene gets the smallest split threshold the budget allows
     const uint32_t total = block_reduce(s, false), fullest = block_reduce(mx, true);
     const uint32_t mean = total / (uint32_t)ntiles;
-    if (budget && (uint64_t)fullest * 4u > (uint64_t)mean * 5u) {
+    const bool structured = (uint64_t)fullest * 4u > (uint64_t)mean * 5u;
+    if (threadIdx.x == 0) *scene = structured ? 1u : 0u;
+    if (budget && structured) {
         auto items_at = [&](uint32_t c) -> uint32_t {
             uint32_t np = 0;
             for (int i = i0; i < i1; ++i) np += totals[i] > c ? (totals[i] + c - 1) / c : 1u;
@@ -939,7 +945,7 @@ extern "C" int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_lo
 
 extern "C" int64_t evk_bucket_index_len(int ntiles, int64_t n) {
     if (ntiles <= 0 || n < 0) return 0;
-    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles);
+    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles) + 1;  // + the scene word
 }
 
 extern "C" int evk_bucket_max_items(int ntiles, int64_t n) { return ntiles > 0 && n >= 0 ? bucket_max_items_balanced(n, ntiles) : 0; }
@@ -989,7 +995,8 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
         k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles),
-                                              balance ? (uint32_t)bucket_item_budget(ntiles) : 0u, bucket_start);
+                                              balance ? (uint32_t)bucket_item_budget(ntiles) : 0u, bucket_start,
+                                              bucket_start + IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles));
     }
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter

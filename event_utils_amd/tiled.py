@@ -58,6 +58,15 @@ class Buckets:
         self.key_mode, self.dom_h, self.dom_w = key_mode, dom_h, dom_w
         self.tw_log2, self.th_log2, self.ntiles = tw_log2, th_log2, ntiles
         self.iwe_flag = 0
+        self._structured = None
+
+    @property
+    def structured(self):
+        """The bucketing's verdict on the scene (last word of the index): True when the fullest tile holds more than 1.25 x
+        the mean tile population.  Read once (one 4-byte copy) and kept."""
+        if self._structured is None:
+            self._structured = bool(int(self.bucket_start[-1].item()))
+        return self._structured
 
     def compact(self):
         """Rewrite the records as 8-byte compact records when that is exact (integer pixel coordinates inside the
@@ -348,14 +357,17 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
         flow = (D.host_ptr(keep[0]), D.host_ptr(keep[1]))
     # bound of any accumulator cell: every event in one pixel, weight |p| * p_scale (* |dt| for the derivative planes);
     # lets the kernel accumulate in 64-bit fixed point (EVK_IWE_FIXED=0 keeps float64 accumulation)
-    # EVK_IWE_FIXED: "0" float64 accumulation, "64" (default) 64-bit fixed-point cells, "32" packed 32-bit pairs for the
-    # gradient / three-flow modes (include/evk.h; measured: -10 % at 50 M events / 720p, +7 % at 10 M / VGA -- the
-    # returning atomics its overflow check needs cost what the halved atomic count saves)
-    p_bound, dt_bound, fixed = 0.0, 0.0, os.environ.get("EVK_IWE_FIXED", "64")
+    # EVK_IWE_FIXED: "0" float64 accumulation, "64" 64-bit fixed-point cells, "32" packed 32-bit pairs for the gradient /
+    # three-flow modes (include/evk.h), "auto" (default) = 64-bit cells, packed pairs where measured faster (below)
+    p_bound, dt_bound, fixed = 0.0, 0.0, os.environ.get("EVK_IWE_FIXED", "auto")
     if fixed != "0":
         p_bound = ev.p_absmax() * abs(float(ev.p_scale))
         dt_bound = max(span, abs(ev.t_at(-1) - t_ref))
-        if fixed == "32":
+        # "auto": packed pairs for the analytic gradient of STRUCTURED scenes, whose events pile up on few cells: there
+        # the same-address conflicts of the LDS atomics dominate and halving their number wins (moving-edge scene,
+        # gradient evaluation: 0.393 -> 0.300 ms at 50 M events / 720p, 0.144 -> 0.126 ms at 10 M / VGA), whereas on
+        # uniform-random events the returning atomics cost more than the halved count saves (0.054 -> 0.066 ms)
+        if fixed == "32" or (fixed == "auto" and batch is None and (flags & _lib.EVK_IWE_GRADIENT) and bk.structured):
             flags = flags | _lib.EVK_IWE_PACK32
     head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
         flow + (bounds_w, bounds_h, ch, cw, flags | bk.iwe_flag, float(ev.p_scale), p_bound, dt_bound)
@@ -405,7 +417,7 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
     evaluation (84 -> 74 us at 10 M events)."""
     import math
     ckey = (t_ref, bounds_w, bounds_h, ch, cw, flags, radius, post_flags, impl or default_impl(), spill_enabled(),
-            os.environ.get("EVK_IWE_FIXED", "64"), os.environ.get("EVK_IWE_RECORDS", "auto"), ev.p_scale)
+            os.environ.get("EVK_IWE_FIXED", "auto"), os.environ.get("EVK_IWE_RECORDS", "auto"), ev.p_scale)
     cache = ev.__dict__.setdefault("_cmax_calls", {})
     c = cache.get(ckey)
     if c is not None and c["buf"] is buf and c["out"] is out and c["scratch"] is scratch and c["weights"] is weights \

@@ -253,7 +253,7 @@ def test_iwe_hot_tiles(E):
         close(iwe, ri); close(diwe, rd)
 
 
-@pytest.mark.parametrize("fixed", ["32", "64", "0"])
+@pytest.mark.parametrize("fixed", ["32", "64", "0", "auto"])
 def test_iwe_accumulator_modes_and_hot_pixel_drain(E, monkeypatch, fixed):
     """The three LDS accumulator modes of the tiled IWE kernel (packed 32-bit pairs, 64-bit fixed point, float64) against
     the oracle -- on uniform events and on a scene whose events all carry the same sign and pile up on a few pixels, so
@@ -466,3 +466,29 @@ def test_events_that_do_not_compact_keep_their_records(E, spoil, monkeypatch):
     ref, _ = R.get_iwe(np.array([40.0, 10.0]), *(f64(v) for v in (x, y, t, p)), R.linvel_warp(), (H, W), sensor_size=(H, W),
                        accum="f64")
     assert np.abs(f64(np.asarray(iwe)) - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_structured_scenes_are_flagged_and_balanced(E, monkeypatch):
+    """The bucketing plan: a moving-edge scene (tiles hold 0.5 .. 2 x the mean) is flagged `structured`, its full tiles
+    are split so that no work item exceeds ~the mean, and the item count stays within 2 per tile; uniform events are
+    neither flagged nor split."""
+    import bench
+    from event_utils_amd import tiled
+    H, W, n = 480, 640, 3_000_000
+    for scene in ("edges", "uniform"):
+        if scene == "edges":
+            x, y, t, p = bench.structured_scene(5, n, H, W)
+        else:
+            x, y, t, p = _events(6, n, H, W, real=True)
+        cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
+        bk = tiled.bucket_events(*cols, 1, H + 1, W + 1, 4, 4)
+        T = bk.ntiles
+        idx = bk.bucket_start.cpu().numpy().astype(np.int64)
+        counts = np.diff(idx[: T + 1])
+        parts = np.diff(idx[T + 1: 2 * T + 2])
+        assert counts.sum() == n and parts.min() >= 1
+        if scene == "edges":
+            assert bk.structured and parts.sum() <= 2 * T and parts.max() >= 2
+            assert (counts / parts).max() <= 1.05 * max(counts.mean(), 4096)
+        else:
+            assert not bk.structured and parts.max() == 1

@@ -13,8 +13,12 @@ import event_utils_amd as E  # noqa: E402
 from event_utils_amd.events import DeviceEvents  # noqa: E402
 
 torch.cuda.set_device(0)
-H, W = 720, 1280
-x, y, t, p = bench.structured_scene(3, 50_000_000, H, W)
+H, W, N = 720, 1280, 50_000_000
+if "--vga" in sys.argv:      # the same scene at C3's size
+    H, W, N = 480, 640, 10_000_000
+if "--small" in sys.argv:
+    H, W, N = 260, 346, 2_000_000
+x, y, t, p = bench.structured_scene(3, N, H, W)
 if "--px" in sys.argv:
     x, y = np.floor(x), np.floor(y)
 ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
@@ -31,8 +35,8 @@ for fixed in ("64", "32", "64", "32"):
             fn(prm, ev, None, None, None, w, (H, W), 1.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(8):
+        for _ in range(20):
             fn(prm, ev, None, None, None, w, (H, W), 1.0)
         torch.cuda.synchronize()
-        row.append("%s %.4f" % (name, (time.perf_counter() - t0) / 8 * 1e3))
+        row.append("%s %.4f" % (name, (time.perf_counter() - t0) / 20 * 1e3))
     print("FIXED=%s records=%s: %s ms" % (fixed, [b.iwe_flag for b in ev._buckets.values()], "  ".join(row)), flush=True)
