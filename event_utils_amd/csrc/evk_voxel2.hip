@@ -298,6 +298,10 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
             np += tot[k] > cap ? (tot[k] + cap - 1) / cap : 1u;
         }
     }
+    // (The balanced plan of k_tile_scan_totals -- more, smaller items for non-uniform scenes -- was tried here and is
+    // slower: this kernel keeps only 2-3 workgroups per CU resident (52-72 KB of LDS each), so items beyond ~768 / 512
+    // run as a second round, and every part of a split tile pays the accumulator zeroing, a staging store and the
+    // combine.  Moving-edge scene, 10 M events / VGA: 66 -> 76 us; 50 M / 720p: 257 -> 278 us.)
     uint32_t total_parts;
     uint32_t prun = block_excl_scan<THREADS>(np, tmp, total_parts);
 #pragma unroll
@@ -410,16 +414,22 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         if (pos >= beg) one(v.x, v.y, pos);
         if (pos + 1 < end) one(v.z, v.w, pos + 1);
     };
+    // Entries go to the threads in equal batches, INTERLEAVED over the waves (slot = lane * NW + wave): a short range -- the
+    // last batch of a tile, or one of the many parts of a hot tile -- then still gives every wave its share instead of
+    // filling wave 0 first (1221 sub-chunks: 3 batches of 408 = 51 entries per wave, not 64, 64, 64 / 64, 5, 0 ...).
+    const int range = sc_hi - sc_lo, nbatch = (range + WG - 1) / WG;
+    const int bsz = nbatch ? ((range + nbatch - 1) / nbatch + NW - 1) / NW * NW : NW;  // <= WG, a multiple of NW
+    const int slot = lane * NW + wave;
     uint32_t ent_next = 0;
     {
-        const int my = sc_lo + (int)threadIdx.x;
-        if (my < sc_hi) ent_next = col[(int64_t)my * q.nt_pad];
+        const int my = sc_lo + slot;
+        if (slot < bsz && my < sc_hi) ent_next = col[(int64_t)my * q.nt_pad];
     }
-    for (int base = sc_lo; base < sc_hi; base += WG) {
+    for (int base = sc_lo; base < sc_hi; base += bsz) {
         const uint32_t ent = ent_next;
         {   // next batch's entries: in flight while this batch is processed
-            const int my = base + WG + (int)threadIdx.x;
-            ent_next = my < sc_hi ? col[(int64_t)my * q.nt_pad] : 0u;
+            const int my = base + bsz + slot;
+            ent_next = (slot < bsz && my < sc_hi) ? col[(int64_t)my * q.nt_pad] : 0u;
         }
         if (V2_ABLATE_B < 1) {
             if (ent == 0xFFFFFFFFu) acc[0] = 1.0;
@@ -438,9 +448,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         }
         const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
         __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
-        const uint32_t wbase = (uint32_t)(base + wave * 64);  // sub-chunk of lane 0's entry
         {
-            const uint32_t rb = (wbase + lane) * (uint32_t)q.S, p0 = rb + (start & ~1u), e0 = rb + start + cnt;
+            const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + (start & ~1u), e0 = rb + start + cnt;
             for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
         }
         __syncthreads();
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             m &= m - 1;
             const uint32_t e2 = __shfl(ent, s, 64);
             const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
-            const uint32_t rb = (wbase + s) * (uint32_t)q.S;
+            const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
             const uint32_t b2 = rb + st, e3 = b2 + cn;
             for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 128u) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(rec + p2);
