@@ -416,6 +416,17 @@ def bench_cmax(E, DeviceEvents, dev, impl):
     obj.sensor_size, obj.impl = (H4, W4), impl
     c4 = {"workload": "configs[3]: 50M events, 1280x720, moving-edge scene (true flow (40,-25) px/s)"}
     c4.update(_time_evals(obj, w, ev, np.array([30.0, -20.0]), (H4, W4), reps=5))
+    bks = list(ev._buckets.values())
+    c4["plan"] = {"records": "compact 8 B" if bks and bks[0].iwe_flag else "full 16 B (sub-pixel coordinates)",
+                  "structured_scene": bool(bks and bks[0].structured),
+                  "gradient_accumulators": "packed 32-bit pairs" if bks and bks[0].structured else "64-bit fixed point"}
+    # the same scene as an event camera delivers it (integer pixel coordinates): the bucketed records compact to 8 bytes
+    evp = DeviceEvents.from_arrays(np.floor(x), np.floor(y), t, p, precision="f32")
+    px = _time_evals(obj, w, evp, np.array([30.0, -20.0]), (H4, W4), reps=5)
+    bks = list(evp._buckets.values())
+    c4["sensor_pixel_events"] = {"f_ms": px["f_ms"], "grad_ms": px["grad_ms"],
+                                 "records": "compact 8 B" if bks and bks[0].iwe_flag else "full 16 B"}
+    del evp
     for mode, numeric, exact in (("bfgs_numeric_grads(reference default)", True, True),
                                  ("bfgs_analytic_consistent_grad", False, False)):
         o = E.variance_objective()

@@ -101,7 +101,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__rest
 #define EVK_POST_BLUR_IWE 2u  // gradient: use the blurred IWE (reference_exact=False); default is the raw IWE (Q5)
 
 __device__ __forceinline__ int reflect_idx(int q, int len) {
-    const int period = 2 * len;
+    if ((unsigned)q < (unsigned)len) return q;                 // inside: the common case, no division
+    if (q >= -len && q < 2 * len) return q < 0 ? -q - 1 : 2 * len - 1 - q;   // one reflection
+    const int period = 2 * len;                                // a radius larger than the image
     int m = q % period;
     if (m < 0) m += period;
     return m >= len ? period - 1 - m : m;
@@ -110,9 +112,12 @@ __device__ __forceinline__ int reflect_idx(int q, int len) {
 // Blurs one plane over a 32x32 output tile (scipy gaussian_filter arithmetic: per-axis float64 accumulation in scipy's
 // symmetric summation order, stored as float32 between the axes).  FILL(py, px) returns the source value at patch position
 // (py, px), i.e. image pixel (y0 - r + py, x0 - r + px) under the 'reflect' boundary rule.
-template <typename FILL>
+// RC = the radius when it is known at compile time (4: sigma = 1, the default blur of every objective), 0 = any radius
+// (bw.radius).  With a constant radius the patch width is a constant (the flat index splits by a multiply-shift, not an
+// integer division) and the taps are unrolled with immediate LDS offsets -- index arithmetic was most of this kernel.
+template <int RC, typename FILL>
 __device__ __forceinline__ void blur_tile_fill(float *patch, float *inter, const BlurWeights &bw, FILL fill, float (&res)[4]) {
-    const int r = bw.radius, PW = EVK_POST_T + 2 * r, PH = PW;
+    const int r = RC ? RC : bw.radius, PW = EVK_POST_T + 2 * r, PH = PW;
     for (int i = threadIdx.x; i < PH * PW; i += EVK_BLOCK) {
         const int py = i / PW, px = i - py * PW;
         patch[i] = fill(py, px);
@@ -122,6 +127,7 @@ __device__ __forceinline__ void blur_tile_fill(float *patch, float *inter, const
         const int y = i / PW, xx = i - y * PW;
         const float *col = patch + (y + r) * PW + xx;
         double acc = (double)col[0] * bw.w[r];
+#pragma unroll
         for (int j = r; j >= 1; --j) acc += ((double)col[-j * PW] + (double)col[j * PW]) * bw.w[r - j];
         inter[i] = (float)acc;
     }
@@ -132,18 +138,19 @@ __device__ __forceinline__ void blur_tile_fill(float *patch, float *inter, const
         const int y = o / EVK_POST_T, x = o - y * EVK_POST_T;
         const float *row = inter + y * PW + x + r;
         double acc = (double)row[0] * bw.w[r];
+#pragma unroll
         for (int j = r; j >= 1; --j) acc += ((double)row[-j] + (double)row[j]) * bw.w[r - j];
         res[k] = (float)acc;
     }
     __syncthreads();
 }
 // the same with the source read from global memory: LOAD(gy, gx) returns image pixel (gy, gx)
-template <typename LOAD>
+template <int RC, typename LOAD>
 __device__ __forceinline__ void blur_tile(float *patch, float *inter, const BlurWeights &bw, int y0, int x0, int ch,
                                           int cw, LOAD load, float (&res)[4]) {
-    const int r = bw.radius;
-    blur_tile_fill(patch, inter, bw,
-                   [&](int py, int px) { return load(reflect_idx(y0 - r + py, ch), reflect_idx(x0 - r + px, cw)); }, res);
+    const int r = RC ? RC : bw.radius;
+    blur_tile_fill<RC>(patch, inter, bw,
+                       [&](int py, int px) { return load(reflect_idx(y0 - r + py, ch), reflect_idx(x0 - r + px, cw)); }, res);
 }
 
 }  // namespace evk

@@ -85,14 +85,14 @@ __device__ __forceinline__ unsigned int float_order_bits(float f) {  // monotone
 // MODE 2: sum v, sum v^2, sum exp(v), sum exp(-p v), count(v > thresh) and max v of the blurred image.
 // MODE 3: MODE 1 and MODE 0 together (function value AND gradient of one evaluation): the 5 sums of MODE 1, then
 //         sum v, sum v^2 of the blurred IWE.
-template <int MODE>
+template <int MODE, int RC>
 __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restrict__ iwe,
                                                           const float *__restrict__ diwe, int ch, int cw,
                                                           BlurWeights bw, PostParams pp,
                                                           double *__restrict__ partials) {
     const uint32_t flags = pp.flags;
     extern __shared__ float sm[];
-    const int r = bw.radius, PW = EVK_POST_T + 2 * r;
+    const int r = RC ? RC : bw.radius, PW = EVK_POST_T + 2 * r;
     float *patch = sm, *inter = sm + PW * PW;
     const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T, ntile = tiles_x * ((ch + EVK_POST_T - 1) / EVK_POST_T);
     const int64_t plane = (int64_t)ch * cw;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     const int y0 = (tile / tiles_x) * EVK_POST_T, x0 = (tile % tiles_x) * EVK_POST_T;
     if constexpr (MODE == 0 || MODE == 2) {
         float v[4];
-        blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
+        blur_tile<RC>(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, v);
         float vmax = -__builtin_inff();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -129,6 +129,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     } else {
         float d[2][4], a[4];
         for (int c = 0; c < 2; ++c) {
+            // channel reflected at offsets -j / +j of the length-2 channel axis: the same for every pixel, so the two
+            // reflections per tap are taken once per tile (bit j of lo / hi), not once per tap and pixel
+            uint64_t lo = 0, hi = 0;
+            for (int j = 1; j <= r; ++j) {
+                lo |= (uint64_t)reflect_idx(c - j, 2) << j;
+                hi |= (uint64_t)reflect_idx(c + j, 2) << j;
+            }
             auto load_mixed = [&](int gy, int gx) -> float {
                 const int64_t pix = (int64_t)gy * cw + gx;
                 if (!(flags & EVK_POST_MIX)) return diwe[c * plane + pix];
@@ -136,13 +143,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
                 const float dv[2] = {diwe[pix], diwe[plane + pix]};
                 double s = (double)dv[c] * bw.w[r];
                 for (int j = r; j >= 1; --j)
-                    s += ((double)dv[reflect_idx(c - j, 2)] + (double)dv[reflect_idx(c + j, 2)]) * bw.w[r - j];
+                    s += ((double)((lo >> j) & 1 ? dv[1] : dv[0]) + (double)((hi >> j) & 1 ? dv[1] : dv[0])) * bw.w[r - j];
                 return (float)s;
             };
-            blur_tile(patch, inter, bw, y0, x0, ch, cw, load_mixed, d[c]);
+            blur_tile<RC>(patch, inter, bw, y0, x0, ch, cw, load_mixed, d[c]);
         }
         if (MODE == 3 || (flags & EVK_POST_BLUR_IWE)) {
-            blur_tile(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, a);
+            blur_tile<RC>(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, a);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -254,7 +261,8 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     hipStream_t s = (hipStream_t)stream;
     PostParams pp;
     pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr;
-    k_post_fused<MODE><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
+    if (radius == 4) k_post_fused<MODE, 4><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
+    else k_post_fused<MODE, 0><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     const bool publish = pub && pub->slot && pub->flag && nplanes <= 3;
     k_reduce_final<MODE><<<nplanes, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out,
                                                       publish ? *pub : HostPublish{nullptr, nullptr, 0u});
@@ -343,7 +351,8 @@ extern "C" int evk_objective_stats_f32(const float *img, int h, int w, const dou
     if (e != hipSuccess) return (int)e;
     PostParams pp;
     pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits;
-    k_post_fused<2><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
+    if (radius == 4) k_post_fused<2, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
+    else k_post_fused<2, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
     k_reduce_final<0, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, wide);
     k_stats_finish<<<1, 1, 0, s>>>(wide, max_bits, out8);
     return launch_status();
@@ -364,7 +373,8 @@ extern "C" int evk_objective_gradsums_f32(const float *iwe, const float *diwe, i
     hipStream_t s = (hipStream_t)stream;
     PostParams pp;
     pp.flags = flags, pp.gfun = gfun, pp.gparam = gparam, pp.thresh = 0.0, pp.max_bits = nullptr;
-    k_post_fused<1><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
+    if (radius == 4) k_post_fused<1, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
+    else k_post_fused<1, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     k_reduce_final<1, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out8);
     return launch_status();
 }

@@ -176,7 +176,12 @@ def test_random_event_image_variants_equal_the_oracle(seed):
     got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W),
                                   clip_out_of_range=clip, interpolation=interp, padding=padding, default=default)
     assert tuple(got.shape) == ref.shape
-    assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * max(np.max(np.abs(ref)), 1e-30)
+    # float32 accumulation (as the reference's index_put_): the clipped events pile up on one pixel, thousands of N(0, 1)
+    # weights whose sum cancels -- its rounding error scales with the accumulated magnitude, not with the cancelled sum
+    mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), clip_out_of_range=clip, interpolation=interp,
+                                  padding=padding, default=0.0, accum="f64")
+    tol = 1e-5 * max(np.max(np.abs(ref)), 1e-30) + 2e-7 * np.max(np.abs(mag))
+    assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= tol
     # numpy entry point: integer coordinates inside the (H+1, W+1) canvas, nearest, with and without meanval
     xi, yi = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n)
     pi = rng.integers(-3, 4, n)
