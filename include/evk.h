@@ -237,8 +237,12 @@ int64_t evk_reduce_scratch_bytes(void);
 int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_log2);
 int64_t evk_bucket_scratch_bytes(int ntiles);
 /* length (uint32 entries) of the bucket index for n events: tile offsets (ntiles+1), work-item offsets (ntiles+1),
- * per-tile arrival counters (ntiles) and the item -> tile map (evk_bucket_max_items entries).  A tile holding more than
- * max(32768, 4n/ntiles) events is split into several work items, so clustered event data cannot serialise on one CU. */
+ * per-tile arrival counters (ntiles), the item -> tile map (evk_bucket_max_items entries) and, LAST, the `scene` word.
+ * A tile holding more than max(32768, 4n/ntiles) events is split into several work items, so clustered event data cannot
+ * serialise on one CU.  When the fullest tile holds more than 1.25 x the mean tile population the scene word is 1 (a
+ * structured scene; 0 otherwise) and the plan is BALANCED: the split threshold is lowered, not below
+ * max(4096, 5/8 of the mean), as far as 2 work items per tile allow -- the tile kernels run one workgroup per item, all
+ * resident at once, so a launch lasts as long as its largest item. */
 int64_t evk_bucket_index_len(int ntiles, int64_t n);
 int evk_bucket_max_items(int ntiles, int64_t n);
 
@@ -382,7 +386,9 @@ int evk_iwe_linvel_tiled_f32(const float *records, const uint32_t *bucket_index,
  * alternating 0 / 1 from call to call on one stream.  The evaluation then needs no memset: the rare events outside their
  * LDS window go to spill[parity], the gather writes iwe_buf = spill[parity] + windows and zeroes what the previous call
  * left in spill[parity ^ 1].
- * host_out (optional, HOST pointer to 4 doubles): the call copies `out` there and synchronises the stream itself. */
+ * host_out (optional, HOST pointer to 4 doubles): the call also delivers `out` there and returns only when it has
+ * (the finalise kernel stores the results and a sequence number in a pinned slot that the call polls: no copy command, no
+ * stream synchronisation).  Everything enqueued on the stream before the call has completed when it returns. */
 int evk_cmax_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
                                 int tw_log2, int th_log2, int slices, int win_w, int win_h, double t_first, double t_ref, double vx,
                                 double vy, double bounds_w, double bounds_h, int canvas_h, int canvas_w,
