@@ -245,10 +245,16 @@ def main():
         result["cmax"] = bench_cmax(E, DeviceEvents, dev, impl)
     if rank == 0 and world == 1 and not use_dist and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(x, y, t, p)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    # RCCL's version banner sits in the C stdio buffer (stdout is a pipe) and would come out at exit, AFTER the JSON:
+    # push everything out first so that the JSON is the last line of stdout
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 def roofline_block(kinfo, alg_bytes, n, tag):
