@@ -425,7 +425,7 @@ def bench_cmax(E, DeviceEvents, dev, impl):
     bks = list(ev._buckets.values())
     c4["plan"] = {"records": "compact 8 B" if bks and bks[0].iwe_flag else "full 16 B (sub-pixel coordinates)",
                   "structured_scene": bool(bks and bks[0].structured),
-                  "gradient_accumulators": "packed 32-bit pairs" if bks and bks[0].structured else "64-bit fixed point"}
+                  "accumulators": "64-bit fixed point, odd LDS pitches"}
     # the same scene as an event camera delivers it (integer pixel coordinates): the bucketed records compact to 8 bytes
     evp = DeviceEvents.from_arrays(np.floor(x), np.floor(y), t, p, precision="f32")
     px = _time_evals(obj, w, evp, np.array([30.0, -20.0]), (H4, W4), reps=5)

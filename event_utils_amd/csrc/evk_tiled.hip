@@ -628,6 +628,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                                                          float *__restrict__ diwe) {
     extern __shared__ __attribute__((aligned(16))) acc_t win[];
     const int wcells = q.win_w * q.win_h;
+    // LDS pitches: ODD numbers of 8-byte cells.  With an even pitch the rows of one column share few banks (40 cells = 80
+    // dwords: 4 distinct bank pairs out of 32), and real scenes are edges -- a wave's events sit in one column, different
+    // rows: 78 % of the LDS cycles of this kernel were bank conflicts on the moving-edge scene
+    // (profiles/r02_c4_iwe_lds_counters.json).  lw: row pitch of the row-major planes, lh: of the column-major E0 plane.
+    const int lw = q.win_w | 1, lh = q.win_h | 1, lcells = lw * lh;
     constexpr bool GRAD = (MODE == 1);
     constexpr int PLANES = MODE == 0 ? 1 : 3;
     const int ntiles = g.tiles_x * g.tiles_y;
@@ -642,7 +647,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     const uint32_t cnt = bhi - blo;
     const uint32_t lo = blo + (uint32_t)(((uint64_t)cnt * sub) / nsub);
     const uint32_t hi = blo + (uint32_t)(((uint64_t)cnt * (sub + 1)) / nsub);
-    for (int i = threadIdx.x; i < PLANES * wcells; i += EVK_BLOCK) win[i] = 0.0;
+    for (int i = threadIdx.x; i < PLANES * lcells; i += EVK_BLOCK) win[i] = 0.0;
     // Window origin from the time span of this slice (records are time-ordered up to intra-block interleaving; an
     // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
     int wx0 = 0, wy0 = 0;
@@ -701,36 +706,36 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                 unsigned long long *W = reinterpret_cast<unsigned long long *>(wp);
                 const int col = (lx & 1) ? halfw + (lx >> 1) : (lx >> 1);
                 float *gc = gp + (int64_t)py * q.cw + px;  // the event's top-left pixel in the output image
-                add_pair(W + ly * q.win_w + col, mp * ax * ay, mp * dx * ay, sI, invI,
+                add_pair(W + ly * lw + col, mp * ax * ay, mp * dx * ay, sI, invI,
                          [&] { return PairOverflow{nullptr, gc, nullptr, gc + 1}; });
-                add_pair(W + (ly + 1) * q.win_w + col, mp * ax * dy, mp * dx * dy, sI, invI,
+                add_pair(W + (ly + 1) * lw + col, mp * ax * dy, mp * dx * dy, sI, invI,
                          [&] { return PairOverflow{nullptr, gc + q.cw, nullptr, gc + q.cw + 1}; });
                 if constexpr (GRAD) {
                     // E0 = (a*ay at (x, y), a*dy at (x, y+1)): a vertical pair, plane held column-major;
                     // E1 = (a*ax at (x, y), a*dx at (x+1, y)): a horizontal pair.  In the image E0(x, y) is -d0[y][x],
                     // +d0[y][x+1] and E1(x, y) is -d1[y][x], +d1[y+1][x] (the finite differences of the flush).
-                    unsigned long long *V = W + wcells, *H1 = V + wcells;
+                    unsigned long long *V = W + lcells, *H1 = V + lcells;
                     float *d0 = diwe + (int64_t)py * q.cw + px, *d1 = d0 + plane;
-                    add_pair(V + lx * q.win_h + ((ly & 1) ? halfh + (ly >> 1) : (ly >> 1)), a * ay, a * dy, sE, invE,
+                    add_pair(V + lx * lh + ((ly & 1) ? halfh + (ly >> 1) : (ly >> 1)), a * ay, a * dy, sE, invE,
                              [&] { return PairOverflow{d0, d0 + 1, d0 + q.cw, d0 + q.cw + 1}; });
-                    add_pair(H1 + ly * q.win_w + col, a * ax, a * dx, sE, invE,
+                    add_pair(H1 + ly * lw + col, a * ax, a * dx, sE, invE,
                              [&] { return PairOverflow{d1, d1 + q.cw, d1 + 1, d1 + q.cw + 1}; });
                 }
                 return;
             }
-            acc_t *c = wp + ly * q.win_w + lx;
+            acc_t *c = wp + ly * lw + lx;
             lds_acc(c, mp * ax * ay);
             lds_acc(c + 1, mp * dx * ay);
-            lds_acc(c + q.win_w, mp * ax * dy);
-            lds_acc(c + q.win_w + 1, mp * dx * dy);
+            lds_acc(c + lw, mp * ax * dy);
+            lds_acc(c + lw + 1, mp * dx * dy);
             if constexpr (GRAD) {
                 // The reference's 8 derivative contributions come in +/- pairs on neighbouring pixels
                 // (image.py:132-135): d0[y][x] gets -a*ay from px == x and +a*ay from px == x-1, etc.  Accumulate
                 // the 4 magnitudes (E0: a*ay, a*dy; E1: a*ax, a*dx) and take the finite difference at the flush:
                 // d0[y][x] = E0[y][x-1] - E0[y][x],  d1[y][x] = E1[y-1][x] - E1[y][x]   (8 LDS atomics, not 12).
-                acc_t *e0 = c + wcells, *e1 = e0 + wcells;
+                acc_t *e0 = c + lcells, *e1 = e0 + lcells;
                 lds_acc(e0, a * ay);
-                lds_acc(e0 + q.win_w, a * dy);
+                lds_acc(e0 + lw, a * dy);
                 lds_acc(e1, a * ax);
                 lds_acc(e1 + 1, a * dx);
             }
@@ -756,8 +761,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     auto one = [&](const float4 &r) {
         splat(r, q.vx, q.vy, win, iwe);
         if constexpr (MODE == 2) {  // planes 1, 2 of the (3, ch, cw) buffer = diwe, diwe + plane
-            splat(r, q.vxb[0], q.vyb[0], win + wcells, diwe);
-            splat(r, q.vxb[1], q.vyb[1], win + 2 * wcells, diwe + plane);
+            splat(r, q.vxb[0], q.vyb[0], win + lcells, diwe);
+            splat(r, q.vxb[1], q.vyb[1], win + 2 * lcells, diwe + plane);
         }
     };
     if constexpr (COMPACT) {
@@ -778,19 +783,19 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         const unsigned long long *W = reinterpret_cast<const unsigned long long *>(win);
         for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
             const int lx = c % q.win_w, ly = c / q.win_w;
-            st[c] = (float)((double)pair_cell(W + ly * q.win_w, q.win_w, lx) * (double)invI);
+            st[c] = (float)((double)pair_cell(W + ly * lw, q.win_w, lx) * (double)invI);
             if constexpr (GRAD) {
-                const unsigned long long *V = W + wcells, *H1 = V + wcells;
-                const long long e0 = pair_cell(V + lx * q.win_h, q.win_h, ly);
-                const long long e0l = lx > 0 ? pair_cell(V + (lx - 1) * q.win_h, q.win_h, ly) : 0ll;
-                const long long e1 = pair_cell(H1 + ly * q.win_w, q.win_w, lx);
-                const long long e1u = ly > 0 ? pair_cell(H1 + (ly - 1) * q.win_w, q.win_w, lx) : 0ll;
+                const unsigned long long *V = W + lcells, *H1 = V + lcells;
+                const long long e0 = pair_cell(V + lx * lh, q.win_h, ly);
+                const long long e0l = lx > 0 ? pair_cell(V + (lx - 1) * lh, q.win_h, ly) : 0ll;
+                const long long e1 = pair_cell(H1 + ly * lw, q.win_w, lx);
+                const long long e1u = ly > 0 ? pair_cell(H1 + (ly - 1) * lw, q.win_w, lx) : 0ll;
                 st[wcells + c] = (float)((double)(e0l - e0) * (double)invE);      // d0[y][x] = E0[y][x-1] - E0[y][x]
                 st[2 * wcells + c] = (float)((double)(e1u - e1) * (double)invE);  // d1[y][x] = E1[y-1][x] - E1[y][x]
             }
             if constexpr (MODE == 2) {
-                st[wcells + c] = (float)((double)pair_cell(W + wcells + ly * q.win_w, q.win_w, lx) * (double)invI);
-                st[2 * wcells + c] = (float)((double)pair_cell(W + 2 * wcells + ly * q.win_w, q.win_w, lx) * (double)invI);
+                st[wcells + c] = (float)((double)pair_cell(W + lcells + ly * lw, q.win_w, lx) * (double)invI);
+                st[2 * wcells + c] = (float)((double)pair_cell(W + 2 * lcells + ly * lw, q.win_w, lx) * (double)invI);
             }
         }
         if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
@@ -809,16 +814,16 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         }
     };
     for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
-        st[c] = cell(win + c);
+        const int lx = c % q.win_w, ly = c / q.win_w, li = ly * lw + lx;  // staging cell c = LDS cell li
+        st[c] = cell(win + li);
         if constexpr (GRAD) {
-            const int lx = c % q.win_w, ly = c / q.win_w;
-            const acc_t *e0 = win + wcells, *e1 = e0 + wcells;
-            st[wcells + c] = diff(lx > 0 ? e0 + c - 1 : nullptr, e0 + c);
-            st[2 * wcells + c] = diff(ly > 0 ? e1 + c - q.win_w : nullptr, e1 + c);
+            const acc_t *e0 = win + lcells, *e1 = e0 + lcells;
+            st[wcells + c] = diff(lx > 0 ? e0 + li - 1 : nullptr, e0 + li);
+            st[2 * wcells + c] = diff(ly > 0 ? e1 + li - lw : nullptr, e1 + li);
         }
         if constexpr (MODE == 2) {
-            st[wcells + c] = cell(win + wcells + c);
-            st[2 * wcells + c] = cell(win + 2 * wcells + c);
+            st[wcells + c] = cell(win + lcells + li);
+            st[2 * wcells + c] = cell(win + 2 * lcells + li);
         }
     }
     if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
@@ -1147,7 +1152,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     if ((planes == 3 && !diwe) || slices < 1 || slices > 256 || canvas_h <= 1 || canvas_w <= 1) return EVK_EINVAL;
     const int tw = 1 << tw_log2, th = 1 << th_log2;
     if (win_w < tw + 3 || win_h < th + 3) return EVK_EINVAL;
-    const size_t lds = (size_t)planes * win_w * win_h * sizeof(acc_t);
+    const size_t lds = (size_t)planes * (win_w | 1) * (win_h | 1) * sizeof(acc_t);  // odd LDS pitches, see k_iwe_tiled
     if (lds > 64 * 1024) return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (n < 0 || staging_bytes < evk_iwe_tiled_staging_bytes(ntiles, n, slices, planes, win_w, win_h)) return EVK_ESCRATCH;

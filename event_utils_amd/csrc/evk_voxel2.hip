@@ -331,9 +331,11 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 // A tile's records sit in ~100-200 byte segments, one per sub-chunk.  Every thread fetches the table entry of one
 // sub-chunk; each wave then cuts its 64 segments into 64-byte CHUNKS (8 records, 16-byte aligned), lists the chunks
 // in LDS (wave scan of the chunk counts) and hands them out to groups of 4 lanes, 16 bytes per lane: all lanes stay busy
-// whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 64
+// whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 56
 // records (clustered scenes) are streamed by the whole wave instead.
-#define V2_CHUNK_CAP 512  // 64 segments x <= 8 chunks
+#define V2_MAX_CHUNKS 7    // chunks of a listed segment (longer ones are streamed by the whole wave)
+#define V2_CHUNK_CAP (64 * V2_MAX_CHUNKS)  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
+                                           // workgroups still fit a CU's 160 KB
 template <int WG, int U, bool SPLIT>
 __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
@@ -364,16 +366,21 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         item = k * q8 + (k < r8 ? k : r8) + j;
     }
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
+    // LDS layout of the accumulators: rows of tw + 1 cells (8 bytes), i.e. an ODD pitch.  With a pitch of 32 cells = 64
+    // dwords every row of one column lands on the same pair of banks, and the events of a real scene sit on edges: a
+    // wave's events share a column and differ in the row (moving-edge scene: 66 us against 36 us on uniform events).
+    const int tpitch = tw + 1, ppix = tpitch * th;   // cells per accumulator plane
     const int tile = (int)item_tile[item];
     const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     const uint32_t part_id = item - first_item;
     const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
-    for (int i = threadIdx.x; i < NB * tpix; i += WG) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
     const uint32_t *col = table + tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, grp = lane >> 2;
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
-        const int local = (int)(hi_w & V2_LOCAL_MASK);
+        const int lraw = (int)(hi_w & V2_LOCAL_MASK);
+        const int local = lraw + (lraw >> g.tw_log2);   // row * (tw + 1) + column
         const float p = (hi_w & V2_WIDE) ? pw[ridx] : __uint_as_float(hi_w & V2_P_MASK);
         const float tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
         if (V2_ABLATE_B < 3) {
@@ -388,22 +395,22 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             float w = p;
             if constexpr (split) {
                 if (!(p > 0.0f) && !(p <= 0.0f)) return;  // a NaN polarity is in neither grid
-                a += p > 0.0f ? 0 : B * tpix;
+                a += p > 0.0f ? 0 : B * ppix;
                 w = 1.0f;
             }
             const int b0 = (int)tn;
             const float v0 = w * (1.0f - (tn - (float)b0)), v1 = w * (1.0f - fabsf(tn - (float)(b0 + 1)));
-            if (v0 != 0.0f) lds_add(a + b0 * tpix, v0);
-            if (b0 + 1 < B && v1 != 0.0f) lds_add(a + (b0 + 1) * tpix, v1);
+            if (v0 != 0.0f) lds_add(a + b0 * ppix, v0);
+            if (b0 + 1 < B && v1 != 0.0f) lds_add(a + (b0 + 1) * ppix, v1);
         } else if (!split) {
-            voxel_bins_lds(acc, tpix, local, B, tn, p);
+            voxel_bins_lds(acc, ppix, local, B, tn, p);
         } else if (tn != tn) {
-            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
-            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc, ppix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc + B * ppix, ppix, local, B, tn, 1.0f);
         } else if (p > 0.0f) {
-            voxel_bins_lds(acc, tpix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc, ppix, local, B, tn, 1.0f);
         } else if (p <= 0.0f) {
-            voxel_bins_lds(acc + B * tpix, tpix, local, B, tn, 1.0f);
+            voxel_bins_lds(acc + B * ppix, ppix, local, B, tn, 1.0f);
         }
     };
     auto pair = [&](const uint4 &v, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
@@ -438,7 +445,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
         const uint32_t span = cnt ? (start + cnt) - (start & ~1u) : 0u;  // records from the aligned start
         const uint32_t nch = (span + 7u) >> 3;
-        const bool is_long = nch > 8u;
+        const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
         const uint32_t mych = is_long ? 0u : nch;
         uint32_t incl = mych;
 #pragma unroll
@@ -479,7 +486,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             issue(j0, va, pa, ba, ea);
             consume(va, pa, ba, ea);
         }
-        // long segments (> 64 records): the whole wave streams each of them, 16 bytes per lane
+        // long segments (> 7 chunks = 56 records): the whole wave streams each of them, 16 bytes per lane
         uint64_t m = __ballot(is_long);
         while (m) {
             const int s = __builtin_ctzll(m);
@@ -507,14 +514,18 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             }
         }
     };
+    auto lds_cell = [&](int c) -> float {   // dense cell c = (plane, pixel) -> padded LDS layout
+        const int b = c / tpix, l = c - b * tpix;
+        return (float)acc[b * ppix + l + (l >> g.tw_log2)];
+    };
     if (nparts == 1) {
-        flush([&](int c) { return (float)acc[c]; });
+        flush(lds_cell);
         return;
     }
     // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
     const int cells = NB * tpix;
     float *mine = staging + (int64_t)item * cells;
-    for (int c = threadIdx.x; c < cells; c += WG) mine[c] = (float)acc[c];
+    for (int c = threadIdx.x; c < cells; c += WG) mine[c] = lds_cell(c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int is_last;
@@ -676,7 +687,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const int ntiles = g.tiles_x * g.tiles_y;
     if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
-    const size_t lds_acc = (size_t)planes * sizeof(acc_t) << (tw_log2 + th_log2);
+    const size_t lds_acc = (size_t)planes * sizeof(acc_t) * (((size_t)1 << tw_log2) + 1) << th_log2;  // odd row pitch
     if (lds_acc > 140 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2, share);

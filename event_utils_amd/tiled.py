@@ -358,16 +358,16 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     # bound of any accumulator cell: every event in one pixel, weight |p| * p_scale (* |dt| for the derivative planes);
     # lets the kernel accumulate in 64-bit fixed point (EVK_IWE_FIXED=0 keeps float64 accumulation)
     # EVK_IWE_FIXED: "0" float64 accumulation, "64" 64-bit fixed-point cells, "32" packed 32-bit pairs for the gradient /
-    # three-flow modes (include/evk.h), "auto" (default) = 64-bit cells, packed pairs where measured faster (below)
+    # three-flow modes (include/evk.h), "auto" (default) = 64-bit cells
     p_bound, dt_bound, fixed = 0.0, 0.0, os.environ.get("EVK_IWE_FIXED", "auto")
     if fixed != "0":
         p_bound = ev.p_absmax() * abs(float(ev.p_scale))
         dt_bound = max(span, abs(ev.t_at(-1) - t_ref))
-        # "auto": packed pairs for the analytic gradient of STRUCTURED scenes, whose events pile up on few cells: there
-        # the same-address conflicts of the LDS atomics dominate and halving their number wins (moving-edge scene,
-        # gradient evaluation: 0.393 -> 0.300 ms at 50 M events / 720p, 0.144 -> 0.126 ms at 10 M / VGA), whereas on
-        # uniform-random events the returning atomics cost more than the halved count saves (0.054 -> 0.066 ms)
-        if fixed == "32" or (fixed == "auto" and batch is None and (flags & _lib.EVK_IWE_GRADIENT) and bk.structured):
+        # "auto" = 64-bit cells.  (Round 2 first chose packed pairs for the analytic gradient of structured scenes -- they
+        # halve the atomics, and with EVEN LDS pitches the same-column events of an edge scene fought over 4 bank pairs:
+        # 0.393 -> 0.300 ms at 50 M events / 720p.  With odd pitches the 64-bit cells run as fast (0.288 vs 0.290 ms;
+        # 0.109 vs 0.109 ms at 10 M / VGA) and keep 2^-27 resolution and bit-reproducible sums, so nothing is chosen.)
+        if fixed == "32":
             flags = flags | _lib.EVK_IWE_PACK32
     head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
         flow + (bounds_w, bounds_h, ch, cw, flags | bk.iwe_flag, float(ev.p_scale), p_bound, dt_bound)
