@@ -160,6 +160,12 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
         }
     };
     if (sc0 < sc_end) load_xy(sc0);
+    // vmcnt(0), expcnt / lgkmcnt untouched.  As a BUILTIN, so that the compiler's wait-count pass knows that x, y are in
+    // their registers from here on: their first use, at the top of the loop, would otherwise get an `s_waitcnt vmcnt(0)`
+    // of its own -- and that one also waits for the write-out stores of the previous sub-chunk (one counter for loads and
+    // stores), ~1-2 us on every pass.  Waiting HERE and before the write-out (below) costs nothing: the loads are old.
+#define V2_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+    V2_WAIT_VM0();
     for (int sc = sc0; sc < sc_end; ++sc) {
         const int64_t lo = (int64_t)sc * q.S;
         for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;
@@ -200,13 +206,15 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
         uint32_t kept;
         uint32_t run = block_excl_scan<THREADS>(mine, tmp, kept);
         uint32_t *trow = table + (int64_t)sc * q.nt_pad;
+        uint32_t tval[PER_MAX];   // this thread's table entries: stored with the write-out (no store before the next loads)
 #pragma unroll
         for (int k = 0; k < PER_MAX; ++k) {
             const int i = i0 + k;
+            tval[k] = 0;
             if (k < per && i < i1) {
                 const uint32_t cnt = hist[i];
                 hist[i] = run;
-                trow[i] = run | (cnt << 16);
+                tval[k] = run | (cnt << 16);
                 mytot[k] += cnt;
                 run += cnt;
             }
@@ -221,7 +229,11 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
                 tv[k].v[e] = (tv[k].v[e] - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
                 asm volatile("" : "+v"(tv[k].v[e]));
             }
-        if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during placement and write-out
+        // Nothing outstanding from here (t, p are in; the previous sub-chunk's stores are a histogram and a scan old) -- said
+        // with the builtin so that the placement's uses of t, p get no wait of their own: with x, y of the next sub-chunk
+        // just issued such a wait is a vmcnt(0), i.e. the full latency of those loads in every placement.
+        V2_WAIT_VM0();
+        if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement
         if (V2_ABLATE_A < 3) {
             uint32_t sink = 0;
 #pragma unroll
@@ -250,6 +262,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
                 if (wide_mask >> s & 1u) pw[lo + kl[s]] = pv[s >> 2].v[s & 3], ++nwide;
         }
         lds_barrier();
+        V2_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: see above
         // ---- one contiguous, coalesced run of `kept` records
         if (V2_ABLATE_A >= 4) {
             const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
@@ -257,6 +270,9 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
             const int n16 = (int)((kept + 1) >> 1);
             for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
         }
+#pragma unroll
+        for (int k = 0; k < PER_MAX; ++k)
+            if (k < per && i0 + k < i1) trow[i0 + k] = tval[k];
         lds_barrier();  // sorted / hist are rewritten by the next sub-chunk
     }
     if (dropped && oob) atomicAdd(oob, dropped);
