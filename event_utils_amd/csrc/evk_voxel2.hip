@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
     // loaded before the placement of j and land during its placement + write-out.  (gfx9 counts loads and stores with ONE
     // counter that is in order only among loads, so a wave with stores in flight cannot wait for a particular load: the
     // first use of loaded data waits for everything outstanding.  Deeper pipelines -- t, p one sub-chunk ahead as well --
-    // only added register spills: measured 150 us instead of 62.)
+    // added register spills at 12-16 events per thread (150 us instead of 62) and, at 8 events per thread where they fit
+    // (128 registers, no spill), bunch all eight loads of a sub-chunk into one phase: 57 us instead of 48.5.)
     const int sc0 = blockIdx.x * q.per_block;
     const int sc_end = (sc0 + q.per_block < q.nsc) ? sc0 + q.per_block : q.nsc;
     Vec4<float> xv[NQ], yv[NQ], tv[NQ], pv[NQ];
