@@ -23,6 +23,9 @@
 
 namespace evk {
 
+#ifndef V2_PIPE
+#define V2_PIPE 1
+#endif
 #define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info)
 #define V2_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
 #define V2_TOTALS V2_HDR
@@ -398,7 +401,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
         const int lraw = (int)(hi_w & V2_LOCAL_MASK);
         const int local = lraw + (lraw >> g.tw_log2);   // row * (tw + 1) + column
-        const float p = (hi_w & V2_WIDE) ? pw[ridx] : __uint_as_float(hi_w & V2_P_MASK);
+        float p = __uint_as_float(hi_w & V2_P_MASK);
+        if (hi_w & V2_WIDE) {   // rare: the exact float32 polarity from the side array.  The wait stays INSIDE the branch
+            p = pw[ridx];       // (builtin: the compiler's scoreboard sees it) -- at the join it would be a vmcnt(0) on
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // every event, i.e. the next round's record loads could never stay in flight
+        }
         const float tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
         if (V2_ABLATE_B < 3) {
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
@@ -477,31 +484,62 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
         }
         __syncthreads();
-        // chunk rounds: U loads per lane in flight, then accumulated (double-buffering them measured slower: 60 vs 46 us).
+        // Chunk rounds, software-pipelined in three stages: list entries of round r + 2 (LDS) | record loads of round r + 1
+        // (global) | accumulation of round r.  The loads are UNCONDITIONAL -- a lane group without a chunk reads the head
+        // of the record buffer -- so that nothing but arithmetic sits between them and the compiler can wait for the
+        // older round alone (`vmcnt(U)`).  V2_PIPE=0 restores the plain issue / wait / accumulate rounds.
         // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
         // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
         // while its 600 segments are pulled
-        auto issue = [&](uint32_t j0, uint4(&v)[U], uint32_t(&pos)[U], uint32_t(&beg)[U], uint32_t(&end)[U]) {
+        auto meta = [&](uint32_t j0, uint2(&cs)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t j = j0 + 16u * u + grp;
-                const uint2 cs = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
-                pos[u] = (cs.x & ~1u) + 2u * sub;
-                beg[u] = (cs.x & ~1u) + (cs.x & 1u);   // == the segment's first record when it lies inside this chunk
-                end[u] = cs.y;
-                if (pos[u] < end[u]) v[u] = *reinterpret_cast<const uint4 *>(rec + pos[u]);
+                cs[u] = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
             }
         };
-        auto consume = [&](uint4(&v)[U], uint32_t(&pos)[U], uint32_t(&beg)[U], uint32_t(&end)[U]) {
+        auto fire = [&](const uint2(&cs)[U], uint4(&v)[U]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (pos[u] < end[u]) pair(v[u], pos[u], beg[u], end[u]);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
+                v[u] = *reinterpret_cast<const uint4 *>(rec + (pos < cs[u].y ? pos : 2u * sub));
+            }
         };
-        uint4 va[U];
-        uint32_t pa[U], ba[U], ea[U];
-        for (uint32_t j0 = 0; j0 < total; j0 += 16u * U) {
-            issue(j0, va, pa, ba, ea);
-            consume(va, pa, ba, ea);
+        auto eat = [&](const uint2(&cs)[U], const uint4(&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
+                // beg == the segment's first record when it lies inside this chunk
+                if (pos < cs[u].y) pair(v[u], pos, (cs[u].x & ~1u) + (cs[u].x & 1u), cs[u].y);
+            }
+        };
+        constexpr uint32_t step = 16u * U;
+        if (V2_PIPE) {
+            uint2 ca[U], cb[U], cn[U];
+            uint4 va[U], vb[U];
+            meta(0u, ca);
+            fire(ca, va);
+            meta(step, cb);
+            for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
+                fire(cb, vb);               // round j0 + step
+                meta(j0 + 2u * step, cn);
+                eat(ca, va);                // round j0
+                fire(cn, va);               // round j0 + 2 step
+#pragma unroll
+                for (int u = 0; u < U; ++u) ca[u] = cn[u];
+                meta(j0 + 3u * step, cn);
+                eat(cb, vb);                // round j0 + step
+#pragma unroll
+                for (int u = 0; u < U; ++u) cb[u] = cn[u];
+            }
+        } else {
+            uint2 ca[U];
+            uint4 va[U];
+            for (uint32_t j0 = 0; j0 < total; j0 += step) {
+                meta(j0, ca);
+                fire(ca, va);
+                eat(ca, va);
+            }
         }
         // long segments (> 7 chunks = 56 records): the whole wave streams each of them, 16 bytes per lane
         uint64_t m = __ballot(is_long);
