@@ -414,10 +414,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
-        if (tn >= 0.0f && tn <= bm1) {
+        if (__builtin_expect(tn >= 0.0f && tn <= bm1, 1)) {
             // the common case, straight-line: t inside [ts[0], ts[-1]].  Bins b0 = floor(t_norm) and b0 + 1 with the
             // weights of voxel_grid.py:138 -- 1 - |t_norm - b| evaluated exactly as there (for b0 the absolute value is
-            // the identity; max(0, .) cannot bind for these two bins)
+            // the identity; max(0, .) cannot bind for these two bins).  A zero weight is added like any other (x + 0 = x;
+            // the reference's index_put_ adds it too): skipping it cost a compare and a branch per bin on every event.
             acc_t *a = acc + local;
             float w = p;
             if constexpr (split) {
@@ -427,8 +428,9 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             }
             const int b0 = (int)tn;
             const float v0 = w * (1.0f - (tn - (float)b0)), v1 = w * (1.0f - fabsf(tn - (float)(b0 + 1)));
-            if (v0 != 0.0f) lds_add(a + b0 * ppix, v0);
-            if (b0 + 1 < B && v1 != 0.0f) lds_add(a + (b0 + 1) * ppix, v1);
+            a += b0 * ppix;
+            lds_add(a, v0);
+            if (b0 + 1 < B) lds_add(a + ppix, v1);
         } else if (!split) {
             voxel_bins_lds(acc, ppix, local, B, tn, p);
         } else if (tn != tn) {
