@@ -834,10 +834,12 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
 // window, shifted by at most [s_lo, s_hi], intersects it; all their work items and time slices) are listed once in LDS
 // (sorted by window id, so the float32 summation order is fixed), then every pixel walks that short list.
 #define EVK_GATHER_PX 32
-#define EVK_GATHER_PY 8    // (32 x 16 patches, two rows per thread: 18.8 instead of 21 us at 720p but 11.1 instead of 8.0 us at VGA)
+// patch height PY (template): 8 rows, or 16 (two rows per thread) when the 8-row patches would not all be resident at once
+// (more than 2048 of them: 720p and up) -- 32 x 16 patches measured 18.8 instead of 21 us at 720p, but 11.1 instead of
+// 8.0 us at VGA
 #define EVK_GATHER_CAP 128
 #define EVK_GATHER_CAND 1024  // windows of all candidate tiles (before the overlap test)
-template <bool GRAD>
+template <bool GRAD, int PY>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restrict__ staging,
                                                           const int4 *__restrict__ origins,
                                                           const uint32_t *__restrict__ index, TileGrid g, int slices,
@@ -854,15 +856,15 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
     const int64_t plane = (int64_t)ch * cw;
     const uint32_t *part_start = index + IDX_PART(g.tiles_x * g.tiles_y);
     const int patches_x = (cw + EVK_GATHER_PX - 1) / EVK_GATHER_PX;
-    const int X0 = (blockIdx.x % patches_x) * EVK_GATHER_PX, Y0 = (blockIdx.x / patches_x) * EVK_GATHER_PY;
-    const int X1 = min(X0 + EVK_GATHER_PX, cw) - 1, Y1 = min(Y0 + EVK_GATHER_PY, ch) - 1;  // inclusive
+    const int X0 = (blockIdx.x % patches_x) * EVK_GATHER_PX, Y0 = (blockIdx.x / patches_x) * PY;
+    const int X1 = min(X0 + EVK_GATHER_PX, cw) - 1, Y1 = min(Y0 + PY, ch) - 1;  // inclusive
     // a window starts at tile_origin + shift, shift in [s_lo, s_hi] (clamped by k_iwe_tiled): tile tx can reach the
     // patch columns [X0, X1] iff tx*tw + s_lo <= X1 and X0 < tx*tw + s_hi + win_w
     const int tx_a = max((X0 - sx_hi - win_w + 1) >> g.tw_log2, 0), tx_b = min((X1 - sx_lo) >> g.tw_log2, g.tiles_x - 1);
     const int ty_a = max((Y0 - sy_hi - win_h + 1) >> g.th_log2, 0), ty_b = min((Y1 - sy_lo) >> g.th_log2, g.tiles_y - 1);
     // a thread owns column X and ROWS rows (RSTEP apart) of the patch; what the output needs from the spill pair is
     // fetched first, so that these loads are in flight while the window list is built
-    constexpr int RSTEP = EVK_BLOCK / EVK_GATHER_PX, ROWS = EVK_GATHER_PY / RSTEP;
+    constexpr int RSTEP = EVK_BLOCK / EVK_GATHER_PX, ROWS = PY / RSTEP;
     const int X = X0 + (threadIdx.x & (EVK_GATHER_PX - 1)), Yb = Y0 + threadIdx.x / EVK_GATHER_PX;
     bool inside[ROWS];
     float sp[ROWS][PLANES], sc[ROWS][PLANES];
@@ -1206,7 +1208,9 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
     float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
     hipStream_t s = (hipStream_t)stream;
-    const int ggrid = ((canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX) * ((canvas_h + EVK_GATHER_PY - 1) / EVK_GATHER_PY);
+    const int gpx = (canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX;
+    const bool tall = mode == 0 && gpx * ((canvas_h + 7) / 8) > 2048;   // see k_iwe_gather (three planes: 29.3 vs 28.3 us)
+    const int ggrid = gpx * ((canvas_h + (tall ? 15 : 7)) / (tall ? 16 : 8));
     const float4 *rec = (const float4 *)records;
     const bool compact = (flags & EVK_IWE_COMPACT) != 0;  // `records` are 8-byte compact records
     if (compact && ((1 << (tw_log2 + th_log2)) > (int)EVK_REC_LOCAL_MASK + 1 || !aligned16(records))) return EVK_EINVAL;
@@ -1230,13 +1234,16 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     } while (0)
     if (mode == 0) {
         EVK_IWE_LAUNCH(0);
-        k_iwe_gather<false><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+        if (tall) k_iwe_gather<false, 16><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
+                                                       spill, spill_clean);
+        else k_iwe_gather<false, 8><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
                                                        canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
                                                        spill, spill_clean);
     } else {
         if (mode == 1) EVK_IWE_LAUNCH(1);
         else EVK_IWE_LAUNCH(2);
-        k_iwe_gather<true><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+        k_iwe_gather<true, 8><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
                                                       spill, spill_clean);
     }
