@@ -521,9 +521,19 @@ def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
         dist.all_reduce(grid, op=dist.ReduceOp.SUM)
 
     res = {"workload": "configs[4]: %d x 50M events, 1280x720, event-sharded, RCCL all-reduce of the grids" % world}
-    for name, fn, reps in (("voxel", voxel, 10),
-                           ("f", lambda: obj.evaluate_function(prm, ev, None, None, None, w, (H5, W5), 1.0), 10),
-                           ("grad", lambda: obj.evaluate_gradient(prm, ev, None, None, None, w, (H5, W5), 1.0), 10)):
+
+    def rows(fn):   # the same evaluation with the row-sharded post-pass (all-to-all of row blocks + 8-double all-reduce)
+        def run():
+            os.environ["EVK_SHARDED_POST"] = "rows"
+            try:
+                return fn()
+            finally:
+                os.environ["EVK_SHARDED_POST"] = "replicated"
+        return run
+    f_eval = lambda: obj.evaluate_function(prm, ev, None, None, None, w, (H5, W5), 1.0)      # noqa: E731
+    g_eval = lambda: obj.evaluate_gradient(prm, ev, None, None, None, w, (H5, W5), 1.0)      # noqa: E731
+    for name, fn, reps in (("voxel", voxel, 10), ("f", f_eval, 10), ("grad", g_eval, 10),
+                           ("f_rows_post", rows(f_eval), 10), ("grad_rows_post", rows(g_eval), 10)):
         for _ in range(2):
             fn()
         dist.barrier()

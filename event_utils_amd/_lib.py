@@ -69,6 +69,7 @@ SIGNATURES = {
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],
+    "evk_objective_variance_rows_f32": [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_compact_records_f32": [P, c_int64, c_int, c_int, c_int, c_int, P, P, P],
     "evk_allreduce_f32": [P, c_int64, P, P],
     "evk_allreduce_i32": [P, c_int64, P, P],

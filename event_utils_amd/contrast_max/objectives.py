@@ -265,6 +265,16 @@ class objective_function(ABC):
                 _lib.call("evk_objective_variance_f32", D.ptr(img), ch, cw, wp, radius, D.ptr(out), D.ptr(scratch),
                           nbytes, D.stream())
             return out.cpu().numpy()
+        if DD.post_mode() == "rows":
+            mode = (3 if post_flags & _lib.EVK_POST_VALUE else 1) if grad else 0
+            sums = self.__dict__.setdefault("_sums8", torch.zeros(8, dtype=torch.float64, device=dev))
+
+            def rows_post(block, y_lo, y_hi):
+                _lib.call("evk_objective_variance_rows_f32", D.ptr(block), mode, int(block.shape[1]), cw, int(y_lo), int(y_hi),
+                          D.host_ptr(w) if w is not None else None, radius, post_flags & ~_lib.EVK_POST_VALUE, D.ptr(sums),
+                          D.ptr(scratch), nbytes, D.stream())
+                return sums
+            return DD.sharded_evaluate_rows(local_iwe, rows_post, max(radius, 0), mode, self.process_group)
         return DD.sharded_evaluate(local_iwe, finish, self.process_group)
 
     def _iwe(self, params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient):

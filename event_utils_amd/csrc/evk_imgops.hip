@@ -74,6 +74,9 @@ struct PostParams {
     double gparam;  // MODE 1: parameter of g;  MODE 2: p of sum(exp(-p v))
     double thresh;  // MODE 2: threshold of count(v > thresh)
     unsigned int *max_bits;  // MODE 2: running max of v as order-preserving uint bits (atomicMax)
+    int y_lo, y_hi;          // rows whose pixels enter the sums (the whole image: 0, ch).  A row block of an image that is
+                             // sharded by rows (evk_objective_variance_rows_f32) carries halo rows that are blurred FROM
+                             // but not summed
 };
 
 __device__ __forceinline__ unsigned int float_order_bits(float f) {  // monotone map float -> uint
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
-            if (y < ch && x < cw) {
+            if (y >= pp.y_lo && y < pp.y_hi && x < cw) {
                 acc[0] += (double)v[k];
                 acc[1] += (double)v[k] * (double)v[k];
                 if constexpr (MODE == 2) {
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int o = threadIdx.x + k * EVK_BLOCK, y = y0 + o / EVK_POST_T, x = x0 + o % EVK_POST_T;
-            if (y < ch && x < cw) {
+            if (y >= pp.y_lo && y < pp.y_hi && x < cw) {
                 const float af = (flags & EVK_POST_BLUR_IWE) ? a[k] : iwe[(int64_t)y * cw + x];
                 double av = (double)af;
                 if (pp.gfun == EVK_G_EXP) av = exp(av);
@@ -262,7 +265,7 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     PostParams pp;
-    pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr;
+    pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = 0, pp.y_hi = h;
     if (radius == 4) k_post_fused<MODE, 4><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     else k_post_fused<MODE, 0><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     const bool publish = pub && pub->slot && pub->flag && nplanes <= 3;
@@ -310,6 +313,56 @@ extern "C" int evk_objective_variance_planes_f32(const float *imgs, int nplanes,
     return launch_post<0>(imgs, nullptr, h, w, host_weights, radius, 0u, out, scratch, scratch_bytes, stream, nplanes);
 }
 
+// ---- row-sharded post-pass (multi-GPU, optional): the image is cut into row blocks, one per rank; a rank holds the rows of
+// its block plus `radius` halo rows on each interior side, already summed over the ranks (an all-to-all of row blocks
+// moves half the bytes of an all-reduce), blurs them and adds up its OWN rows only.  The raw sums of all ranks are then
+// all-reduced (8 doubles) and finalised by the caller: mean = S0/N, var = S1/N - mean^2, g_i = 2/N (S(3+i) - mean S(1+i)).
+__global__ void __launch_bounds__(EVK_BLOCK) k_reduce_raw(const double *__restrict__ partials, int nblocks,
+                                                          double *__restrict__ out) {
+    double acc[EVK_REDUCE_K] = {};
+    for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
+#pragma unroll
+        for (int k = 0; k < EVK_REDUCE_K; ++k) acc[k] += partials[(int64_t)b * EVK_REDUCE_K + k];
+    __shared__ double tot[EVK_REDUCE_K];
+    block_sum<EVK_REDUCE_K>(acc, tot);
+    __syncthreads();
+    if (threadIdx.x < 8) out[threadIdx.x] = threadIdx.x < EVK_REDUCE_K ? tot[threadIdx.x] : 0.0;
+}
+
+template <int MODE>
+static int launch_post_rows(const float *img, int hb, int w, int y_lo, int y_hi, const double *host_weights, int radius,
+                            uint32_t flags, double *sums, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!img || hb <= 0 || w <= 0 || y_lo < 0 || y_hi < y_lo || y_hi > hb || !sums || !scratch) return EVK_EINVAL;
+    if (scratch_bytes < evk_reduce_scratch_bytes()) return EVK_ESCRATCH;
+    static const double identity[1] = {1.0};
+    if (radius < 0) host_weights = identity, radius = 0, flags &= ~EVK_POST_MIX;  // no blur = 1-tap kernel
+    if (!host_weights || radius > EVK_MAX_RADIUS) return EVK_EINVAL;
+    int grid = ((hb + EVK_POST_T - 1) / EVK_POST_T) * ((w + EVK_POST_T - 1) / EVK_POST_T);
+    if (grid > EVK_REDUCE_MAX_BLOCKS) grid = EVK_REDUCE_MAX_BLOCKS;
+    BlurWeights bw;
+    bw.radius = radius;
+    for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
+    const int PW = EVK_POST_T + 2 * radius;
+    const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    PostParams pp;
+    pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = y_lo, pp.y_hi = y_hi;
+    const float *diwe = img + (int64_t)hb * w;
+    if (radius == 4) k_post_fused<MODE, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, diwe, hb, w, bw, pp, (double *)scratch);
+    else k_post_fused<MODE, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, diwe, hb, w, bw, pp, (double *)scratch);
+    k_reduce_raw<<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, sums);
+    return launch_status();
+}
+
+extern "C" int evk_objective_variance_rows_f32(const float *img, int mode, int hb, int w, int y_lo, int y_hi,
+                                               const double *host_weights, int radius, uint32_t flags, double *sums,
+                                               void *scratch, int64_t scratch_bytes, void *stream) {
+    if (mode == 0) return launch_post_rows<0>(img, hb, w, y_lo, y_hi, host_weights, radius, 0u, sums, scratch, scratch_bytes, stream);
+    if (mode == 1) return launch_post_rows<1>(img, hb, w, y_lo, y_hi, host_weights, radius, flags, sums, scratch, scratch_bytes, stream);
+    if (mode == 3) return launch_post_rows<3>(img, hb, w, y_lo, y_hi, host_weights, radius, flags, sums, scratch, scratch_bytes, stream);
+    return EVK_EINVAL;
+}
+
 // Generic objective reductions (the other objectives of objectives.py:266-596 differ from the variance objective only
 // in these scalars): one fused blur + partial-sum launch and a finalise.
 __global__ void k_stats_finish(const double *__restrict__ wide, const unsigned int *__restrict__ max_bits,
@@ -352,7 +405,7 @@ extern "C" int evk_objective_stats_f32(const float *img, int h, int w, const dou
     hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(unsigned int), s);
     if (e != hipSuccess) return (int)e;
     PostParams pp;
-    pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits;
+    pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits, pp.y_lo = 0, pp.y_hi = h;
     if (radius == 4) k_post_fused<2, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
     else k_post_fused<2, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
     k_reduce_final<0, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, wide);
@@ -374,7 +427,7 @@ extern "C" int evk_objective_gradsums_f32(const float *iwe, const float *diwe, i
     if (rc != EVK_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     PostParams pp;
-    pp.flags = flags, pp.gfun = gfun, pp.gparam = gparam, pp.thresh = 0.0, pp.max_bits = nullptr;
+    pp.flags = flags, pp.gfun = gfun, pp.gparam = gparam, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = 0, pp.y_hi = h;
     if (radius == 4) k_post_fused<1, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     else k_post_fused<1, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     k_reduce_final<1, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out8);

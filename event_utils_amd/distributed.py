@@ -199,6 +199,62 @@ def sharded_evaluate(local_iwe, finish, group=None):
     return finish(img)
 
 
+def post_mode():
+    """How the blur + reductions of a sharded objective evaluation run: 'replicated' (default: all-reduce the image, every
+    rank blurs all of it) or 'rows' (EVK_SHARDED_POST=rows: all-to-all of row blocks -- half the bytes of the all-reduce per
+    link --, every rank blurs its block, an 8-double all-reduce of the raw sums)."""
+    return os.environ.get("EVK_SHARDED_POST", "replicated")
+
+
+def row_block(ch, radius, rank, world):
+    """Rows of the (ch, cw) image owned by `rank` -> (y0, y1, lo, hi): it sums rows [y0, y1) and needs rows [lo, hi) for
+    the blur, i.e. `radius` halo rows on every side that is not an edge of the image."""
+    y0, y1 = rank * ch // world, (rank + 1) * ch // world
+    return y0, y1, max(0, y0 - radius), min(ch, y1 + radius)
+
+
+def finalise_sums(sums, n_pixels, mode):
+    """Global raw sums of the row blocks -> the 4 scalars of one evaluation, as k_reduce_final computes them (float64):
+    mode 0 [mean, var, S v, S v^2]; mode 1 [g0, g1, mean a, S a]; mode 3 [g0, g1, mean v, var v]."""
+    s = np.asarray(sums, dtype=np.float64)
+    inv = 1.0 / float(n_pixels)
+    mean = s[0] * inv
+    if mode == 0:
+        return np.array([mean, s[1] * inv - mean * mean, s[0], s[1]])
+    g = [2.0 * inv * (s[3] - mean * s[1]), 2.0 * inv * (s[4] - mean * s[2])]
+    if mode == 1:
+        return np.array([g[0], g[1], mean, s[0]])
+    mv = s[5] * inv
+    return np.array([g[0], g[1], mv, s[6] * inv - mv * mv])
+
+
+def sharded_evaluate_rows(local_iwe, rows_post, radius, mode, group=None):
+    """One event-sharded objective evaluation with a ROW-SHARDED post-pass: `local_iwe()` -> this rank's
+    (planes, ch, cw) partial image; every rank receives the partial rows of ITS block (with halo) from all ranks in one
+    all-to-all and sums them; `rows_post(block, y_lo, y_hi)` -> 8 raw sums over its own rows (a tensor where the backend
+    works); one 8-double all-reduce; finalise_sums on the host.  Identical scalars on every rank."""
+    dist = _dist()
+    img = local_iwe()
+    planes, ch, cw = img.shape
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    y0, y1, lo, hi = row_block(ch, radius, rank, world)
+    if world == 1:
+        block = img
+    else:
+        blocks = [row_block(ch, radius, j, world) for j in range(world)]
+        send = torch.cat([img[:, b[2]:b[3], :].reshape(-1) for b in blocks])
+        in_splits = [planes * (b[3] - b[2]) * cw for b in blocks]
+        mine = planes * (hi - lo) * cw
+        recv = torch.empty(world * mine, dtype=img.dtype, device=img.device)
+        dist.all_to_all_single(recv, send, [mine] * world, in_splits, group=group)
+        block = recv.view(world, planes, hi - lo, cw).sum(dim=0)   # rank order: the same sum on every run
+    sums = rows_post(block.contiguous(), y0 - lo, y1 - lo)
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return finalise_sums(sums.cpu().numpy(), ch * cw, mode)
+
+
 def shard_objective(objective, t_last_global, group=None):
     """Configure a contrast-maximisation objective for event-sharded evaluation: every rank warps to the GLOBAL
     reference time ts[-1] and IWE / dIWE are all-reduced before the blur and the scalar reductions, which then run

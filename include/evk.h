@@ -412,6 +412,18 @@ int evk_iwe_linvel_tiled_batch3_f32(const float *records, const uint32_t *bucket
 /* evk_objective_variance_f32 for nplanes stacked images: out = nplanes x 4 doubles. */
 int evk_objective_variance_planes_f32(const float *imgs, int nplanes, int h, int w, const double *host_weights,
                                       int radius, double *out, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* Row-sharded post-pass (multi-GPU option).  img = (1 | 3, hb, w) float32: the rows of ONE row block of the (ch, cw)
+ * image -- plane 0 the IWE, planes 1, 2 the dIWE for mode 1 / 3 -- including `radius` halo rows on every side that is not
+ * an edge of the whole image, already summed over the ranks.  The block is blurred with the 'reflect' rule at its own
+ * edges (exact: an edge of the buffer is either an edge of the image or lies beyond the halo) and the pixels of rows
+ * [y_lo, y_hi) of the buffer are added up.  mode 0: sums = [S v, S v^2]; mode 1: [S a, S d0, S d1, S a d0, S a d1];
+ * mode 3: those five, then S v, S v^2 of the blurred IWE (flags as evk_objective_variance_grad_f32).  `sums` = 8 doubles
+ * (device); all-reduce them over the ranks and finalise: mean = S0 / N, var = S1 / N - mean^2,
+ * g_i = 2 / N (S(3+i) - (S0 / N) S(1+i)) with N = ch * cw. */
+int evk_objective_variance_rows_f32(const float *img, int mode, int hb, int w, int y_lo, int y_hi,
+                                    const double *host_weights, int radius, uint32_t flags, double *sums, void *scratch,
+                                    int64_t scratch_bytes, void *stream);
 /* memset -> batch3 IWE -> gather -> fused blur + variance of each plane: out12 = 3 x 4 doubles. */
 int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h,
                                        int dom_w, int tw_log2, int th_log2, int slices, int win_w, int win_h,

@@ -80,6 +80,27 @@ def _worker(rank, world, port, n, out_dir):
                            dtype=np.float64))
     f_sh, g_sh = DD.sharded_evaluate(local_iwe, finish)
     err3 = max(abs(f_sh - f_full) / abs(f_full), np.abs(g_sh - g_full).max() / np.abs(g_full).max())
+    # the same evaluation with the ROW-SHARDED post-pass (distributed.sharded_evaluate_rows): all-to-all of row blocks with
+    # halo -> every rank blurs its block (scipy on the block: 'reflect' at the block's own edges, sums over its own rows) ->
+    # 8-double all-reduce -> finalise_sums.  Un-mixed blur (reference_exact=False): the oracle's consistent gradient.
+    from scipy.ndimage import gaussian_filter
+
+    def rows_post(block, y_lo, y_hi):
+        b = block.numpy().astype(np.float32)
+        v = gaussian_filter(b[0], 1.0)[y_lo:y_hi].astype(np.float64)
+        d0 = gaussian_filter(b[1], 1.0)[y_lo:y_hi].astype(np.float64)
+        d1 = gaussian_filter(b[2], 1.0)[y_lo:y_hi].astype(np.float64)
+        return torch.tensor([v.sum(), d0.sum(), d1.sum(), (v * d0).sum(), (v * d1).sum(), v.sum(), (v * v).sum(), 0.0],
+                            dtype=torch.float64)
+    res = DD.sharded_evaluate_rows(lambda: local_iwe().to(torch.float32), rows_post, 4, 3)
+    full = np.concatenate([iwe_full[None], d_full]).astype(np.float32)
+    vf = gaussian_filter(full[0], 1.0).astype(np.float64)
+    gf = [gaussian_filter(full[1 + k], 1.0).astype(np.float64) for k in range(2)]
+    npx = vf.size
+    want = np.array([2.0 / npx * ((vf * gf[0]).sum() - vf.mean() * gf[0].sum()),
+                     2.0 / npx * ((vf * gf[1]).sum() - vf.mean() * gf[1].sum()), vf.mean(), vf.var()])
+    err3 = max(err3, float(np.abs(res - want).max() / np.abs(want).max()))
+    assert DD.row_block(H + 1, 4, 0, world)[:2] == (0, (H + 1) // 2) and DD.row_block(H + 1, 4, world - 1, world)[1] == H + 1
     both = torch.tensor([f_sh, -f_sh], dtype=torch.float64)           # identical scalars on every rank
     dist.all_reduce(both, op=dist.ReduceOp.MAX)
     same = float(both[0]) == f_sh and float(both[1]) == -f_sh

@@ -125,3 +125,59 @@ def test_two_emulated_ranks_are_additive():
         lo, hi = DD.shard_bounds(n, rank, 2)
         acc += _voxel_f32_device(*(c[lo:hi] for c in cols), B, (H, W), float(t[0]), float(t[-1]))
     assert (acc - full).abs().max().item() <= 1e-5 * full.abs().max().item()
+
+
+@pytest.mark.parametrize("sigma", [1.0, 0.0, 2.0])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_row_sharded_post_pass_equals_the_replicated_one(world, sigma):
+    """evk_objective_variance_rows_f32 on the row blocks (with halo) of `world` emulated ranks, raw sums added, finalised
+    on the host (distributed.finalise_sums) == the full-image fused post-pass, for the value, the reference's gradient
+    (channel-mixing blur, raw IWE) and value + consistent gradient in one pass."""
+    from event_utils_amd import _device as D, _lib, distributed as DD
+    from event_utils_amd.contrast_max.objectives import _blur_kernel
+    ch, cw = 181, 241
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy(rng.normal(size=(3, ch, cw)).astype(np.float32)).cuda()
+    w, radius = _blur_kernel(sigma)
+    wp = D.host_ptr(w) if w is not None else None
+    dev = img.device
+    out, (scratch, nbytes) = D.out4(dev), D.reduce_scratch(dev)
+    sums = torch.zeros(8, dtype=torch.float64, device=dev)
+    cases = ((0, 0, "evk_objective_variance_f32"), (1, _lib.EVK_POST_MIX, "evk_objective_variance_grad_f32"),
+             (3, _lib.EVK_POST_BLUR_IWE, "evk_objective_variance_fg_f32"))
+    for mode, flags, fn in cases:
+        if mode == 0:
+            _lib.call(fn, D.ptr(img), ch, cw, wp, radius, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+        else:
+            _lib.call(fn, D.ptr(img), D.ptr(img[1:]), ch, cw, wp, radius, flags, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+        want = out.cpu().numpy().copy()
+        total = np.zeros(8)
+        for rank in range(world):
+            y0, y1, lo, hi = DD.row_block(ch, max(radius, 0), rank, world)
+            block = img[:, lo:hi, :].contiguous()
+            _lib.call("evk_objective_variance_rows_f32", D.ptr(block), mode, hi - lo, cw, y0 - lo, y1 - lo, wp, radius, flags,
+                      D.ptr(sums), D.ptr(scratch), nbytes, D.stream())
+            total += sums.cpu().numpy()
+        got = DD.finalise_sums(total, ch * cw, mode)
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max() + 1e-15, (mode, world, got, want)
+
+
+def test_shard_objective_with_row_sharded_post(pg, monkeypatch):
+    """EVK_SHARDED_POST=rows through shard_objective on the 1-rank RCCL group == the replicated post-pass."""
+    import event_utils_amd as E
+    from event_utils_amd import distributed as DD
+    from event_utils_amd.events import DeviceEvents
+    H, W, n = 120, 160, 400_000
+    x, y, t, p = _events(3, n, H, W)
+    ev = DeviceEvents.from_arrays(x, y, t, p)
+    w, prm = E.linvel_warp(), np.array([30., -20.])
+    res = {}
+    for mode in ("replicated", "rows"):
+        monkeypatch.setenv("EVK_SHARDED_POST", mode)
+        obj = DD.shard_objective(E.variance_objective(), float(t[-1]))
+        obj.sensor_size = (H, W)
+        f = float(obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0))
+        g = f64(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0))
+        fg = obj.evaluate_function_and_gradient(prm, ev, None, None, None, w, (H, W), 1.0)
+        res[mode] = np.concatenate([[f], g, [float(fg[0])], f64(fg[1])])
+    assert np.abs(res["rows"] - res["replicated"]).max() <= 1e-9 * np.abs(res["replicated"]).max()
