@@ -534,15 +534,13 @@ struct IweParams {
     float pair_sI, pair_sE, pair_invI, pair_invE;  // FIXED 2: 2^20 / pow2ceil(bound) for the IWE / E planes, inverses
 };
 
-// Same per-event arithmetic as evk_scatter.hip's iwe_event (kept textually identical: parity depends on it).
+// Same per-event arithmetic as evk_scatter.hip's iwe_event (parity depends on it; the polarity shortcut below is exact).
 __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &q, double vx, double vy, int &px,
                                               int &py, float &dx, float &dy, float &mp, float &jf) {
     const double dt = (double)r.z - q.t_ref;
     const double xw = (double)r.x - dt * vx;
     const double yw = (double)r.y - dt * vy;
     if (xw <= 0.0 || xw > q.bw || yw <= 0.0 || yw > q.bh) return false;
-    const double ps = (double)r.w * q.p_scale;
-    const double pd = q.abs_p ? fabs(ps) : ps;
     const float xf = (float)xw, yf = (float)yw;
     if (xf >= q.clipx || yf >= q.clipy) return false;
     const float fx = floorf(xf), fy = floorf(yf);
@@ -550,7 +548,14 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
     dy = yf - fy;
     px = (int)fx;
     py = (int)fy;
-    mp = (float)pd;
+    // polarity: (float)((double)p * p_scale) [, |.|] -- with p_scale == 1 (everything but the adaptive-lifespan x100, Q10)
+    // that is p itself, bit for bit, and the two conversions and the float64 multiply go away
+    if (q.p_scale == 1.0) {
+        mp = q.abs_p ? fabsf(r.w) : r.w;
+    } else {
+        const double ps = (double)r.w * q.p_scale;
+        mp = (float)(q.abs_p ? fabs(ps) : ps);
+    }
     jf = (float)(-dt);
     return true;
 }
@@ -679,7 +684,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             // round-to-nearest double -> int64 with one add: for |x| < 2^51 the low mantissa bits of x + 1.5*2^52 hold
             // x as a two's-complement integer (the host caps k so that every contribution satisfies |x| < 2^50)
             const double magic = 6755399441055744.0;
-            const long long fx = __double_as_longlong((double)v * q.fx_scale + magic) - __double_as_longlong(magic);
+            // (fma: one instruction; the product by a power of two is exact, so the single rounding changes nothing)
+            const long long fx = __double_as_longlong(__builtin_fma((double)v, q.fx_scale, magic)) - __double_as_longlong(magic);
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)fx,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else
