@@ -125,6 +125,35 @@ def test_full_size_iwe_properties(cfg, monkeypatch):
     assert np.max(np.abs(np.asarray(gt, float) - np.asarray(gd, float))) <= 1e-5 * np.max(np.abs(np.asarray(gd, float))) + 1e-9
 
 
+def test_full_size_compact_records_and_balanced_plan(monkeypatch):
+    """50 M sensor events (integer pixels) at 1280x720: beyond the Infinity Cache the bucketing compacts its records by
+    itself (EVK_IWE_RECORDS=auto) and, on the moving-edge scene, balances the plan.  Mass conservation, and IWE / dIWE
+    equal to those from the 16-byte records (same plan, same sums: bit-identical up to the float atomics of the few events
+    that leave their windows)."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.objectives import iwe_device
+    n, H, W = 50_000_000, 720, 1280
+    x, y, t, p = bench.structured_scene(3, n, H, W)
+    x, y = np.floor(x), np.floor(y)
+    prm = np.array([30., -20.])
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+    out = {}
+    for mode in ("auto", "full"):
+        monkeypatch.setenv("EVK_IWE_RECORDS", mode)
+        ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+        iwe, diwe = iwe_device(prm, ev, (H, W), True, True, (H, W))
+        bk = list(ev._buckets.values())
+        assert len(bk) == 1 and bool(bk[0].iwe_flag) == (mode == "auto") and bk[0].structured
+        out[mode] = (iwe, diwe)
+        del ev
+    inside = (x + 3.0 < W) & (y - 2.0 > 0)          # the flow moves an event by at most (+3, -2) px
+    assert inside.all()
+    assert abs(out["auto"][0].double().sum().item() - float(p.astype(np.float64).sum())) <= 1e-6 * n ** 0.5 + 1e-3
+    _close(out["auto"][0], out["full"][0])
+    _close(out["auto"][1], out["full"][1])
+
+
 def test_full_size_voxel_per_gpu_share_of_configs4(monkeypatch):
     """One rank's share of configs[4]: 50 M events, 1280x720, 5 bins.  Mass conservation (the two temporal weights of
     an event sum to 1: sum(grid) = sum(p)), tiled == direct, and additivity of two half streams voxelised against the
