@@ -472,8 +472,11 @@ def test_structured_scenes_are_flagged_and_balanced(E, monkeypatch):
     """The bucketing plan: a moving-edge scene (tiles hold 0.5 .. 2 x the mean) is flagged `structured`, its full tiles
     are split so that no work item exceeds ~the mean, and the item count stays within 2 per tile; uniform events are
     neither flagged nor split."""
+    import os
     import bench
     from event_utils_amd import tiled
+    if os.environ.get("EVK_BUCKET_BALANCE") == "0":
+        pytest.skip("the A/B switch of the balanced plan is off")
     H, W, n = 480, 640, 3_000_000
     for scene in ("edges", "uniform"):
         if scene == "edges":
