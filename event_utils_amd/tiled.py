@@ -170,41 +170,57 @@ def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
 
 
 def voxel_path():
-    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip)."""
-    return os.environ.get("EVK_VOXEL_PATH", "v2")
+    """'v3' = one-pass partition with 4-byte records (evk_voxel3.hip, default); 'v2' = the round-2 one-pass partition
+    with 8-byte records (evk_voxel2.hip); 'v1' = three-pass counting sort (evk_tiled.hip)."""
+    return os.environ.get("EVK_VOXEL_PATH", "v3")
+
+
+def voxel_deterministic():
+    """EVK_VOXEL_DETERMINISTIC=1: the tile kernel of the one-pass path accumulates 64-bit fixed point (order-free integer
+    adds) instead of float64 -- bit-identical grids from run to run.  One synchronisation per call (range check)."""
+    return os.environ.get("EVK_VOXEL_DETERMINISTIC", "0") == "1"
 
 
 def voxel2_shape(H, W, planes):
-    """Tile shape for the one-pass voxel path, or None when it does not apply (more tiles than the partition kernel's
-    LDS holds, accumulators beyond 64 KB)."""
+    """Tile shape for the one-pass voxel paths (v2 / v3), or None when they do not apply (more tiles than the partition
+    kernel's LDS holds, accumulators beyond 64 KB)."""
     L = _lib.lib()
+    ver = voxel_path()
+    max_tiles = L.evk_voxel3_max_tiles() if ver == "v3" else L.evk_voxel2_max_tiles()
     tw, th = voxel_tile_shape(H, W, planes)
     for a, b in ((tw, th), (5, 5)):
-        lb = int(os.environ.get("EVK_V2_LB", "10"))        # experiment: builds with -DV2_LB=11 take 2048-pixel tiles
-        if a + b <= lb and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= L.evk_voxel2_max_tiles() and planes * 8 << (a + b) <= (65536 if lb == 10 else 153600):
+        lb = int(os.environ.get("EVK_V2_LB", "10")) if ver == "v2" else 10   # experiment: -DV2_LB=11 builds take 2048-pixel tiles
+        if a + b <= lb and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= max_tiles and planes * 8 << (a + b) <= (65536 if lb == 10 else 153600):
             return a, b
     return None
 
 
 def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
-    """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
-    ts[-1] are read on the device (no transfer before the launch)."""
+    """evk_voxel3_f32 / evk_voxel3_native_f32 (or the round-2 evk_voxel2_* under EVK_VOXEL_PATH=v2): partition + tile
+    kernel from ONE library call.  t_first None = ts[0] and ts[-1] are read on the device (no transfer before the
+    launch)."""
     L = _lib.lib()
     dev = out.device
+    ver = "voxel3" if voxel_path() == "v3" else "voxel2"
     planes = 2 * B if split_polarity else B
     ntiles = L.evk_bucket_num_tiles(H, W, tw, th)
-    key = (ntiles, n, planes, tw, th)
-    sizes = _staging_bytes.get(("v2",) + key)
+    key = (ver, ntiles, n, planes, tw, th)
+    sizes = _staging_bytes.get(key)
     if sizes is None:
-        sizes = _staging_bytes[("v2",) + key] = (int(L.evk_voxel2_index_len(ntiles, n)),
-                                                 int(L.evk_voxel2_scratch_bytes(ntiles, n, planes, tw, th)))
-    index = _zbuf("voxel2_index", sizes[0], dev)
-    scratch = _buf("voxel2_scratch", sizes[1], dev)
+        sizes = _staging_bytes[key] = (int(getattr(L, "evk_%s_index_len" % ver)(ntiles, n)),
+                                       int(getattr(L, "evk_%s_scratch_bytes" % ver)(ntiles, n, planes, tw, th)))
+        if sizes[0] <= 0:
+            raise _lib.EvkError("evk_%s: unsupported geometry (%d tiles, %d events)" % (ver, ntiles, n))
+    index = _zbuf(ver + "_index", sizes[0], dev)
+    scratch = _buf(ver + "_scratch", sizes[1], dev)
     flags = (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | (_lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0) | stage
     if share_cu():
         flags |= 128         # EVK_VOXEL2_SHARE_CU
     if os.environ.get("EVK_V2_XCD_ORDER", "1") == "0":
         flags |= 64          # EVK_VOXEL2_NO_XCD_ORDER (A/B measurement)
+    det = ver == "voxel3" and voxel_deterministic()
+    if det:
+        flags |= _lib.EVK_VOXEL_DETERMINISTIC
     if t_first is None:
         flags |= _lib.EVK_VOXEL_T_FROM_EVENTS
         t_first = t_last = 0.0
@@ -212,9 +228,15 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
             oob.ptr if oob is not None else None, report, seq, D.stream())
     if native is None:
-        _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, *tail)
+        _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail)
     else:
-        _lib.call("evk_voxel2_native_f32", *native.head(), *tail)
+        _lib.call("evk_%s_native_f32" % ver, *native.head(), *tail)
+    if det and not (stage & _lib.EVK_VOXEL2_PARTITION_ONLY):
+        bad = int(index[4].item())          # synchronises: the deterministic mode is a debugging / verification mode
+        if bad:
+            index[4] = 0
+            raise ValueError("EVK_VOXEL_DETERMINISTIC: %d contributions were not finite or beyond 2^30 and cannot be "
+                             "accumulated in fixed point" % bad)
 
 
 def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
@@ -226,7 +248,7 @@ def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=N
     if not (can_tile((xd, yd, td, pd), impl) and 2 * B * 8 * 64 <= 65536):
         return None
     out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
-    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() == "v2" else None
+    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() in ("v2", "v3") else None
     if shape2 is not None:
         voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
         return out
@@ -248,7 +270,7 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
     else:
         tileable = can_tile((xd, yd, td, pd), impl)
-    if tileable and voxel_path() == "v2":
+    if tileable and voxel_path() in ("v2", "v3"):
         shape2 = voxel2_shape(H, W, B)
         if shape2 is not None:
             voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
@@ -497,12 +519,13 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
                 "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
     total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True),
                      reps)
-    shape2 = voxel2_shape(H, W, B) if voxel_path() == "v2" else None
+    shape2 = voxel2_shape(H, W, B) if voxel_path() in ("v2", "v3") else None
     if shape2 is not None:
         n = xd.shape[0]
         run2 = lambda stage: voxel2((xd, yd, td, pd), None, n, t_first, t_last, B, H, W, *shape2, out, None, True, stage=stage)
-        ms = {"k_part_sorted": _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
-              "k_voxel_tiles2": _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
+        kp, kt = ("k_part3", "k_voxel_tiles3") if voxel_path() == "v3" else ("k_part_sorted", "k_voxel_tiles2")
+        ms = {kp: _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
+              kt: _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
         dom = max(ms, key=ms.get)
         return {"impl": "one-pass partition, tiles %dx%d" % (1 << shape2[0], 1 << shape2[1]), "dominant": dom,
                 "dominant_ms": ms[dom], "total_ms": total, "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}
