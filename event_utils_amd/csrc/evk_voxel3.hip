@@ -37,6 +37,15 @@ namespace evk {
 #define V3_DELTA_LIMIT (1u << 20)
 #define V3_NULL 0xFFFFFC00u               // code 3, delta field all ones, pixel 0
 #define V3_NO_TILE 0xFFFFu
+// ablation builds (tools/v3_ablate.sh; timing only, results are wrong): the partition kernel stops a sub-chunk after stage
+// V3_ABLATE_P (1 loads + keys, 2 + histogram + scan, 3 + compression, 4 + placement; 9 = everything) / the tile kernel
+// leaves out V3_ABLATE_T (1 the LDS atomics, 2 the record loads, 3 the chunk rounds altogether, 4 the table walk too)
+#ifndef V3_ABLATE_P
+#define V3_ABLATE_P 9
+#endif
+#ifndef V3_ABLATE_T
+#define V3_ABLATE_T 0
+#endif
 #ifndef V3_TILES_MIN_WAVES
 #define V3_TILES_MIN_WAVES 6  // waves per SIMD the tile kernel must fit (<= 80 registers): 3 workgroups of 8 waves per CU
 #endif
@@ -126,8 +135,8 @@ struct Part3 {
     int nblk;
 };
 
-template <int THREADS, int EPT, typename C>
-__global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int64_t n, TileGrid g, int ntiles, Part3 q, float t_first,
+template <int THREADS, int EPT, int SCHED, typename C>
+__global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, TileGrid g, int ntiles, Part3 q, float t_first,
                                                                  float t_last, float bm1, int t_from_events,
                                                                  uint32_t *__restrict__ rec, uint2 *__restrict__ wide,
                                                                  uint32_t *__restrict__ table, uint32_t *__restrict__ bases,
@@ -189,14 +198,16 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int
             c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, 0, tv + G * k, pv + G * k);
         tb = c.t1((int64_t)sc * q.S);   // the sub-chunk's first event: base of the t_norm deltas (same address in every lane)
     };
-    if (sc0 < sc_end) load_xy(sc0);
-    EVK_WAIT_VM0();
-    for (int sc = sc0; sc < sc_end; ++sc) {
-        asm volatile("" : "+v"(tl_));
-        const int64_t slot0 = (int64_t)sc * q.spad;
-        for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;
-        // ---- tile key + pixel in tile of every event
-        uint32_t kl[EPT];
+    // Two schedules of one sub-chunk's phases (SCHED), measured against each other on the GPU (tools/v3_sweep.sh):
+    //   0: keys | t, p loads | histogram, scan | compress | x, y loads of j + 1 | placement | wait | write-out
+    //      -- a load burst overlaps the two phases after it; 3.5 registers per event (keys OR records + one column pair)
+    //   1: keys, compress | x, y, t, p loads of j + 1 | histogram, scan, placement | wait | write-out
+    //      -- ONE burst per sub-chunk that overlaps everything but the keys and the compression; 5.5 registers per event
+    uint32_t kl[EPT], w[EPT], tl[EPT / 2];
+    uint32_t kept = 0, bbits = 0;
+    uint32_t tval[PER_MAX];   // this thread's table entries: stored with the write-out (no store before the next loads)
+    auto tile_at = [&](int s) -> uint32_t { return (tl[s >> 1] >> (16 * (s & 1))) & 0xFFFFu; };
+    auto do_keys = [&](int sc) {   // tile key + pixel in tile of every event
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int nv = valid_in(sc, k);
@@ -213,16 +224,16 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int
             }
         }
 #pragma unroll
-        for (int s = 0; s < EPT; ++s) asm volatile("" : "+v"(kl[s])::"memory");  // keys first, the t, p loads after
-        load_tp(sc);         // land during the histogram and the scan
-        lds_only_barrier();  // hist is zero
-        // ---- histogram (no-return LDS atomics)
+        for (int s = 0; s < EPT; ++s) asm volatile("" : "+v"(kl[s])::"memory");  // keys first, any load after
+    };
+    auto do_hist = [&]() {   // no-return LDS atomics
 #pragma unroll
-        for (int s = 0; s < EPT; ++s)
-            if (kl[s] != 0xFFFFFFFFu)
-                __hip_atomic_fetch_add(&hist[kl[s] >> V3_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        lds_only_barrier();  // histogram complete
-        // ---- exclusive scan of the PADDED tile counts (thread tid owns tiles [i0, i1)) -> cursors; table row; null padding
+        for (int s = 0; s < EPT; ++s) {
+            const uint32_t tile = SCHED == 0 ? (kl[s] == 0xFFFFFFFFu ? V3_NO_TILE : kl[s] >> V3_LB) : tile_at(s);
+            if (tile != V3_NO_TILE) __hip_atomic_fetch_add(&hist[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto do_scan = [&]() {   // exclusive scan of the PADDED tile counts (thread tid owns tiles [i0, i1)) -> cursors; table row; null padding
         uint32_t cnts[PER_MAX];
         uint32_t mine = 0;
 #pragma unroll
@@ -231,9 +242,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int
             cnts[k] = (k < per && i < i1) ? hist[i] : 0u;
             mine += (cnts[k] + 3u) & ~3u;
         }
-        uint32_t kept;   // slots of the run, padding included (% 4 == 0)
-        uint32_t run = wg_excl_scan<THREADS>(mine, tmp, kept);
-        uint32_t tval[PER_MAX];   // this thread's table entries: stored with the write-out (no store before the next loads)
+        uint32_t run = wg_excl_scan<THREADS>(mine, tmp, kept);   // kept = slots of the run, padding included (% 4 == 0)
 #pragma unroll
         for (int k = 0; k < PER_MAX; ++k) {
             const int i = i0 + k;
@@ -247,10 +256,9 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int
                 run += pc;
             }
         }
-        lds_only_barrier();  // cursors complete (also frees tmp)
-        // ---- (key, t, p) -> record word.  t, p have landed during the histogram and the scan.
-        const uint32_t bbits = __float_as_uint((tb - t_first) / dt * bm1);
-        uint32_t w[EPT], tl[EPT / 2];
+    };
+    auto do_compress = [&](int64_t slot0) {   // (key, t, p) -> record word + 16-bit tile
+        bbits = __float_as_uint((tb - t_first) / dt * bm1);
 #pragma unroll
         for (int s = 0; s < EPT / 2; ++s) tl[s] = 0;
 #pragma unroll
@@ -276,39 +284,81 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k_part3(const C c, int
             tl[s >> 1] |= (live ? (kl[s] >> V3_LB) : V3_NO_TILE) << (16 * (s & 1));
             __builtin_amdgcn_sched_barrier(0);   // one division at a time: interleaved they cost ~5 registers of temporaries each
         }
-        // Nothing outstanding from here (t, p are in; the previous sub-chunk's stores are a histogram and a scan old) -- said
-        // with the builtin so that the loop's later uses get no wait of their own.
-        EVK_WAIT_VM0();
-        // (fences for the compiler: hoisted above the compression, the 2 * EPT registers of the next x, y would be live
-        // together with t, p and the keys -- 6 registers per event instead of 3.5)
+    };
+    auto fence = [&]() {   // for the compiler: loads hoisted above a compute phase keep their 2 * EPT registers live through it
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement and the write-out
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer
+    };
+    auto do_place = [&]() {   // a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer
 #pragma unroll
         for (int s = 0; s < EPT; ++s) {
-            const uint32_t tile = (tl[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
+            const uint32_t tile = tile_at(s);
             if (tile != V3_NO_TILE) {
                 const uint32_t pos = atomicAdd(&hist[tile], 1u);
                 sorted[pos] = w[s];
             }
         }
-        lds_only_barrier();
-        EVK_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement
-        // ---- one contiguous, coalesced run of `kept` record slots
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
-            uint4 *dst = reinterpret_cast<uint4 *>(rec + slot0);
-            const int n16 = (int)(kept >> 2);
-            for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
-        }
+    };
+    auto do_writeout = [&](int sc, int64_t slot0) {   // one contiguous, coalesced run of `kept` record slots; the table row
+        const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
+        uint4 *dst = reinterpret_cast<uint4 *>(rec + slot0);
+        const int n16 = (int)(kept >> 2);
+        for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
         uint32_t *trow = table + (int64_t)sc * q.nt_pad;
 #pragma unroll
         for (int k = 0; k < PER_MAX; ++k)
             if (k < per && i0 + k < i1) trow[i0 + k] = tval[k];
         if (tid == 0) bases[sc] = bbits;
+    };
+    for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;   // (every pass leaves it zero again)
+    if (sc0 < sc_end) {
+        load_xy(sc0);
+        if (SCHED == 1) load_tp(sc0);
+    }
+    // vmcnt(0) as a BUILTIN, so that the compiler's wait-count pass knows the loads are in: their first use, at the top of the
+    // loop, would otherwise get an `s_waitcnt vmcnt(0)` of its own -- and that one also waits for the write-out stores of the
+    // previous sub-chunk (gfx9 has ONE counter for loads and stores)
+    EVK_WAIT_VM0();
+    lds_only_barrier();
+    for (int sc = sc0; sc < sc_end; ++sc) {
+        asm volatile("" : "+v"(tl_));
+        const int64_t slot0 = (int64_t)sc * q.spad;
+        do_keys(sc);
+        if constexpr (SCHED == 0) {
+            load_tp(sc);         // land during the histogram and the scan
+            if (V3_ABLATE_P >= 2) {
+                do_hist();
+                lds_only_barrier();  // histogram complete
+                do_scan();
+                lds_only_barrier();  // cursors complete (also frees tmp)
+            }
+            if (V3_ABLATE_P >= 3) do_compress(slot0);
+            else {
+                uint32_t sink = 0;
+#pragma unroll
+                for (int s = 0; s < EPT; ++s) sink += kl[s] ^ __float_as_uint(tv[s]) ^ __float_as_uint(pv[s]), w[s] = sink;
+#pragma unroll
+                for (int s = 0; s < EPT / 2; ++s) tl[s] = sink == 0x12345u ? 0u : 0xFFFFFFFFu;
+            }
+            EVK_WAIT_VM0();      // nothing outstanding (t, p are in; the previous stores are a histogram and a scan old)
+            fence();
+            if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement
+            fence();
+        } else {
+            do_compress(slot0);
+            fence();
+            if (sc + 1 < sc_end) load_xy(sc + 1), load_tp(sc + 1);  // in flight during the histogram, the scan and the placement
+            fence();
+            do_hist();
+            lds_only_barrier();
+            do_scan();
+            lds_only_barrier();
+        }
+        if (V3_ABLATE_P >= 4) do_place();
+        lds_only_barrier();
+        EVK_WAIT_VM0();   // the next sub-chunk's columns have landed: the stores below then never sit between a load and its use
+        if (V3_ABLATE_P >= 9) do_writeout(sc, slot0);
+        for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;   // cursors are dead: zero for the next pass
         lds_only_barrier();  // sorted / hist are rewritten by the next sub-chunk
     }
     if (dropped && oob) atomicAdd(oob, dropped);
@@ -496,8 +546,58 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
             bins_general(acc + B * ppix, local, tn, 1.0f);
         }
     };
-    auto quad = [&](const uint4 &v, uint32_t bbits, uint32_t q4) {   // the 4 records of quad q4
-        one(v.x, bbits, 4u * q4), one(v.y, bbits, 4u * q4 + 1u), one(v.z, bbits, 4u * q4 + 2u), one(v.w, bbits, 4u * q4 + 3u);
+    // The 4 records of quad q4 (`mine` false: this lane has no quad in this round).  ~99.9 % of all rounds hold nothing but
+    // ordinary records -- a polarity code, t_norm inside [0, B - 1] -- and padding: those take STRAIGHT-LINE code, one
+    // wave-uniform branch per quad.  (Per-record branches for the escape, the padding, the out-of-range bins and the last
+    // bin were ~14 s_cbranch and ~230 instructions of text per record: the tile kernel was bound by instruction issue,
+    // not by its LDS atomics or its record loads.)
+    auto quad = [&](const uint4 &v, uint32_t bbits, uint32_t q4, bool mine) {
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+        float tn[4];
+        bool real[4], bad = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tn[i] = __uint_as_float(bbits + (wd[i] >> V3_DELTA_SHIFT));
+            real[i] = mine & (wd[i] != V3_NULL);
+            bad |= real[i] & ((((wd[i] >> V3_CODE_SHIFT) & 3u) == 3u) | !(tn[i] >= 0.0f) | !(tn[i] <= bm1));
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+            if (mine) one(v.x, bbits, 4u * q4), one(v.y, bbits, 4u * q4 + 1u), one(v.z, bbits, 4u * q4 + 2u), one(v.w, bbits, 4u * q4 + 3u);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // bins b0 = floor(t_norm) and b0 + 1 with the weights of voxel_grid.py:138 -- 1 - |t_norm - b| evaluated exactly as
+            // there (for b0 the absolute value is the identity; max(0, .) cannot bind for these two bins).  A zero weight is
+            // added like any other (x + 0 = x; the reference's index_put_ adds it too); at t_norm == B - 1 the upper bin does
+            // not exist and its weight is exactly 0: it is added to the lower bin's cell instead of being branched around.
+            const uint32_t code = (wd[i] >> V3_CODE_SHIFT) & 3u;
+            const int lraw = (int)(wd[i] & V3_LOCAL_MASK);
+            const int b0 = (int)tn[i];
+            acc_t *a = acc + (lraw + (lraw >> g.tw_log2)) + b0 * ppix;   // row * (tw + 1) + column, plane b0
+            float wgt = __uint_as_float(code == 2u ? 0u : (0x3F800000u | (code << 31)));
+            if constexpr (split) {
+                a += code == 0u ? 0 : B * ppix;   // +1 -> the grid of the positive events; -1, 0 -> the other one
+                wgt = 1.0f;
+            }
+            const float v0 = wgt * (1.0f - (tn[i] - (float)b0)), v1 = wgt * (1.0f - fabsf(tn[i] - (float)(b0 + 1)));
+            if (V3_ABLATE_T == 1) {
+                if (real[i] && v0 + v1 == 1.2345e-30f) a[0] = 1.0;
+                continue;
+            }
+            if (real[i]) {
+                if constexpr (FIXED) {   // |v| <= 1 here: no range test
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a), (unsigned long long)__double2ll_rn((double)v0 * V3_FIXED_ONE),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a + (b0 + 1 < B ? ppix : 0)),
+                                           (unsigned long long)__double2ll_rn((double)v1 * V3_FIXED_ONE), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    lds_add(a, v0);
+                    lds_add(a + (b0 + 1 < B ? ppix : 0), v1);
+                }
+            }
+        }
     };
     // Entries go to the threads in equal batches, INTERLEAVED over the waves (slot = lane * NW + wave): a short range -- the
     // last batch of a tile, or one of the many parts of a hot tile -- then still gives every wave its share
@@ -510,7 +610,7 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
         if (slot < bsz && my < sc_hi) ent_next = col[(int64_t)my * q.nt_pad], base_next = bases[my];
     }
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(rec);
-    for (int base = sc_lo; base < sc_hi; base += bsz) {
+    for (int base = sc_lo; base < (V3_ABLATE_T >= 4 ? sc_lo : sc_hi); base += bsz) {
         const uint32_t ent = ent_next, bb = base_next;
         {   // next batch's entries: in flight while this batch is processed
             const int my = base + bsz + slot;
@@ -536,8 +636,9 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
             cseg[wave][excl + k] = make_uint2(((q0 + 4u * k) << 2) | ((left < 4u ? left : 4u) - 1u), bb);
         }
         __syncthreads();
-        // Chunk rounds, software-pipelined in three stages: list entries of round r + 2 (LDS) | record loads of round r + 1
-        // (global) | accumulation of round r.  The loads are UNCONDITIONAL -- a lane without a quad reads the head of the
+        // Chunk rounds, software-pipelined in two stages: list entries + record loads of round r + 1 | accumulation of round r
+        // (a third stage -- list entries two rounds ahead, as in round 2 -- costs 4 registers the straight-line accumulate
+        // needs more).  The loads are UNCONDITIONAL -- a lane without a quad reads the head of the
         // record buffer -- so that nothing but arithmetic sits between them and the compiler can wait for the older round
         // alone (`vmcnt(U)`).  The two workgroup barriers per batch are kept on purpose: all tiles walking the runs in step
         // keeps each run L2-hot while its segments are pulled.
@@ -551,31 +652,25 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
         auto mine_q = [&](const uint2 &cs) -> bool { return cs.x != 0xFFFFFFFFu && (uint32_t)sub <= (cs.x & 3u); };
         auto fire = [&](const uint2(&cs)[U], uint4(&v)[U]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = rec4[mine_q(cs[u]) ? (cs[u].x >> 2) + sub : (uint32_t)sub];
+            for (int u = 0; u < U; ++u) v[u] = rec4[(V3_ABLATE_T != 2 && mine_q(cs[u])) ? (cs[u].x >> 2) + sub : (uint32_t)sub];
         };
         auto eat = [&](const uint2(&cs)[U], const uint4(&v)[U]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (mine_q(cs[u])) quad(v[u], cs[u].y, (cs[u].x >> 2) + sub);
+            for (int u = 0; u < U; ++u) quad(v[u], cs[u].y, (cs[u].x >> 2) + sub, mine_q(cs[u]));
         };
         constexpr uint32_t step = 16u * U;
-        {
-            uint2 ca[U], cb[U], cn[U];
+        if (V3_ABLATE_T < 3) {
+            uint2 ca[U], cb[U];
             uint4 va[U], vb[U];
             meta(0u, ca);
             fire(ca, va);
-            meta(step, cb);
             for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
-                fire(cb, vb);               // round j0 + step
-                meta(j0 + 2u * step, cn);
-                eat(ca, va);                // round j0
-                fire(cn, va);               // round j0 + 2 step
-#pragma unroll
-                for (int u = 0; u < U; ++u) ca[u] = cn[u];
-                meta(j0 + 3u * step, cn);
-                eat(cb, vb);                // round j0 + step
-#pragma unroll
-                for (int u = 0; u < U; ++u) cb[u] = cn[u];
+                meta(j0 + step, cb);
+                fire(cb, vb);               // round j0 + step in flight ...
+                eat(ca, va);                // ... while round j0 is accumulated
+                meta(j0 + 2u * step, ca);
+                fire(ca, va);
+                eat(cb, vb);
             }
         }
         // long segments: the whole wave streams each of them, one quad per lane
@@ -585,9 +680,11 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
             m &= m - 1;
             const uint32_t e2 = __shfl(ent, s, 64), b2 = __shfl(bb, s, 64);
             const uint32_t qb = (uint32_t)(base + s * NW + wave) * spad4 + (e2 & 0xFFFFu), qe = qb + (e2 >> 16);  // lane s's sub-chunk
-            for (uint32_t q4 = qb + lane; q4 < qe; q4 += 64u) {
-                const uint4 v = rec4[q4];
-                quad(v, b2, q4);
+            for (uint32_t q0w = qb; q0w < qe; q0w += 64u) {   // (wave-uniform trip count: quad() votes across the wave)
+                const uint32_t q4 = q0w + lane;
+                const bool in = q4 < qe;
+                const uint4 v = rec4[in ? q4 : qb];
+                quad(v, b2, q4, in);
             }
         }
     }
@@ -643,24 +740,43 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
 }
 
 // ---- host-side geometry -----------------------------------------------------------------------------------------
-#define V3_THREADS 1024
 #define V3_MIN_SUBCHUNK 8192
-// events per partition thread: 16 (sub-chunks of <= 16 K events, 64 KB of sorted records); a call that has to share its
-// CUs with another kernel's workgroups (EVK_VOXEL2_SHARE_CU: multi-rank jobs, the collective's channels) takes 8
-static int v3_ept(bool share) {
-    static const int forced = [] {
-        const char *s = getenv("EVK_V3_EPT");
-        const int v = s ? atoi(s) : 0;
-        return (v == 8 || v == 12 || v == 16) ? v : 0;
+// Partition geometry: threads per workgroup x events per thread x schedule (k_part3).  Default 1024 x 16 x 0; a call that
+// has to share its CUs with another kernel's workgroups (EVK_VOXEL2_SHARE_CU: multi-rank jobs, the collective's channels)
+// takes 8 events per thread (half the LDS).  EVK_V3_GEO=TxExS selects another compiled geometry (experiments).
+struct V3Geo {
+    int threads, ept, sched;
+};
+// geometries compiled into the library: the two the default dispatch reaches; more under -DEVK_EXPERIMENTS (tools builds)
+#ifdef EVK_EXPERIMENTS
+#define V3_GEOMETRIES(X) X(1024, 16, 0) X(1024, 8, 0) X(1024, 12, 0) X(1024, 8, 1) X(1024, 12, 1) X(512, 16, 0) X(512, 16, 1) X(512, 12, 1) X(512, 8, 1)
+#else
+#define V3_GEOMETRIES(X) X(1024, 16, 0) X(1024, 8, 0)
+#endif
+static bool v3_geo_compiled(const V3Geo &g) {
+#define X(T, E, S) if (g.threads == T && g.ept == E && g.sched == S) return true;
+    V3_GEOMETRIES(X)
+#undef X
+    return false;
+}
+
+static V3Geo v3_geo(bool share) {
+    static const V3Geo forced = [] {
+        V3Geo g{0, 0, 0};
+        const char *s = getenv("EVK_V3_GEO");
+        if (s && sscanf(s, "%dx%dx%d", &g.threads, &g.ept, &g.sched) == 3 && v3_geo_compiled(g)) return g;
+        return V3Geo{0, 0, 0};
     }();
-    if (forced) return forced;
-    return share ? 8 : 16;
+    if (forced.threads) return forced;
+    return share ? V3Geo{1024, 8, 0} : V3Geo{1024, 16, 0};
 }
 
 static Part3 v3_geometry(int64_t n, int ntiles, bool share) {
-    const int64_t smax = (int64_t)V3_THREADS * v3_ept(share);
+    const V3Geo geo = v3_geo(share);
+    const int64_t smax = (int64_t)geo.threads * geo.ept;
     int64_t nblk = (n + V3_MIN_SUBCHUNK - 1) / V3_MIN_SUBCHUNK;
-    if (nblk > EVK_NUM_CU) nblk = EVK_NUM_CU;
+    const int64_t max_blk = (int64_t)EVK_NUM_CU * (1024 / geo.threads);
+    if (nblk > max_blk) nblk = max_blk;
     if (nblk < 1) nblk = 1;
     int64_t per_block = (n + nblk * smax - 1) / (nblk * smax);
     if (per_block < 1) per_block = 1;
@@ -693,8 +809,8 @@ static V3Layout v3_layout(int ntiles, int64_t n, int planes, int tw_log2, int th
     return L;
 }
 
-static size_t v3_part_lds(int ept, int ntiles) {
-    return (size_t)((V3_THREADS * ept + 3 * ntiles + 7) & ~3) * 4 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
+static size_t v3_part_lds(int threads, int ept, int ntiles) {
+    return (size_t)((threads * ept + 3 * ntiles + 7) & ~3) * 4 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
 }
 
 }  // namespace evk
@@ -716,11 +832,11 @@ extern "C" int64_t evk_voxel3_scratch_bytes(int ntiles, int64_t n, int planes, i
 // largest tile count the partition kernel's LDS holds
 extern "C" int evk_voxel3_max_tiles(void) {
     int t = VP_MAX_TILES;
-    while (t > 0 && v3_part_lds(16, t) > 160 * 1024 - 512) t -= 16;
+    while (t > 0 && v3_part_lds(1024, 16, t) > 160 * 1024 - 512) t -= 16;
     return t;
 }
 
-template <int EPT, typename C>
+template <int THREADS, int EPT, int SCHED, typename C>
 static void launch_part3(const C &c, int64_t n, const TileGrid &g, int ntiles, const Part3 &q, float t_first, float t_last,
                          float bm1, int tfe, uint32_t *rec, uint2 *wide, uint32_t *table, uint32_t *bases, uint32_t *index,
                          uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
@@ -728,13 +844,11 @@ static void launch_part3(const C &c, int64_t n, const TileGrid &g, int ntiles, c
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {
-        (void)hipFuncSetAttribute((const void *)k_part3<V3_THREADS, EPT, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_part3<THREADS, EPT, SCHED, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 256);
     });
-    k_part3<V3_THREADS, EPT, C><<<q.nblk, V3_THREADS, v3_part_lds(EPT, ntiles), s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide,
-                                                                                    table, bases, index,
-                                                                                    (uint32_t)bucket_cap(n, ntiles), oob,
-                                                                                    host_report, seq);
+    k_part3<THREADS, EPT, SCHED, C><<<q.nblk, THREADS, v3_part_lds(THREADS, EPT, ntiles), s>>>(
+        c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide, table, bases, index, (uint32_t)bucket_cap(n, ntiles), oob, host_report, seq);
 }
 
 template <bool SPLIT, bool FIXED>
@@ -782,10 +896,12 @@ static int voxel3(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
-        const int ept = v3_ept(share);
-        if (ept == 8) launch_part3<8>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide, table, bases, index, oob, host_report, seq, s);
-        else if (ept == 12) launch_part3<12>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide, table, bases, index, oob, host_report, seq, s);
-        else launch_part3<16>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide, table, bases, index, oob, host_report, seq, s);
+        const V3Geo geo = v3_geo(share);
+#define X(T, E, S)                                                                                                          \
+    if (geo.threads == T && geo.ept == E && geo.sched == S)                                                                  \
+        launch_part3<T, E, S>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, wide, table, bases, index, oob, host_report, seq, s);
+        V3_GEOMETRIES(X)
+#undef X
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int items = bucket_max_items(n, ntiles);

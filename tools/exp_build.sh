@@ -1,0 +1,9 @@
+#!/bin/bash
+# Experiments build of libevk.so (-DEVK_EXPERIMENTS: every partition geometry of evk_voxel3.hip, the round-2 variants of
+# evk_voxel2.hip), loaded with EVK_LIB_PATH=tools/exp/libevk_exp.so.  Extra -D flags may be passed as arguments.
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tools/exp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function -ldl \
+  -DEVK_EXPERIMENTS "$@" event_utils_amd/csrc/*.hip -o tools/exp/libevk_exp.so
+ls -la tools/exp/libevk_exp.so

@@ -96,7 +96,7 @@ def timing(n, H, W, B, reps=20, paths=("v3",), kind="uniform"):
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    print("variant: EVK_V3_EPT=%s LIB=%s" % (os.environ.get("EVK_V3_EPT", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
+    print("variant: EVK_V3_GEO=%s LIB=%s" % (os.environ.get("EVK_V3_GEO", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
     if "--check" in sys.argv:
         check()
     paths = ("v3", "v2") if "--v2" in sys.argv else ("v3",)
