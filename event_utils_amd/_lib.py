@@ -67,10 +67,6 @@ SIGNATURES = {
                        P, P, c_uint32, P],
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
                               c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
-    "evk_voxel3_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, c_int64,
-                       P, P, c_uint32, P],
-    "evk_voxel3_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
-                              c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],
@@ -96,6 +92,16 @@ _SPECIAL = {
     "evk_voxel2_max_tiles": ([], c_int),
     "evk_voxel2_index_len": ([c_int, c_int64], c_int64),
     "evk_voxel2_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
+    "evk_voxel2_num_tiles": ([c_int, c_int, c_int, c_int], c_int),
+}
+
+
+# entry points of experiments builds only (-DEVK_EXPERIMENTS, csrc/evk_experiments.h): bound when the loaded library has them
+_OPTIONAL = {
+    "evk_voxel3_f32": ([P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, c_int64,
+                        P, P, c_uint32, P], c_int),
+    "evk_voxel3_native_f32": ([P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
+                               c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P], c_int),
     "evk_voxel3_max_tiles": ([], c_int),
     "evk_voxel3_index_len": ([c_int, c_int64], c_int64),
     "evk_voxel3_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
@@ -128,6 +134,11 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = restype
+        for name, (argtypes, restype) in _OPTIONAL.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.argtypes = argtypes
+                fn.restype = restype
         _lib = L
     return _lib
 

@@ -50,17 +50,48 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t mine, uint32_t *tmp, u
     return tmp[32 + wave] + incl - mine;   // the caller puts a barrier before tmp is used again
 }
 
-// Nearest-pixel key (EVK_KEY_NEAREST of tile_key) that also returns the pixel inside the tile.  Branch-free: sixteen of
-// these per thread with early returns became thirty-two divergent branches and the register allocator spilled across them.
-__device__ __forceinline__ int nearest_key_local(float x, float y, const TileGrid &g, uint32_t &local) {
+// Tile grid of the one-pass voxel paths: tiles of ANY width and height (pixels), not only powers of two, so that the
+// tile COUNT can be chosen: the tile kernel runs one workgroup per tile, all resident at once, and a launch lasts as long
+// as the busiest CU -- 600 tiles of 32x16 on 256 CUs are 3 workgroups on 88 CUs and 2 on the others (measured: the same
+// 10 M events on a 512x512 sensor, 512 tiles, take 17 % less), 512 tiles of 20x30 are 2 everywhere.
+// Inside a tile a pixel is addressed as row * pitch + column with an ODD pitch (tile_w | 1): that is directly the index of
+// its LDS accumulator cell (the events of a real scene sit on edges -- same column, different rows -- and an even pitch
+// would put every row of a column on the same pair of banks).  Divisions by the tile size are multiplications by
+// ceil(2^32 / d) (exact for operands below 2^16).
+struct TileGridG {
+    int tw, th, pitch;     // tile size in pixels; accumulator row pitch in cells
+    int tiles_x, tiles_y;
+    int dom_w, dom_h;      // key domain in pixels
+    uint32_t mx, my, mp;   // ceil(2^32 / tw), ceil(2^32 / th), ceil(2^32 / (tw * th))
+};
+__host__ __device__ inline uint32_t magic_div(uint32_t d) { return (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); }
+__device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t m) { return __umulhi(x, m); }   // x / d for x < 2^16
+#define EVK_GRIDG_MAX_CELLS 1024   // pitch * th: the pixel field of a record has 10 bits
+
+static inline int make_grid_g(TileGridG &g, int dom_h, int dom_w, int tw, int th) {
+    if (dom_h <= 0 || dom_w <= 0 || dom_h > 65535 || dom_w > 65535 || tw < 4 || th < 4 || tw > 256 || th > 256 ||
+        (tw | 1) * th > EVK_GRIDG_MAX_CELLS)
+        return EVK_EINVAL;
+    g.tw = tw, g.th = th, g.pitch = tw | 1;
+    g.dom_w = dom_w, g.dom_h = dom_h;
+    g.tiles_x = (dom_w + tw - 1) / tw;
+    g.tiles_y = (dom_h + th - 1) / th;
+    g.mx = magic_div((uint32_t)tw), g.my = magic_div((uint32_t)th), g.mp = magic_div((uint32_t)(tw * th));
+    return EVK_OK;
+}
+
+// Nearest-pixel key (EVK_KEY_NEAREST of tile_key): the tile of an event, and the accumulator cell inside the tile.
+// Branch-free: sixteen of these per thread with early returns became thirty-two divergent branches and the register
+// allocator spilled across them.
+__device__ __forceinline__ int nearest_key_cell(float x, float y, const TileGridG &g, uint32_t &cell) {
     int xi = (int)x, yi = (int)y;   // .long() truncation (saturating v_cvt_i32_f32; NaN -> 0, rejected below)
     xi += xi < 0 ? g.dom_w : 0;     // negative indices wrap once, as index_put_ does
     yi += yi < 0 ? g.dom_h : 0;
     const bool ok = (x == x) & (y == y) & ((uint32_t)xi < (uint32_t)g.dom_w) & ((uint32_t)yi < (uint32_t)g.dom_h);
-    const int tw1 = (1 << g.tw_log2) - 1, th1 = (1 << g.th_log2) - 1;
-    local = (uint32_t)(((yi & th1) << g.tw_log2) | (xi & tw1));
-    const int key = (yi >> g.th_log2) * g.tiles_x + (xi >> g.tw_log2);
-    return ok ? key : -1;
+    const uint32_t ux = ok ? (uint32_t)xi : 0u, uy = ok ? (uint32_t)yi : 0u;   // (< 2^16: the magic division is exact)
+    const uint32_t tx = div_magic(ux, g.mx), ty = div_magic(uy, g.my);
+    cell = (uy - ty * (uint32_t)g.th) * (uint32_t)g.pitch + (ux - tx * (uint32_t)g.tw);
+    return ok ? (int)(ty * (uint32_t)g.tiles_x + tx) : -1;
 }
 
 }  // namespace evk

@@ -17,9 +17,11 @@
 // Hot tiles (clustered data): every partition block adds its per-tile counts to global totals; the LAST block to
 // finish (ticket) builds the work-item plan (a tile with more than max(32768, 4n/T) events is split over several
 // workgroups, by sub-chunk range), exactly the plan k_tile_scan_totals builds for the three-pass path.
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 
-#include "evk_tiles.h"
+#include "evk_part.h"
 
 namespace evk {
 
@@ -87,18 +89,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t *tmp
     return tmp[32 + wave] + incl - mine;   // the caller puts a barrier before tmp is used again
 }
 
-// Nearest-pixel key (EVK_KEY_NEAREST of tile_key) that also returns the pixel inside the tile.
-__device__ __forceinline__ int key_local(float x, float y, const TileGrid &g, uint32_t &local) {
-    if (x != x || y != y) return -1;
-    int xi = (int)x, yi = (int)y;
-    if (xi < 0) xi += g.dom_w;
-    if (yi < 0) yi += g.dom_h;
-    if (xi < 0 || xi >= g.dom_w || yi < 0 || yi >= g.dom_h) return -1;
-    const int tw1 = (1 << g.tw_log2) - 1, th1 = (1 << g.th_log2) - 1;
-    local = (uint32_t)(((yi & th1) << g.tw_log2) | (xi & tw1));
-    return (yi >> g.th_log2) * g.tiles_x + (xi >> g.tw_log2);
-}
-
 struct Part2 {
     int S;          // events per sub-chunk (% 4 == 0, <= THREADS * EPT)
     int per_block;  // consecutive sub-chunks per partition block
@@ -108,11 +98,12 @@ struct Part2 {
 };
 
 template <int THREADS, int EPT, int BPC, typename C>
-__global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(const C c, int64_t n, TileGrid g, int ntiles, Part2 q,
+__global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q,
                                                             float t_first, float t_last, float bm1, int t_from_events,
                                                             uint2 *__restrict__ rec, float *__restrict__ pw,
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
-                                                            uint32_t cap, uint32_t *oob, uint32_t *host_report, uint32_t seq) {
+                                                            uint32_t cap, uint32_t part, uint32_t *oob, uint32_t *host_report,
+                                                            uint32_t seq) {
     constexpr int NQ = EPT / 4;
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -181,7 +172,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 uint32_t local = 0;
-                const int key = e < nv ? key_local(xv[k].v[e], yv[k].v[e], g, local) : -1;
+                const int key = e < nv ? nearest_key_cell(xv[k].v[e], yv[k].v[e], g, local) : -1;
                 kl[4 * k + e] = key >= 0 ? (((uint32_t)key << V2_LB) | local) : 0xFFFFFFFFu;
                 dropped += (key < 0 && e < nv) ? 1u : 0u;
             }
@@ -315,7 +306,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
         if (k < per && i < i1) {
             tot[k] = __hip_atomic_load(gidx + V2_TOTALS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gidx + V2_TOTALS + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            np += tot[k] > cap ? (tot[k] + cap - 1) / cap : 1u;
+            np += tot[k] > cap ? (tot[k] + part - 1) / part : 1u;
         }
     }
     // (The balanced plan of k_tile_scan_totals -- more, smaller items for non-uniform scenes -- was tried here and is
@@ -328,7 +319,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
     for (int k = 0; k < PER_MAX; ++k) {
         const int i = i0 + k;
         if (k < per && i < i1) {
-            const uint32_t parts = tot[k] > cap ? (tot[k] + cap - 1) / cap : 1u;
+            const uint32_t parts = tot[k] > cap ? (tot[k] + part - 1) / part : 1u;
             part_start[i] = prun;
             counters[i] = 0;
             for (uint32_t jj = 0; jj < parts; ++jj) item_tile[prun + jj] = (uint32_t)i;
@@ -356,10 +347,14 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
 #define V2_MAX_CHUNKS 7    // chunks of a listed segment (longer ones are streamed by the whole wave)
 #define V2_CHUNK_CAP (64 * V2_MAX_CHUNKS)  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
                                            // workgroups still fit a CU's 160 KB
-template <int WG, int U, bool SPLIT>
+// FIXED (EVK_VOXEL_DETERMINISTIC): the cells are int64 multiples of 2^-32 instead of float64 -- integer adds commute, so the
+// grid is bit-identical from run to run and for any order of the events.  |contribution| < 2^30 and finite, else it is
+// counted in index[4] and left out (the wrapper raises).
+#define V2_FIXED_ONE 4294967296.0
+template <int WG, int U, bool SPLIT, bool FIXED>
 __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
-                                                     TileGrid g, Part2 q, int B, int flags, float *__restrict__ vox,
+                                                     TileGridG g, Part2 q, int B, int flags, float *__restrict__ vox,
                                                      float *__restrict__ staging) {
     constexpr int NW = WG / 64;
     const int overwrite = flags & EVK_VOXEL_OVERWRITE;
@@ -381,19 +376,22 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     // range of the tile-ordered work items: the 128-byte lines two adjacent tiles share are then fetched into ONE L2
     // once instead of into two L2s
     uint32_t item = blockIdx.x;
-    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER)) {
+    // (not when tiles were cut: the pieces of a hot tile are neighbours in the item order, a contiguous range would hand most
+    // of a blob to two or three XCDs -- blob scene 68 -> 63 us in plain order, uniform events 29 -> 34 us)
+    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER) && nitems == (uint32_t)ntiles) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, q8 = nitems >> 3, r8 = nitems & 7u;
         item = k * q8 + (k < r8 ? k : r8) + j;
     }
-    const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
-    // LDS layout of the accumulators: rows of tw + 1 cells (8 bytes), i.e. an ODD pitch.  With a pitch of 32 cells = 64
+    const int tw = g.tw, th = g.th, tpix = tw * th;
+    // LDS layout of the accumulators: rows of tw | 1 cells (8 bytes), i.e. an ODD pitch.  With a pitch of 32 cells = 64
     // dwords every row of one column lands on the same pair of banks, and the events of a real scene sit on edges: a
     // wave's events share a column and differ in the row (moving-edge scene: 66 us against 36 us on uniform events).
-    const int tpitch = tw + 1, ppix = tpitch * th;   // cells per accumulator plane
+    // The records carry row * pitch + column (evk_part.h): the cell index itself.
+    const int tpitch = g.pitch, ppix = tpitch * th;   // cells per accumulator plane
     const int tile = (int)item_tile[item];
     const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     const uint32_t part_id = item - first_item;
-    const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+    const int tx0 = (tile % g.tiles_x) * tw, ty0 = (tile / g.tiles_x) * th;
     // (64-bit fixed-point cells as in k_iwe_tiled -- ds_add_u64 is the faster LDS atomic -- with the scale from a max |p|
     // the partition kernel collects: no faster here (33.9 vs 34.6 us at 10 M events, 152.6 vs 148 us at 50 M) and the
     // extra bookkeeping in the placement pushed the partition kernel from 48 to 91 us.  Float64 cells stay.)
@@ -401,9 +399,36 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
     const uint32_t *col = table + tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, grp = lane >> 2;
+    auto add = [&](acc_t *a, float v) {
+        if constexpr (FIXED) {
+            const double sc = (double)v * V2_FIXED_ONE;
+            if (!(fabs(sc) < 4.0e18)) {   // NaN, infinity or beyond 2^30: not representable
+                __hip_atomic_fetch_add(index + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a), (unsigned long long)__double2ll_rn(sc), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            lds_add(a, v);
+        }
+    };
+    auto bins_general = [&](acc_t *base, int local, float tn, float p) {   // any t_norm: voxel_bins_lds with `add`
+        if (tn != tn) {  // dt == 0 (Q9): NaN in every bin of the pixel
+            for (int b = 0; b < B; ++b) add(base + b * ppix + local, tn * p);
+            return;
+        }
+        const float fl = floorf(tn);
+        const int b0 = (int)fmaxf(fminf(fl, (float)(B + 1)), -2.0f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b0 + k;
+            if (b < 0 || b >= B) continue;
+            const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - (float)b));
+            if (val != 0.0f) add(base + b * ppix + local, val);
+        }
+    };
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
-        const int lraw = (int)(hi_w & V2_LOCAL_MASK);
-        const int local = lraw + (lraw >> g.tw_log2);   // row * (tw + 1) + column
+        const int local = (int)(hi_w & V2_LOCAL_MASK);   // row * pitch + column
         float p = __uint_as_float(hi_w & V2_P_MASK);
         if (hi_w & V2_WIDE) {   // rare: the exact float32 polarity from the side array.  The wait stays INSIDE the branch
             p = pw[ridx];       // (builtin: the compiler's scoreboard sees it) -- at the join it would be a vmcnt(0) on
@@ -429,17 +454,17 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             const int b0 = (int)tn;
             const float v0 = w * (1.0f - (tn - (float)b0)), v1 = w * (1.0f - fabsf(tn - (float)(b0 + 1)));
             a += b0 * ppix;
-            lds_add(a, v0);
-            if (b0 + 1 < B) lds_add(a + ppix, v1);
+            add(a, v0);
+            if (b0 + 1 < B) add(a + ppix, v1);
         } else if (!split) {
-            voxel_bins_lds(acc, ppix, local, B, tn, p);
+            bins_general(acc, local, tn, p);
         } else if (tn != tn) {
-            voxel_bins_lds(acc, ppix, local, B, tn, 1.0f);
-            voxel_bins_lds(acc + B * ppix, ppix, local, B, tn, 1.0f);
+            bins_general(acc, local, tn, 1.0f);
+            bins_general(acc + B * ppix, local, tn, 1.0f);
         } else if (p > 0.0f) {
-            voxel_bins_lds(acc, ppix, local, B, tn, 1.0f);
+            bins_general(acc, local, tn, 1.0f);
         } else if (p <= 0.0f) {
-            voxel_bins_lds(acc + B * ppix, ppix, local, B, tn, 1.0f);
+            bins_general(acc + B * ppix, local, tn, 1.0f);
         }
     };
     auto pair = [&](const uint4 &v, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
@@ -555,18 +580,36 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
             const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
             const uint32_t b2 = rb + st, e3 = b2 + cn;
-            for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 128u) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(rec + p2);
-                pair(v, p2, b2, e3);
+            // four loads per lane in flight (the parts of a hot tile are all long segments: with one dependent load at a
+            // time a part was a chain of ~2 us round trips)
+            for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 512u) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pu = p2 + 128u * u;
+                    v[u] = *reinterpret_cast<const uint4 *>(rec + (pu < e3 ? pu : p2));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t pu = p2 + 128u * u;
+                    if (pu < e3) pair(v[u], pu, b2, e3);
+                }
             }
         }
     }
     __syncthreads();
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    auto split_cell = [&](int c, int &b, int &row, int &col) {   // dense cell c = (plane, row, column) of the tile
+        b = (int)div_magic((uint32_t)c, g.mp);
+        const int l = c - b * tpix;
+        row = (int)div_magic((uint32_t)l, g.mx);
+        col = l - row * tw;
+    };
     auto flush = [&](auto value_of) {
         for (int c = threadIdx.x; c < NB * tpix; c += WG) {
-            const int b = c / tpix, l = c - b * tpix;
-            const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
+            int b, row, col;
+            split_cell(c, b, row, col);
+            const int X = tx0 + col, Y = ty0 + row;
             if (X < g.dom_w && Y < g.dom_h) {
                 float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
                 const float v = value_of(c);
@@ -574,9 +617,12 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             }
         }
     };
-    auto lds_cell = [&](int c) -> float {   // dense cell c = (plane, pixel) -> padded LDS layout
-        const int b = c / tpix, l = c - b * tpix;
-        return (float)acc[b * ppix + l + (l >> g.tw_log2)];
+    auto lds_cell = [&](int c) -> float {   // dense cell c -> padded LDS layout
+        int b, row, col;
+        split_cell(c, b, row, col);
+        const acc_t a = acc[b * ppix + row * tpitch + col];
+        if constexpr (FIXED) return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V2_FIXED_ONE));
+        return (float)a;
     };
     if (nparts == 1) {
         flush(lds_cell);
@@ -611,47 +657,37 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
 }
 
 // ---- host-side geometry -----------------------------------------------------------------------------------------
+// Partition geometry = threads x events per thread, ONE workgroup per CU.  The library ships the two the default dispatch
+// reaches: 1024 x 8 (sub-chunks of 8 K events: 105 registers, 68 KB of LDS -- room for the workgroups of another kernel,
+// e.g. an overlapped RCCL collective) and 1024 x 12 (12 K events: longer segments for the tile kernel, taken when there
+// are more than 680 tiles and the call need not share its CUs).  Measured and rejected (compiled
+// only with -DEVK_EXPERIMENTS, tools/exp_build.sh, and selected with EVK_V2_PART): 512x32 / 1024x16 (16 K events: the
+// whole register file, 67 / 74 us), 1024x8x2 / 512x16x2 / 768x12x2 (two workgroups per CU: spills, 75-150 us).
 struct V2Config {
-    int threads, ept, blocks_per_cu, wg, u;
+    int threads, ept, blocks_per_cu;
 };
+#ifdef EVK_EXPERIMENTS
+#define V2_GEOMETRIES(X) X(1024, 8, 1) X(1024, 12, 1) X(512, 32, 1) X(1024, 16, 1) X(1024, 8, 2) X(512, 16, 2) X(768, 12, 2)
+#else
+#define V2_GEOMETRIES(X) X(1024, 8, 1) X(1024, 12, 1)
+#endif
 static V2Config v2_config_env() {
-        V2Config c{1024, 12, 1, 512, 2};
-        // partition geometries (EVK_V2_PART = threads x events per thread), one workgroup per CU.  Default "1024x12s":
-        // sub-chunks of 12 K events, 53 us at 10 M events and the longer segments make the tile kernel 11 % faster than
-        // with "1024x8s" (8 K events, 51 us, 105 registers, no spills) -- which is what a multi-rank job gets
-        // (EVK_VOXEL2_SHARE_CU) because it leaves LDS AND registers for another kernel's workgroups
-        // (profiles/r02_cu_contention_probe.txt).  Measured alternatives:
-        // "512x32" / "1024x16" (16 K events: longer segments for the tile kernel, but 67 / 74 us and the whole CU taken),
-        // "1024x8" / "512x16" / "768x12" (two workgroups per CU: spills, 75-150 us)
-        const char *geo = getenv("EVK_V2_PART");
-        if (geo && !strcmp(geo, "512x32")) c.threads = 512, c.ept = 32, c.blocks_per_cu = 1;
-        else if (geo && !strcmp(geo, "1024x8")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 2;
-        else if (geo && !strcmp(geo, "512x16")) c.threads = 512, c.ept = 16, c.blocks_per_cu = 2;
-        else if (geo && !strcmp(geo, "768x12")) c.threads = 768, c.ept = 12, c.blocks_per_cu = 2;
-        else if (geo && !strcmp(geo, "1024x16")) c.threads = 1024, c.ept = 16, c.blocks_per_cu = 1;
-        else if (geo && !strcmp(geo, "1024x8s")) c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
-        else if (geo && !strcmp(geo, "1024x12s")) c.threads = 1024, c.ept = 12, c.blocks_per_cu = 1;
-        else c.threads = 1024, c.ept = 12, c.blocks_per_cu = 1;
-        if (const char *s = getenv("EVK_V2_WG")) c.wg = atoi(s) == 512 ? 512 : (atoi(s) == 1024 ? 1024 : 256);
-        if (const char *s = getenv("EVK_V2_U")) c.u = atoi(s) == 2 ? 2 : (atoi(s) == 8 ? 8 : 4);
-        return c;
+    V2Config c{0, 0, 0};
+    const char *geo = getenv("EVK_V2_PART");
+    int t = 0, e = 0, b = 1;
+    if (geo && sscanf(geo, "%dx%dx%d", &t, &e, &b) >= 2) {
+#define X(T, E, BPC) if (t == T && e == E && b == BPC) c = V2Config{T, E, BPC};
+        V2_GEOMETRIES(X)
+#undef X
+    }
+    return c;
 }
-// Geometry of one call.  Without EVK_V2_PART: sub-chunks of 8 K events ("1024x8s": 51 us at 10 M events, 105 registers:
-// LDS and registers left for the workgroups of another kernel, e.g. an overlapped RCCL collective) unless the tile kernel
-// would then pull segments shorter than ~12 records -- more than 680 tiles, e.g. 1280x720 -- and the call does not have
-// to share its CUs (`share`, EVK_VOXEL2_SHARE_CU: multi-rank jobs): then 12 K events ("1024x12s").  Measured, 10 M events
-// 640x480 (600 tiles): 0.092 ms with 8 K vs 0.095 with 12 K; 50 M events 1280x720 (920 tiles): 0.464 vs 0.443 ms.
 static const V2Config &v2_config(bool share = false, int ntiles = 0) {
-    static const bool forced = getenv("EVK_V2_PART") != nullptr;
-    static const V2Config base = v2_config_env();
-    static const V2Config small = [] {
-        V2Config c = base;
-        c.threads = 1024, c.ept = 8, c.blocks_per_cu = 1;
-        return c;
-    }();
+    static const V2Config forced = v2_config_env();
+    static const V2Config small{1024, 8, 1}, large{1024, 12, 1};
     if (share) return small;
-    if (forced) return base;
-    return ntiles > 680 ? base : small;
+    if (forced.threads) return forced;
+    return ntiles > 680 ? large : small;
 }
 #define V2_MIN_SUBCHUNK 8192
 
@@ -676,10 +712,41 @@ static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
 }
 static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 
+// Hot tiles.  The tile kernel runs one workgroup per work item and lasts as long as its busiest CU, so a tile holding more
+// than V2_SPLIT_AT x the mean tile population is cut into pieces of about V2_PART x the mean (ranges of sub-chunks; the last
+// piece to arrive sums the partial tiles).  Two numbers, because cutting costs (a staging store, a ticket, the combine --
+// measured on the moving-edge scene, where most tiles hold 1.5-3 x the mean: cutting everything above 1.5 x made the kernel
+// 30 % slower, 41 -> 53 us) but a blob that holds half of the events in twenty tiles must become many small pieces (cut at
+// 4 x into pieces of < 4 x: 111 us; into pieces of ~1 x: see DESIGN.md).  Uniform events are never cut.
+// EVK_V2_SPLIT="at,part" overrides (measurements).
+struct V2Split {
+    double at, part;
+};
+static const V2Split &v2_split() {
+    static const V2Split f = [] {
+        V2Split v{3.0, 1.5};
+        const char *s = getenv("EVK_V2_SPLIT");
+        double a = 0, p = 0;
+        if (s && sscanf(s, "%lf,%lf", &a, &p) == 2 && a >= 1.0 && p >= 0.25 && p <= a) v = V2Split{a, p};
+        return v;
+    }();
+    return f;
+}
+static int64_t v2_mean(int64_t n, int ntiles) { return n / (ntiles > 0 ? ntiles : 1); }
+static int64_t v2_cap(int64_t n, int ntiles) {   // a tile with more events than this is cut ...
+    const int64_t c = (int64_t)(v2_split().at * (double)v2_mean(n, ntiles));
+    return c > 16384 ? c : 16384;
+}
+static int64_t v2_part(int64_t n, int ntiles) {   // ... into pieces of at most this many
+    const int64_t c = (int64_t)(v2_split().part * (double)v2_mean(n, ntiles));
+    return c > 8192 ? c : 8192;
+}
+static int v2_max_items(int64_t n, int ntiles) { return ntiles + (int)(n / v2_part(n, ntiles)) + 1; }
+
 struct V2Layout {
     int64_t table, rec, pw, staging, total;
 };
-static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw_log2, int th_log2, bool share = false) {
+static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw, int th, bool share = false) {
     const Part2 q = v2_geometry(n, ntiles, share);
     const int64_t slots = (int64_t)q.nsc * q.S;
     V2Layout L;
@@ -687,7 +754,7 @@ static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw_log2, int th
     L.rec = al256((int64_t)q.nsc * q.nt_pad * 4);
     L.pw = L.rec + al256(slots * 8);
     L.staging = L.pw + al256(slots * 4);
-    L.total = L.staging + al256((int64_t)bucket_max_items(n, ntiles) * ((int64_t)planes << (tw_log2 + th_log2)) * 4);
+    L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * ((int64_t)planes * tw * th) * 4);
     return L;
 }
 
@@ -697,60 +764,81 @@ using namespace evk;
 
 extern "C" int64_t evk_voxel2_index_len(int ntiles, int64_t n) {
     if (ntiles <= 0 || ntiles > V2_MAX_TILES || n < 0) return 0;
-    return (int64_t)V2_ITEM(ntiles) + bucket_max_items(n, ntiles);
+    return (int64_t)V2_ITEM(ntiles) + v2_max_items(n, ntiles);
 }
 
-extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
-    if (ntiles <= 0 || n < 0 || planes <= 0) return 0;
-    const int64_t a = v2_layout(ntiles, n, planes, tw_log2, th_log2, false).total;
-    const int64_t b = v2_layout(ntiles, n, planes, tw_log2, th_log2, true).total;
+extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tile_w, int tile_h) {
+    if (ntiles <= 0 || n < 0 || planes <= 0 || tile_w <= 0 || tile_h <= 0) return 0;
+    const int64_t a = v2_layout(ntiles, n, planes, tile_w, tile_h, false).total;
+    const int64_t b = v2_layout(ntiles, n, planes, tile_w, tile_h, true).total;
     return a > b ? a : b;
+}
+
+// tiles of tile_w x tile_h pixels covering an (h, wd) image, or 0 when the one-pass path cannot take that tiling
+extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
+    TileGridG g;
+    if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK) return 0;
+    return g.tiles_x * g.tiles_y;
 }
 
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
 extern "C" int evk_voxel2_max_tiles(void) {
-    const V2Config &c = v2_config();
-    const int64_t budget = (int64_t)160 * 1024 / c.blocks_per_cu - (int64_t)c.threads * c.ept * 8 - 1024;
+    const int64_t budget = (int64_t)160 * 1024 - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
     const int64_t t = budget / 4;
     return (int)(t < V2_MAX_TILES ? (t > 0 ? t : 0) : V2_MAX_TILES);
 }
 
 template <int THREADS, int EPT, int BPC, typename C>
-static void launch_part(const C &c, int64_t n, const TileGrid &g, int ntiles, const Part2 &q, float t_first, float t_last,
+static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part2 &q, float t_first, float t_last,
                         float bm1, int t_from_events, uint2 *rec, float *pw, uint32_t *table, uint32_t *index,
                         uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
     const size_t lds = (size_t)THREADS * EPT * 8 + 16 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
-    static uint64_t attr_set = 0;
+    static std::once_flag once[64];   // per device and instantiation: the attribute belongs to the loaded code object
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!(attr_set >> (dev & 63) & 1)) {
-        // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
+    std::call_once(once[dev & 63], [] {   // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
         (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, BPC, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 256);
-        attr_set |= (uint64_t)1 << (dev & 63);
-    }
+    });
     k_part_sorted<THREADS, EPT, BPC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
-                                                                    rec, pw, table, index, (uint32_t)bucket_cap(n, ntiles), oob,
+                                                                    rec, pw, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
                                                                     host_report, seq);
 }
 
+// Tile kernel: 512 threads, 2 chunk loads per lane in flight (256 / 1024 threads, 4 / 8 loads: 48-69 us against 34,
+// DESIGN.md section 3; EVK_EXPERIMENTS builds keep them, EVK_V2_WG / EVK_V2_U).  `lds_dyn` >= the accumulators: asking for
+// more LDS than they need is how the launch fixes the number of workgroups a CU holds (below).
+template <int WG, int U, bool SPLIT, bool FIXED>
+static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const uint2 *rec, const float *pw, const uint32_t *table,
+                         uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox, float *staging) {
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [] {
+        (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - (int)sizeof(uint2) * (WG / 64) * V2_CHUNK_CAP - 256);
+    });
+    k_voxel_tiles2<WG, U, SPLIT, FIXED><<<items, WG, lds_dyn, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);
+}
+
 template <typename C>
-static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first, float t_last, int B,
+static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, float t_first, float t_last, int B,
                   int flags, float *vox, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                   uint32_t *host_report, uint32_t seq, void *stream) {
-    TileGrid g;
+    TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
-                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU;
-    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
-        n > (int64_t)4000000000LL || (flags & ~known) || tw_log2 + th_log2 > V2_LB)
+                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC;
+    if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
+        n > (int64_t)4000000000LL || (flags & ~known))
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
-    const size_t lds_acc = (size_t)planes * sizeof(acc_t) * (((size_t)1 << tw_log2) + 1) << th_log2;  // odd row pitch
-    if (lds_acc > 140 * 1024) return EVK_EINVAL;
+    const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
+    const size_t lds_static = sizeof(uint2) * 8 * V2_CHUNK_CAP + 64;        // the tile kernel's chunk lists (512 threads)
+    if (lds_acc + lds_static > 150 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
-    const V2Layout L = v2_layout(ntiles, n, planes, tw_log2, th_log2, share);
+    const V2Layout L = v2_layout(ntiles, n, planes, tile_w, tile_h, share);
     if (scratch_bytes < L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
     const Part2 q = v2_geometry(n, ntiles, share);
@@ -764,63 +852,53 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
-        if (cfg.ept == 32) launch_part<512, 32, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else if (cfg.threads == 1024 && cfg.ept == 12) launch_part<1024, 12, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else if (cfg.threads == 1024 && cfg.ept == 8 && cfg.blocks_per_cu == 1) launch_part<1024, 8, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else if (cfg.threads == 1024 && cfg.ept == 8) launch_part<1024, 8, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else if (cfg.threads == 512) launch_part<512, 16, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else if (cfg.threads == 768) launch_part<768, 12, 2>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
-        else launch_part<1024, 16, 1>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+#define X(T, E, BPC)                                                                                                  \
+    if (cfg.threads == T && cfg.ept == E && cfg.blocks_per_cu == BPC)                                                 \
+        launch_part<T, E, BPC>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+        V2_GEOMETRIES(X)
+#undef X
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
-        const int items = bucket_max_items(n, ntiles);
+        const int items = v2_max_items(n, ntiles);
         const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
-#define V2_LAUNCH(WG, U)                                                                                           \
-    do {                                                                                                           \
-        if (lds_acc > 64 * 1024) {                                                                                 \
-            (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);  \
-            (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); \
-        }                                                                                                          \
-        if (kf & EVK_VOXEL_SPLIT_POLARITY)                                                                         \
-            k_voxel_tiles2<WG, U, true><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);   \
-        else                                                                                                       \
-            k_voxel_tiles2<WG, U, false><<<items, WG, lds_acc, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);  \
+        // (512 tiles on 768 workgroup slots: the dispatcher spreads them evenly by itself -- asking for more LDS than the
+        // accumulators need, so that a CU holds exactly its share, changed nothing for uniform events and cost the blob scene
+        // 81 against 68 us, its many pieces then waiting for slots)
+        const size_t lds_dyn = lds_acc;
+        const bool sp = flags & EVK_VOXEL_SPLIT_POLARITY, fx = flags & EVK_VOXEL_DETERMINISTIC;
+#define V2_TILES(WG, U)                                                                                                   \
+    do {                                                                                                                  \
+        if (sp && fx) launch_tiles<WG, U, true, true>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
+        else if (sp) launch_tiles<WG, U, true, false>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
+        else if (fx) launch_tiles<WG, U, false, true>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
+        else launch_tiles<WG, U, false, false>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);           \
     } while (0)
-#define V2_LAUNCH_U(WG)                    \
-    do {                                   \
-        if (cfg.u == 2) V2_LAUNCH(WG, 2);  \
-        else if (cfg.u == 8) V2_LAUNCH(WG, 8); \
-        else V2_LAUNCH(WG, 4);             \
-    } while (0)
-        if (cfg.wg == 1024) V2_LAUNCH_U(1024);
-        else if (cfg.wg == 256) V2_LAUNCH_U(256);
-        else V2_LAUNCH_U(512);
-#undef V2_LAUNCH_U
-#undef V2_LAUNCH
+        V2_TILES(512, 2);
+#undef V2_TILES
     }
     return launch_status();
 }
 
 extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
-                              int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                              int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                               uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                               uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
     const ColsF32 c{x, y, t, p};
-    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+    return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }
 
 extern "C" int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
-                                     double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2,
-                                     int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                                     double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tile_w,
+                                     int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                                      uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                                      uint32_t *host_report, uint32_t seq, void *stream) {
     ColsNative c;
     const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
     if (rc != EVK_OK) return rc;
     if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
-    return voxel2(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+    return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }

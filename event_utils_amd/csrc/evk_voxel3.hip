@@ -23,10 +23,13 @@
 // also mean a 64 KB LDS buffer sorts 16 K events instead of 8 K (and the (key, t, p) triple of an event is compressed
 // to its record word BEFORE the next sub-chunk's x, y loads are issued, so 16 events per thread fit the register file):
 // the tile kernel pulls half as many segments of the same ~110 bytes.
+#ifdef EVK_EXPERIMENTS   // measured, not adopted: tools/exp_build.sh builds it, EVK_VOXEL_PATH=v3 runs it
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
 #include "evk_part.h"
+#include "evk_experiments.h"
 
 namespace evk {
 
@@ -136,7 +139,7 @@ struct Part3 {
 };
 
 template <int THREADS, int EPT, int SCHED, typename C>
-__global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, TileGrid g, int ntiles, Part3 q, float t_first,
+__global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, TileGridG g, int ntiles, Part3 q, float t_first,
                                                                  float t_last, float bm1, int t_from_events,
                                                                  uint32_t *__restrict__ rec, uint2 *__restrict__ wide,
                                                                  uint32_t *__restrict__ table, uint32_t *__restrict__ bases,
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 uint32_t local = 0;
-                const int key = nearest_key_local(xv[G * k + e], yv[G * k + e], g, local);   // (of a stale value beyond the stream)
+                const int key = nearest_key_cell(xv[G * k + e], yv[G * k + e], g, local);   // (of a stale value beyond the stream)
                 kl[G * k + e] = ((key >= 0) & (e < nv)) ? (((uint32_t)key << V3_LB) | local) : 0xFFFFFFFFu;
                 dropped += ((key < 0) & (e < nv)) ? 1u : 0u;
                 asm volatile("" : "+v"(dropped));   // counted HERE: sunk to the end of the loop body it kept a second copy of every key alive
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
 template <int WG, int U, bool SPLIT, bool FIXED>
 __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const uint32_t *__restrict__ rec, const uint2 *__restrict__ wide,
                                                      const uint32_t *__restrict__ table, const uint32_t *__restrict__ bases,
-                                                     uint32_t *__restrict__ index, TileGrid g, Part3 q, int B, int flags,
+                                                     uint32_t *__restrict__ index, TileGridG g, Part3 q, int B, int flags,
                                                      float *__restrict__ vox, float *__restrict__ staging) {
     constexpr int NW = WG / 64;
     const int overwrite = flags & EVK_VOXEL_OVERWRITE;
@@ -460,14 +463,14 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, q8 = nitems >> 3, r8 = nitems & 7u;
         item = k * q8 + (k < r8 ? k : r8) + j;
     }
-    const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tpix = tw * th;
+    const int tw = g.tw, th = g.th, tpix = tw * th;
     // accumulator rows of tw + 1 cells: an ODD pitch (the events of a real scene sit on edges -- same column, different
     // rows -- and with 32 cells = 64 dwords per row every row of a column would share one pair of banks)
-    const int tpitch = tw + 1, ppix = tpitch * th;
+    const int tpitch = g.pitch, ppix = tpitch * th;
     const int tile = (int)item_tile[item];
     const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     const uint32_t part_id = item - first_item;
-    const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
+    const int tx0 = (tile % g.tiles_x) * tw, ty0 = (tile / g.tiles_x) * th;
     for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;   // (+0.0 and int64 0 are the same bits)
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
     const uint32_t *col = table + tile;
@@ -504,8 +507,7 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
     };
     auto one = [&](uint32_t word, uint32_t bbits, uint32_t slot) {
         const uint32_t code = (word >> V3_CODE_SHIFT) & 3u;
-        const int lraw = (int)(word & V3_LOCAL_MASK);
-        const int local = lraw + (lraw >> g.tw_log2);   // row * (tw + 1) + column
+        const int local = (int)(word & V3_LOCAL_MASK);   // row * pitch + column
         float tn, p;
         if (code == 3u) {
             if ((word >> V3_DELTA_SHIFT) == 0xFFFFFu) return;   // padding
@@ -572,9 +574,8 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
             // added like any other (x + 0 = x; the reference's index_put_ adds it too); at t_norm == B - 1 the upper bin does
             // not exist and its weight is exactly 0: it is added to the lower bin's cell instead of being branched around.
             const uint32_t code = (wd[i] >> V3_CODE_SHIFT) & 3u;
-            const int lraw = (int)(wd[i] & V3_LOCAL_MASK);
             const int b0 = (int)tn[i];
-            acc_t *a = acc + (lraw + (lraw >> g.tw_log2)) + b0 * ppix;   // row * (tw + 1) + column, plane b0
+            acc_t *a = acc + (int)(wd[i] & V3_LOCAL_MASK) + b0 * ppix;   // row * pitch + column, plane b0
             float wgt = __uint_as_float(code == 2u ? 0u : (0x3F800000u | (code << 31)));
             if constexpr (split) {
                 a += code == 0u ? 0 : B * ppix;   // +1 -> the grid of the positive events; -1, 0 -> the other one
@@ -690,10 +691,17 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
     }
     __syncthreads();
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    auto split_cell = [&](int c, int &b, int &row, int &col) {   // dense cell c = (plane, row, column) of the tile
+        b = (int)div_magic((uint32_t)c, g.mp);
+        const int l = c - b * tpix;
+        row = (int)div_magic((uint32_t)l, g.mx);
+        col = l - row * tw;
+    };
     auto flush = [&](auto value_of) {
         for (int c = threadIdx.x; c < NB * tpix; c += WG) {
-            const int b = c / tpix, l = c - b * tpix;
-            const int X = tx0 + (l & (tw - 1)), Y = ty0 + (l >> g.tw_log2);
+            int b, row, col;
+            split_cell(c, b, row, col);
+            const int X = tx0 + col, Y = ty0 + row;
             if (X < g.dom_w && Y < g.dom_h) {
                 float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
                 const float v = value_of(c);
@@ -701,9 +709,10 @@ __global__ void __launch_bounds__(WG, V3_TILES_MIN_WAVES) k_voxel_tiles3(const u
             }
         }
     };
-    auto lds_cell = [&](int c) -> float {   // dense cell c = (plane, pixel) -> padded LDS layout
-        const int b = c / tpix, l = c - b * tpix;
-        const acc_t a = acc[b * ppix + l + (l >> g.tw_log2)];
+    auto lds_cell = [&](int c) -> float {   // dense cell c -> padded LDS layout
+        int b, row, col;
+        split_cell(c, b, row, col);
+        const acc_t a = acc[b * ppix + row * tpitch + col];
         if constexpr (FIXED) return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V3_FIXED_ONE));
         return (float)a;
     };
@@ -796,7 +805,7 @@ static inline int64_t v3_al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 struct V3Layout {
     int64_t table, bases, rec, wide, staging, total;
 };
-static V3Layout v3_layout(int ntiles, int64_t n, int planes, int tw_log2, int th_log2, bool share) {
+static V3Layout v3_layout(int ntiles, int64_t n, int planes, int tw, int th, bool share) {
     const Part3 q = v3_geometry(n, ntiles, share);
     const int64_t slots = (int64_t)q.nsc * q.spad;
     V3Layout L;
@@ -805,7 +814,7 @@ static V3Layout v3_layout(int ntiles, int64_t n, int planes, int tw_log2, int th
     L.rec = L.bases + v3_al256((int64_t)q.nsc * 4);
     L.wide = L.rec + v3_al256(slots * 4);
     L.staging = L.wide + v3_al256(slots * 8);
-    L.total = L.staging + v3_al256((int64_t)bucket_max_items(n, ntiles) * ((int64_t)planes << (tw_log2 + th_log2)) * 4);
+    L.total = L.staging + v3_al256((int64_t)bucket_max_items(n, ntiles) * ((int64_t)planes * tw * th) * 4);
     return L;
 }
 
@@ -822,10 +831,10 @@ extern "C" int64_t evk_voxel3_index_len(int ntiles, int64_t n) {
     return (int64_t)VP_ITEM(ntiles) + bucket_max_items(n, ntiles);
 }
 
-extern "C" int64_t evk_voxel3_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2) {
-    if (ntiles <= 0 || n < 0 || planes <= 0) return 0;
-    const int64_t a = v3_layout(ntiles, n, planes, tw_log2, th_log2, false).total;
-    const int64_t b = v3_layout(ntiles, n, planes, tw_log2, th_log2, true).total;
+extern "C" int64_t evk_voxel3_scratch_bytes(int ntiles, int64_t n, int planes, int tile_w, int tile_h) {
+    if (ntiles <= 0 || n < 0 || planes <= 0 || tile_w <= 0 || tile_h <= 0) return 0;
+    const int64_t a = v3_layout(ntiles, n, planes, tile_w, tile_h, false).total;
+    const int64_t b = v3_layout(ntiles, n, planes, tile_w, tile_h, true).total;
     return a > b ? a : b;
 }
 
@@ -837,7 +846,7 @@ extern "C" int evk_voxel3_max_tiles(void) {
 }
 
 template <int THREADS, int EPT, int SCHED, typename C>
-static void launch_part3(const C &c, int64_t n, const TileGrid &g, int ntiles, const Part3 &q, float t_first, float t_last,
+static void launch_part3(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part3 &q, float t_first, float t_last,
                          float bm1, int tfe, uint32_t *rec, uint2 *wide, uint32_t *table, uint32_t *bases, uint32_t *index,
                          uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
     static std::once_flag once[64];   // per device: the attribute is a property of the loaded code object
@@ -853,7 +862,7 @@ static void launch_part3(const C &c, int64_t n, const TileGrid &g, int ntiles, c
 
 template <bool SPLIT, bool FIXED>
 static void launch_tiles3(int items, size_t lds_acc, hipStream_t s, const uint32_t *rec, const uint2 *wide, const uint32_t *table,
-                          const uint32_t *bases, uint32_t *index, const TileGrid &g, const Part3 &q, int B, int kf, float *vox,
+                          const uint32_t *bases, uint32_t *index, const TileGridG &g, const Part3 &q, int B, int kf, float *vox,
                           float *staging) {
     if (lds_acc > 32 * 1024) {
         static std::once_flag once[64];
@@ -868,24 +877,23 @@ static void launch_tiles3(int items, size_t lds_acc, hipStream_t s, const uint32
 }
 
 template <typename C>
-static int voxel3(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first, float t_last, int B,
+static int voxel3(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, float t_first, float t_last, int B,
                   int flags, float *vox, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                   uint32_t *host_report, uint32_t seq, void *stream) {
-    TileGrid g;
+    TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC;
-    if (make_grid(g, h, wd, tw_log2, th_log2) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 || (flags & ~known) ||
-        tw_log2 + th_log2 > V3_LB)
+    if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 || (flags & ~known))
         return EVK_EINVAL;
     const int ntiles = g.tiles_x * g.tiles_y;
     if (ntiles > evk_voxel3_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
-    const size_t lds_acc = (size_t)planes * sizeof(acc_t) * (((size_t)1 << tw_log2) + 1) << th_log2;  // odd row pitch
+    const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
     if (lds_acc > 96 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const Part3 q = v3_geometry(n, ntiles, share);
     if ((int64_t)q.nsc * q.spad >= ((int64_t)1 << 32) - 64) return EVK_EINVAL;   // quad indices are 30 bits
-    const V3Layout L = v3_layout(ntiles, n, planes, tw_log2, th_log2, share);
+    const V3Layout L = v3_layout(ntiles, n, planes, tile_w, tile_h, share);
     if (scratch_bytes < L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
     char *sb = (char *)scratch;
@@ -916,19 +924,19 @@ static int voxel3(const C &c, int64_t n, int h, int wd, int tw_log2, int th_log2
 }
 
 extern "C" int evk_voxel3_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
-                              int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                              int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                               uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                               uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
     const SrcF32 c{x, y, t, p};
-    return voxel3(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+    return voxel3(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }
 
 extern "C" int evk_voxel3_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,
-                                     double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2,
-                                     int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                                     double t_offset, const void *p, int p_kind, int64_t n, int h, int wd, int tile_w,
+                                     int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                                      uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                                      uint32_t *host_report, uint32_t seq, void *stream) {
     ColsNative v;
@@ -937,10 +945,11 @@ extern "C" int evk_voxel3_native_f32(const int16_t *x, const int16_t *y, int xy_
     if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
     if (t_kind == EVK_T_F64) {
         const SrcNative<true> c{v.x, v.y, v.t, v.p, v.t_offset, v.xy_stride, v.p_kind};
-        return voxel3(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob,
+        return voxel3(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob,
                       host_report, seq, stream);
     }
     const SrcNative<false> c{v.x, v.y, v.t, v.p, v.t_offset, v.xy_stride, v.p_kind};
-    return voxel3(c, n, h, wd, tw_log2, th_log2, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+    return voxel3(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }
+#endif  // EVK_EXPERIMENTS

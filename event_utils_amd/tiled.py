@@ -170,9 +170,9 @@ def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
 
 
 def voxel_path():
-    """'v3' = one-pass partition with 4-byte records (evk_voxel3.hip, default); 'v2' = the round-2 one-pass partition
-    with 8-byte records (evk_voxel2.hip); 'v1' = three-pass counting sort (evk_tiled.hip)."""
-    return os.environ.get("EVK_VOXEL_PATH", "v3")
+    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip); 'v3' = the
+    4-byte-record variant of the one-pass path (evk_voxel3.hip), present in experiments builds only (tools/exp_build.sh)."""
+    return os.environ.get("EVK_VOXEL_PATH", "v2")
 
 
 def voxel_deterministic():
@@ -181,18 +181,49 @@ def voxel_deterministic():
     return os.environ.get("EVK_VOXEL_DETERMINISTIC", "0") == "1"
 
 
+_NUM_CU = 256
+_TILE_LIST_BYTES = 8 * 448 * 8 + 64      # the tile kernel's chunk lists (static LDS, 512 threads)
+_shape_cache = {}
+
+
 def voxel2_shape(H, W, planes):
-    """Tile shape for the one-pass voxel paths (v2 / v3), or None when they do not apply (more tiles than the partition
-    kernel's LDS holds, accumulators beyond 64 KB)."""
+    """Tile size (width, height in PIXELS) for the one-pass voxel path, or None when it does not apply.
+    The tile kernel runs one workgroup per tile and a launch lasts as long as its busiest CU, so the tiling is chosen to
+    minimise (tiles per CU, rounded up) x (pixels per tile): 640x480 -> 512 tiles of 40x15 (2 per CU, against 600 tiles
+    of 32x16 = 3 on 88 CUs and 2 on the rest: -17 % measured), 1280x720 -> 1024 tiles of 40x23.  Constraints: the
+    accumulator cell index (row * (width | 1) + column) has 10 bits; B planes of float64 cells plus the chunk lists must
+    fit the LDS; at most evk_voxel2_max_tiles() tiles.  Small penalties prefer fewer tiles (longer record segments),
+    all tiles resident at once (<= 3 workgroups per CU) and wide tiles (rows are contiguous in the grid)."""
+    key = (H, W, planes, voxel_path(), os.environ.get("EVK_VOXEL2_TILE"))
+    if key in _shape_cache:
+        return _shape_cache[key]
     L = _lib.lib()
-    ver = voxel_path()
-    max_tiles = L.evk_voxel3_max_tiles() if ver == "v3" else L.evk_voxel2_max_tiles()
-    tw, th = voxel_tile_shape(H, W, planes)
-    for a, b in ((tw, th), (5, 5)):
-        lb = int(os.environ.get("EVK_V2_LB", "10")) if ver == "v2" else 10   # experiment: -DV2_LB=11 builds take 2048-pixel tiles
-        if a + b <= lb and 0 < L.evk_bucket_num_tiles(H, W, a, b) <= max_tiles and planes * 8 << (a + b) <= (65536 if lb == 10 else 153600):
-            return a, b
-    return None
+    max_tiles = L.evk_voxel3_max_tiles() if voxel_path() == "v3" else L.evk_voxel2_max_tiles()
+    env = os.environ.get("EVK_VOXEL2_TILE")
+    best = None
+    if env:
+        a, b = (int(v) for v in env.split("x"))
+        if 0 < L.evk_voxel2_num_tiles(H, W, a, b) <= max_tiles:
+            best = (0.0, a, b)
+    else:
+        for tw in range(8, 129):
+            for th in range(4, 129):
+                cells = (tw | 1) * th
+                lds = planes * 8 * cells + _TILE_LIST_BYTES
+                if cells > 1024 or lds > 150 * 1024:
+                    break
+                T = -(-W // tw) * -(-H // th)
+                if T > max_tiles:
+                    continue
+                resident = min(3, (160 * 1024) // lds)
+                per_cu = -(-T // _NUM_CU)
+                cost = per_cu * tw * th * (1.0 + T / 20000.0) * (1.0 + 0.08 * max(0, -(-per_cu // resident) - 1)) \
+                    * (1.0 + 0.02 * (th > tw)) * (1.0 + 0.01 * max(0.0, tw / th - 4.0))
+                if best is None or cost < best[0]:
+                    best = (cost, tw, th)
+    shape = (best[1], best[2]) if best is not None else None
+    _shape_cache[key] = shape
+    return shape
 
 
 def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
@@ -203,7 +234,7 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     dev = out.device
     ver = "voxel3" if voxel_path() == "v3" else "voxel2"
     planes = 2 * B if split_polarity else B
-    ntiles = L.evk_bucket_num_tiles(H, W, tw, th)
+    ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
     key = (ver, ntiles, n, planes, tw, th)
     sizes = _staging_bytes.get(key)
     if sizes is None:
@@ -218,7 +249,7 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
         flags |= 128         # EVK_VOXEL2_SHARE_CU
     if os.environ.get("EVK_V2_XCD_ORDER", "1") == "0":
         flags |= 64          # EVK_VOXEL2_NO_XCD_ORDER (A/B measurement)
-    det = ver == "voxel3" and voxel_deterministic()
+    det = voxel_deterministic()
     if det:
         flags |= _lib.EVK_VOXEL_DETERMINISTIC
     if t_first is None:
@@ -527,7 +558,7 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
         ms = {kp: _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
               kt: _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
         dom = max(ms, key=ms.get)
-        return {"impl": "one-pass partition, tiles %dx%d" % (1 << shape2[0], 1 << shape2[1]), "dominant": dom,
+        return {"impl": "one-pass partition, tiles %dx%d" % shape2, "dominant": dom,
                 "dominant_ms": ms[dom], "total_ms": total, "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}
     tw, th = voxel_tile_shape(H, W, B)
     bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)

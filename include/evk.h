@@ -322,8 +322,15 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  *            EVK_VOXEL_T_FROM_EVENTS: t_first / t_last are read on the device from t[0] / t[n-1] (voxel_grid.py:133-134
  *            takes them from the same column), so the caller needs no device-to-host transfer before the launch;
  *            EVK_VOXEL2_PARTITION_ONLY / EVK_VOXEL2_TILES_ONLY: launch one of the two kernels (timing).
- * Tiles: 2^tw_log2 x 2^th_log2 <= 1024 pixels, at most evk_voxel2_max_tiles() of them. */
+ *            EVK_VOXEL_DETERMINISTIC: the tile kernel accumulates int64 multiples of 2^-32 instead of float64 (integer
+ *            adds commute: the grid is bit-identical from run to run and for any order of the events); every
+ *            contribution must be finite and below 2^30, anything else is counted in index[4] (the caller reads and
+ *            clears it) and left out.
+ * Tiles: tile_w x tile_h PIXELS, any size with (tile_w | 1) * tile_h <= 1024 (evk_voxel2_num_tiles() > 0), at most
+ * evk_voxel2_max_tiles() of them.  The tile kernel runs one workgroup per tile, all resident at once, so a tile COUNT
+ * that is a multiple of the 256 CUs (640x480: 512 tiles of 20x30) keeps every CU equally busy. */
 #define EVK_VOXEL_T_FROM_EVENTS 4
+#define EVK_VOXEL_DETERMINISTIC 256
 #define EVK_VOXEL2_PARTITION_ONLY 16
 #define EVK_VOXEL2_TILES_ONLY 32
 #define EVK_VOXEL2_SHARE_CU 128    /* partition with 64 KB of LDS per CU instead of 128 KB, so that workgroups of another,
@@ -331,44 +338,15 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 #define EVK_VOXEL2_NO_XCD_ORDER 64 /* A/B switch: tile kernel work items in plain order instead of one contiguous range per XCD */
 int evk_voxel2_max_tiles(void);
 int64_t evk_voxel2_index_len(int ntiles, int64_t n);
-int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2);
+int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h);   /* 0 = this tiling is not supported */
+int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tile_w, int tile_h);
 int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
-                   int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
+                   int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                    uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                    uint32_t seq, void *stream);
 /* the same from the reference's on-disk dtypes (see evk_bucket_events_native_f32) */
 int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind, double t_offset,
-                          const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first,
-                          float t_last, int B, int flags, float *vox, uint32_t *index, void *scratch,
-                          int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
-
-/* ---- one-pass voxel path, 4-byte records (evk_voxel3.hip; DESIGN.md section 3, K1'' / K2'') -- the default --------
- * Same contract, arguments, flags and results as evk_voxel2_f32 (replaces the B index_put_ passes of
- * voxel_grid.py:136-152), but a record is ONE 32-bit word: [31:12] the float32 t_norm of voxel_grid.py:134 as a
- * bit-pattern delta from its sub-chunk's first event (exact), [11:10] polarity code (+1 / -1 / +0 / escape), [9:0] pixel in
- * the tile; records that do not fit (other polarity values, unsorted or sparse time stamps, NaN) escape, exactly, to an
- * 8-byte side array.  24 B/event moved instead of 32, sub-chunks of <= 16 K events.
- *   index    evk_voxel3_index_len(ntiles, n) uint32, ZEROED ONCE by the caller (self-resetting counters);
- *            index[3] counts escaped records (information), index[4] the contributions EVK_VOXEL_DETERMINISTIC could not
- *            represent (the caller reads and clears it)
- *   scratch  evk_voxel3_scratch_bytes(...) bytes, 16-byte aligned, uninitialised
- *   flags    those of evk_voxel2_f32, plus
- *            EVK_VOXEL_DETERMINISTIC: the tile kernel accumulates int64 multiples of 2^-32 (integer adds commute: the
- *            grid is bit-identical from run to run and for any order of the events); |p * weight| must stay below 2^30
- *            and be finite, anything else is counted in index[4] and left out.
- * Tiles: 2^tw_log2 x 2^th_log2 <= 1024 pixels, at most evk_voxel3_max_tiles() of them; n * (1 + 3 * ntiles / 16384) < 2^32. */
-#define EVK_VOXEL_DETERMINISTIC 256
-int evk_voxel3_max_tiles(void);
-int64_t evk_voxel3_index_len(int ntiles, int64_t n);
-int64_t evk_voxel3_scratch_bytes(int ntiles, int64_t n, int planes, int tw_log2, int th_log2);
-int evk_voxel3_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
-                   int tw_log2, int th_log2, float t_first, float t_last, int B, int flags, float *vox,
-                   uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
-                   uint32_t seq, void *stream);
-/* the same from the reference's on-disk dtypes (event_packagers.py:90-93, h5_to_memmap.py:119-121; see
- * evk_bucket_events_native_f32): 13 B/event read */
-int evk_voxel3_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind, double t_offset,
-                          const void *p, int p_kind, int64_t n, int h, int wd, int tw_log2, int th_log2, float t_first,
+                          const void *p, int p_kind, int64_t n, int h, int wd, int tile_w, int tile_h, float t_first,
                           float t_last, int B, int flags, float *vox, uint32_t *index, void *scratch,
                           int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
 

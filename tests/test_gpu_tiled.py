@@ -76,10 +76,12 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
 
 
 @pytest.mark.parametrize("knobs", [{"EVK_SHARE_CU": "1"}, {"EVK_V2_XCD_ORDER": "0"}, {"EVK_VOXEL_PATH": "v1"},
-                                   {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}])
+                                   {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}, {"EVK_VOXEL2_TILE": "32x16"},
+                                   {"EVK_VOXEL2_TILE": "31x33"}, {"EVK_VOXEL_DETERMINISTIC": "1"}])
 def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
     """The voxel fast path under its run-time switches: the partition geometry a multi-rank job gets (8 K-event
-    sub-chunks, room for a collective's workgroups), plain work-item order, and the round-1 three-pass path."""
+    sub-chunks, room for a collective's workgroups), plain work-item order, the round-1 three-pass path, power-of-two and
+    odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     for (n, H, W, B, seed) in ((700_001, 480, 640, 5, 3), (90_000, 100, 130, 3, 4)):
@@ -89,6 +91,47 @@ def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
         v = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W))
         close(v.cpu().numpy(), ref)
     E.check_errors()
+
+
+def test_voxel_deterministic_mode_is_bit_reproducible_at_full_size(E, monkeypatch):
+    """EVK_VOXEL_DETERMINISTIC=1 (a deterministic mode): int64 fixed-point cells, integer adds commute
+    -- configs[1] (10 M events, 640x480, 5 bins) gives the SAME bits on every run and for a permuted event order of equal
+    time stamps; a non-finite weight is refused, not silently dropped."""
+    n, H, W, B = 10_000_000, 480, 640, 5
+    x, y, t, p = _events(1, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    plain = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
+    monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
+    runs = [E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy() for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    close(runs[0], plain, 1e-6)
+    assert abs(float(runs[0].astype(np.float64).sum()) - float(p.astype(np.float64).sum())) <= 1e-3 * n ** 0.5
+    # the same multiset of events in another order (time stamps of each swapped pair made equal): same bits
+    k = np.arange(0, n - 1, 2)
+    t2 = t.copy(); t2[k + 1] = t2[k]
+    base = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t2, p)), B, sensor_size=(H, W)).cpu().numpy()
+    x3, y3, p3 = x.copy(), y.copy(), p.copy()
+    for a in (x3, y3, p3):
+        a[k], a[k + 1] = a[k + 1].copy(), a[k].copy()
+    perm = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x3, y3, t2, p3)), B, sensor_size=(H, W)).cpu().numpy()
+    assert np.array_equal(base, perm)
+    p4 = p[:400_000].copy(); p4[7] = np.inf
+    with pytest.raises(ValueError):
+        E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x[:400_000], y[:400_000], t[:400_000], p4)), B,
+                                sensor_size=(H, W))
+
+
+def test_voxel_tiling_is_balanced_over_the_cus(E):
+    """The one-pass path tiles the sensor so that every CU gets the same number of tiles (the tile kernel runs one
+    workgroup per tile, all resident): 512 tiles at 640x480, a multiple of 256 within 1 % at 1280x720."""
+    from event_utils_amd import tiled
+    for (H, W, planes) in ((480, 640, 5), (720, 1280, 5), (480, 640, 10), (260, 346, 5)):
+        tw, th = tiled.voxel2_shape(H, W, planes)
+        T = -(-W // tw) * -(-H // th)
+        assert _lib.lib().evk_voxel2_num_tiles(H, W, tw, th) == T and (tw | 1) * th <= 1024
+        per_cu = -(-T // 256)
+        assert per_cu * 256 - T <= 0.05 * T, (H, W, tw, th, T)
+        assert per_cu * tw * th <= 1.06 * H * W / 256 + 64, (H, W, tw, th, T)
 
 
 def test_voxel_tiled_errors_and_wrap(E, monkeypatch):

@@ -85,13 +85,13 @@ def timing(n, H, W, B, reps=20, paths=("v3",), kind="uniform"):
     x, y, t, p = synth(1, n, H, W) if kind == "uniform" else scene(kind, n, H, W)
     cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
     for path in paths:
-        os.environ["EVK_VOXEL_PATH"] = path
+        if len(paths) > 1:
+            os.environ["EVK_VOXEL_PATH"] = path
         k = tiled.time_voxel_kernels(*cols, float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
         alg = 16.0 * n + B * H * W * 4
         print("%s %-7s n=%d %dx%dx%d: total %.4f ms (%.1f Gev/s, whole-call frac %.3f)  %s  [%s]" % (
             path, kind, n, H, W, B, k["total_ms"], n / k["total_ms"] / 1e6, alg / (k["total_ms"] * 1e-3) / 8e12,
             k["kernels_ms"], k["impl"]), flush=True)
-    os.environ["EVK_VOXEL_PATH"] = "v3"
 
 
 if __name__ == "__main__":
