@@ -83,15 +83,99 @@ static inline int make_grid_g(TileGridG &g, int dom_h, int dom_w, int tw, int th
 // Nearest-pixel key (EVK_KEY_NEAREST of tile_key): the tile of an event, and the accumulator cell inside the tile.
 // Branch-free: sixteen of these per thread with early returns became thirty-two divergent branches and the register
 // allocator spilled across them.
-__device__ __forceinline__ int nearest_key_cell(float x, float y, const TileGridG &g, uint32_t &cell) {
-    int xi = (int)x, yi = (int)y;   // .long() truncation (saturating v_cvt_i32_f32; NaN -> 0, rejected below)
+__device__ __forceinline__ int nearest_key_cell_int(int xi, int yi, bool finite, const TileGridG &g, uint32_t &cell) {
     xi += xi < 0 ? g.dom_w : 0;     // negative indices wrap once, as index_put_ does
     yi += yi < 0 ? g.dom_h : 0;
-    const bool ok = (x == x) & (y == y) & ((uint32_t)xi < (uint32_t)g.dom_w) & ((uint32_t)yi < (uint32_t)g.dom_h);
+    const bool ok = finite & ((uint32_t)xi < (uint32_t)g.dom_w) & ((uint32_t)yi < (uint32_t)g.dom_h);
     const uint32_t ux = ok ? (uint32_t)xi : 0u, uy = ok ? (uint32_t)yi : 0u;   // (< 2^16: the magic division is exact)
     const uint32_t tx = div_magic(ux, g.mx), ty = div_magic(uy, g.my);
     cell = (uy - ty * (uint32_t)g.th) * (uint32_t)g.pitch + (ux - tx * (uint32_t)g.tw);
     return ok ? (int)(ty * (uint32_t)g.tiles_x + tx) : -1;
 }
+__device__ __forceinline__ int nearest_key_cell(float x, float y, const TileGridG &g, uint32_t &cell) {
+    // .long() truncation (saturating v_cvt_i32_f32; NaN -> 0, rejected explicitly: torch gives INT64_MIN -> IndexError)
+    return nearest_key_cell_int((int)x, (int)y, (x == x) & (y == y), g, cell);
+}
+
+// ---- column sources of the one-pass partition: G consecutive events per lane -------------------------------------------
+// A load returns RAW 32-bit words; the event's values are decoded where they are USED (x_of ... p_of).  Converting at the
+// load site -- int16 -> float, (float)(t - t_offset) in float64, {0,1} -> -1/+1, as round 2 did -- makes the compiler wait
+// for the data right behind the load instruction: the loads then overlap nothing, which is why the 13 B/event path was
+// slower than the 16 B/event one.
+struct SrcF32 {  // four float32 SoA columns, 16 B / event
+    static constexpr int G = 4, XYW = 8, TPW = 8;
+    const float *x, *y, *t, *p;
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(t + ev0)[gl], b = reinterpret_cast<const uint4 *>(p + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
+        return nearest_key_cell(__uint_as_float(r[e]), __uint_as_float(r[4 + e]), g, cell);
+    }
+    __device__ __forceinline__ float t_of(const uint32_t *r, int e) const { return __uint_as_float(r[e]); }
+    __device__ __forceinline__ float p_of(const uint32_t *r, int e) const { return __uint_as_float(r[4 + e]); }
+    __device__ __forceinline__ float t1(int64_t i) const { return t[i]; }
+};
+
+// The on-disk dtypes of the reference's event files (event_packagers.py:90-93: xs, ys int16, ts float64, ps bool;
+// h5_to_memmap.py:119-121: xy int16 (N, 2), t float64, p uint8): 13 B / event.  xy_stride 1: separate x / y columns;
+// 2: one interleaved (N, 2) array.  t float64 (T64) or float32; the record holds (float)(t - t_offset), the subtraction in
+// float64 (the loaders' (ts - ts_0).float(), base_dataset.py:306).  p: EVK_P_U8_PM1 uint8 / bool {0,1} -> 2p - 1 (what
+// the loaders' get_events does, hdf5_dataset.py:22, memmap_dataset.py:23), EVK_P_U8 uint8 as is, EVK_P_I8 int8 as is.
+template <bool T64>
+struct SrcNative {
+    static constexpr int G = 4, XYW = 4, TPW = T64 ? 9 : 5;
+    const int16_t *x, *y;
+    const void *t;
+    const uint8_t *p;
+    double t_offset;
+    int xy_stride, p_kind;
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        if (xy_stride == 2) {   // x0 y0 | x1 y1 | x2 y2 | x3 y3
+            const uint4 w = reinterpret_cast<const uint4 *>(x + 2 * ev0)[gl];
+            r[0] = w.x, r[1] = w.y, r[2] = w.z, r[3] = w.w;
+        } else {                // x0 x1 | x2 x3 ; y0 y1 | y2 y3
+            const uint2 a = reinterpret_cast<const uint2 *>(x + ev0)[gl], b = reinterpret_cast<const uint2 *>(y + ev0)[gl];
+            r[0] = a.x, r[1] = a.y, r[2] = b.x, r[3] = b.y;
+        }
+    }
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        if constexpr (T64) {    // two 16-byte loads, issued together
+            const uint4 a = reinterpret_cast<const uint4 *>(static_cast<const double *>(t) + ev0)[2 * gl];
+            const uint4 b = reinterpret_cast<const uint4 *>(static_cast<const double *>(t) + ev0)[2 * gl + 1];
+            r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+        } else {
+            const uint4 a = reinterpret_cast<const uint4 *>(static_cast<const float *>(t) + ev0)[gl];
+            r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
+        }
+        r[TPW - 1] = reinterpret_cast<const uint32_t *>(p + ev0)[gl];
+    }
+    __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
+        // integer pixel coordinates straight from the int16 (no float round trip); the int16 is moved to the high half and
+        // shifted back arithmetically
+        const uint32_t wx = xy_stride == 2 ? r[e] << 16 : (e & 1 ? r[e >> 1] : r[e >> 1] << 16);
+        const uint32_t wy = xy_stride == 2 ? r[e] : (e & 1 ? r[2 + (e >> 1)] : r[2 + (e >> 1)] << 16);
+        return nearest_key_cell_int((int32_t)wx >> 16, (int32_t)wy >> 16, true, g, cell);
+    }
+    __device__ __forceinline__ float t_of(const uint32_t *r, int e) const {
+        if constexpr (T64) {
+            const double d = __hiloint2double((int)r[2 * e + 1], (int)r[2 * e]);
+            return (float)(d - t_offset);
+        } else {
+            return (float)((double)__uint_as_float(r[e]) - t_offset);
+        }
+    }
+    __device__ __forceinline__ float p_of(const uint32_t *r, int e) const {
+        const uint32_t b = (r[TPW - 1] >> (8 * e)) & 0xffu;
+        return p_kind == EVK_P_U8_PM1 ? (float)(2 * (int)b - 1) : (p_kind == EVK_P_I8 ? (float)(int8_t)b : (float)b);
+    }
+    __device__ __forceinline__ float t1(int64_t i) const {
+        return (float)((T64 ? static_cast<const double *>(t)[i] : (double)static_cast<const float *>(t)[i]) - t_offset);
+    }
+};
 
 }  // namespace evk

@@ -97,91 +97,97 @@ struct Part2 {
     int nblk;
 };
 
-template <int THREADS, int EPT, int BPC, typename C>
-__global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q,
-                                                            float t_first, float t_last, float bm1, int t_from_events,
+// C = column source (evk_part.h): SrcF32, or SrcNative<.> for the reference's on-disk dtypes.  G = C::G consecutive events
+// per lane and load instruction.
+template <int THREADS, int EPT, typename C>
+__global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q, float t_first,
+                                                            float t_last, float bm1, int t_from_events,
                                                             uint2 *__restrict__ rec, float *__restrict__ pw,
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                             uint32_t cap, uint32_t part, uint32_t *oob, uint32_t *host_report,
                                                             uint32_t seq) {
-    constexpr int NQ = EPT / 4;
+    constexpr int G = C::G, NG = EPT / G;
+    static_assert(EPT % G == 0, "events per thread");
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2 *sorted = reinterpret_cast<uint2 *>(smem);                           // [THREADS * EPT] + 2 (trash slot)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts, then cursors; [ntiles] = dummy
-    uint32_t *tmp = hist + ((ntiles + 4) & ~3);                                 // [65] scan scratch
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts, then cursors
+    uint32_t *tot = hist + ((ntiles + 4) & ~3);                                 // [ntiles] this workgroup's totals
+    uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [65] scan scratch (plan); [66] = run length
     __shared__ int is_last;
-    const int tid = threadIdx.x;
-    const int per = (ntiles + THREADS - 1) / THREADS;
-    const int i0 = tid * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
-    uint32_t mytot[PER_MAX];
-#pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) mytot[k] = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
     uint32_t dropped = 0, nwide = 0;
     if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
     const float dt = t_last - t_first;
 
-    // Quad k of sub-chunk sc = 4 consecutive events of thread tid, one 16-byte load per column.  A quad that is only
-    // partly inside the stream is loaded whole (the over-read stays inside an aligned block; the extra events are
-    // ignored); a quad entirely outside is not loaded.  There is no scalar tail path: it would put branches -- and the
-    // compiler's waits -- between the loads of one sub-chunk.
-    auto valid_in = [&](int sc, int k) -> int {  // events of quad k inside the stream (<= 0: none)
+    // Group k of sub-chunk sc = G consecutive events of thread tid.  A group that is only partly inside the stream is
+    // loaded whole (the over-read stays inside an aligned block; the extra events are ignored); a group entirely outside
+    // re-reads the sub-chunk's first group.  No branches: between the loads they cost waits and registers.
+    // (tl_ = the thread index as the LOOP BODY sees it: re-materialised through an empty asm in every iteration, so that the
+    // per-group offsets and predicates derived from it are recomputed -- a few VALU instructions -- instead of being hoisted
+    // out of the loop into registers that stay live across it.)
+    int tl_ = tid;
+    auto valid_in = [&](int sc, int k) -> int {  // events of group k inside the stream (<= 0: none)
         const int64_t lo = (int64_t)sc * q.S;
         const int64_t hi = (lo + q.S < n) ? lo + q.S : n;
-        return (int)(hi - lo) - 4 * (tid + k * THREADS);
+        return (int)(hi - lo) - G * (tl_ + k * THREADS);
+    };
+    // Addresses are (uniform base of the row of THREADS groups) + (one 32-bit lane offset): scalar registers and the
+    // saddr form of the load, not a 64-bit VGPR pair per load.
+    auto row_base = [&](int sc, int k) -> int64_t {   // first event of group row k; a row entirely outside: the first row
+        const int64_t lo = (int64_t)sc * q.S, hi = (lo + q.S < n) ? lo + q.S : n, r = lo + (int64_t)G * k * THREADS;
+        return r < hi ? r : lo;
     };
     // Software pipeline over the two halves of an event: x, y are needed first (tile key, histogram), t, p only at
     // placement.  t, p of sub-chunk j are loaded after its keys and land during its histogram + scan; x, y of j + 1 are
-    // loaded before the placement of j and land during its placement + write-out.  (gfx9 counts loads and stores with ONE
-    // counter that is in order only among loads, so a wave with stores in flight cannot wait for a particular load: the
-    // first use of loaded data waits for everything outstanding.  Deeper pipelines -- t, p one sub-chunk ahead as well --
-    // added register spills at 12-16 events per thread (150 us instead of 62) and, at 8 events per thread where they fit
-    // (128 registers, no spill), bunch all eight loads of a sub-chunk into one phase: 57 us instead of 48.5.)
+    // loaded before the placement of j and land during its placement.  (gfx9 counts loads and stores with ONE counter
+    // that is in order only among loads, so a wave with stores in flight cannot wait for a particular load: the first use
+    // of loaded data waits for everything outstanding -- hence the explicit wait points below, at moments when everything
+    // outstanding is old.)
     const int sc0 = blockIdx.x * q.per_block;
     const int sc_end = (sc0 + q.per_block < q.nsc) ? sc0 + q.per_block : q.nsc;
-    Vec4<float> xv[NQ], yv[NQ], tv[NQ], pv[NQ];
+    uint32_t xyr[NG * C::XYW], tpr[NG * C::TPW];   // RAW loaded words: decoded where they are used (evk_part.h)
+    float tv[EPT];
+    uint32_t kl[EPT];
     auto load_xy = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int nv = valid_in(sc, k);
-            if (nv > 0) c.xy4n((int64_t)sc * q.S, k * THREADS, (uint32_t)tid, nv, xv[k], yv[k]);
-        }
+        for (int k = 0; k < NG; ++k) c.load_xy(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
     };
     auto load_tp = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int nv = valid_in(sc, k);
-            if (nv > 0) c.tp4n((int64_t)sc * q.S, k * THREADS, (uint32_t)tid, nv, tv[k], pv[k]);
-        }
+        for (int k = 0; k < NG; ++k) c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
     };
+    auto fence = [&]() {   // for the compiler: loads hoisted above a compute phase keep their 2 * EPT registers live through it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0, tot[i] = 0;   // (every pass leaves hist zero again)
     if (sc0 < sc_end) load_xy(sc0);
-    // vmcnt(0), expcnt / lgkmcnt untouched.  As a BUILTIN, so that the compiler's wait-count pass knows that x, y are in
-    // their registers from here on: their first use, at the top of the loop, would otherwise get an `s_waitcnt vmcnt(0)`
-    // of its own -- and that one also waits for the write-out stores of the previous sub-chunk (one counter for loads and
-    // stores), ~1-2 us on every pass.  Waiting HERE and before the write-out (below) costs nothing: the loads are old.
-#define V2_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
-    V2_WAIT_VM0();
+    EVK_WAIT_VM0();
+    lds_barrier();
     for (int sc = sc0; sc < sc_end; ++sc) {
+        asm volatile("" : "+v"(tl_));
         const int64_t lo = (int64_t)sc * q.S;
-        for (int i = tid; i <= ntiles; i += THREADS) hist[i] = 0;
-        // ---- tile key + pixel in tile of every event
-        uint32_t kl[EPT];
+        // ---- tile key + accumulator cell of every event
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
+        for (int k = 0; k < NG; ++k) {
             const int nv = valid_in(sc, k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                uint32_t local = 0;
-                const int key = e < nv ? nearest_key_cell(xv[k].v[e], yv[k].v[e], g, local) : -1;
-                kl[4 * k + e] = key >= 0 ? (((uint32_t)key << V2_LB) | local) : 0xFFFFFFFFu;
-                dropped += (key < 0 && e < nv) ? 1u : 0u;
+            for (int e = 0; e < G; ++e) {
+                uint32_t cell = 0;
+                const int key = c.key_of(xyr + C::XYW * k, e, g, cell);   // (of stale words beyond the stream)
+                kl[G * k + e] = ((key >= 0) & (e < nv)) ? (((uint32_t)key << V2_LB) | cell) : 0xFFFFFFFFu;
+                dropped += ((key < 0) & (e < nv)) ? 1u : 0u;
+                asm volatile("" : "+v"(dropped));   // counted HERE: sunk to the end of the loop body it kept a copy of every key alive
+                // one event at a time: GCN issues dependent VALU instructions back to back, while interleaving the EPT
+                // independent chains (what the scheduler does for ILP) keeps ~4 temporaries per event live at once
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2) asm volatile("" : "+v"(kl[s2])::"memory");  // keys first, the t, p loads after
         load_tp(sc);    // land during the histogram and the scan
-        lds_barrier();  // hist is zero
-        // ---- histogram (no-return LDS atomics)
+        // ---- histogram (no-return LDS atomics; hist is zero: the previous pass, or the prologue, left it so)
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2)
             if (kl[s2] != 0xFFFFFFFFu)
@@ -190,95 +196,100 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
         if (V2_ABLATE_A < 2) {
             uint32_t sink = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2 >> 2].v[s2 & 3]) ^ __float_as_uint(pv[s2 >> 2].v[s2 & 3]);
-            if (sink == 0x12345u) hist[1] = 1;
+            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(c.t_of(tpr + C::TPW * (s2 / G), s2 % G)) ^ __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
+            if (sink == 0x12345u) tot[1] = 1;
+            for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0;
             if (sc + 1 < sc_end) load_xy(sc + 1);
+            EVK_WAIT_VM0();
+            lds_barrier();
             continue;
         }
-        // ---- exclusive scan of the tile counts (thread tid owns tiles [i0, i1)) -> cursors; table row; totals
-        uint32_t mine = 0;
-        for (int i = i0; i < i1; ++i) mine += hist[i];
-        uint32_t kept;
-        uint32_t run = block_excl_scan<THREADS>(mine, tmp, kept);
-        uint32_t *trow = table + (int64_t)sc * q.nt_pad;
-        uint32_t tval[PER_MAX];   // this thread's table entries: stored with the write-out (no store before the next loads)
+        // ---- exclusive scan of the tile counts -> cursors, the table row, this workgroup's totals: ONE wave, 64 tiles per
+        //      step, no workgroup barrier inside (the three-barrier workgroup scan of round 2 made 7 barriers per pass of
+        //      16 waves; this makes 4)
+        if (tid < 64) {
+            uint32_t *trow = table + (int64_t)sc * q.nt_pad;
+            uint32_t carry = 0;
+            for (int i0 = 0; i0 < ntiles; i0 += 64) {
+                const int i = i0 + lane;
+                const uint32_t cnt = i < ntiles ? hist[i] : 0u;
+                uint32_t incl = cnt;
 #pragma unroll
-        for (int k = 0; k < PER_MAX; ++k) {
-            const int i = i0 + k;
-            tval[k] = 0;
-            if (k < per && i < i1) {
-                const uint32_t cnt = hist[i];
-                hist[i] = run;
-                tval[k] = run | (cnt << 16);
-                mytot[k] += cnt;
-                run += cnt;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += v;
+                }
+                if (i < ntiles) {
+                    const uint32_t start = carry + incl - cnt;
+                    hist[i] = start;
+                    tot[i] += cnt;
+                    trow[i] = start | (cnt << 16);
+                }
+                carry += __shfl(incl, 63, 64);
             }
+            if (lane == 0) tmp[66] = carry;
         }
-        lds_barrier();  // cursors complete (also frees tmp)
-        // normalised time, in place (t has landed during the histogram and the scan); pinned so that the 4 * NQ divisions
-        // are not interleaved with the placement below (that costs ~70 registers of temporaries)
+        lds_barrier();  // cursors complete
+        const uint32_t kept = tmp[66];
+        // normalised time, in place (t has landed during the histogram and the scan), one division at a time
 #pragma unroll
-        for (int k = 0; k < NQ; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                tv[k].v[e] = (tv[k].v[e] - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
-                asm volatile("" : "+v"(tv[k].v[e]));
-            }
+        for (int s2 = 0; s2 < EPT; ++s2) {
+            tv[s2] = (c.t_of(tpr + C::TPW * (s2 / G), s2 % G) - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // Nothing outstanding from here (t, p are in; the previous sub-chunk's stores are a histogram and a scan old) -- said
         // with the builtin so that the placement's uses of t, p get no wait of their own: with x, y of the next sub-chunk
         // just issued such a wait is a vmcnt(0), i.e. the full latency of those loads in every placement.
-        V2_WAIT_VM0();
+        EVK_WAIT_VM0();
+        fence();
         if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement
+        fence();
         if (V2_ABLATE_A < 3) {
             uint32_t sink = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2 >> 2].v[s2 & 3]) ^ __float_as_uint(pv[s2 >> 2].v[s2 & 3]);
-            if (sink == 0x12345u) hist[1] = 1;
+            for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2]) ^ __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
+            if (sink == 0x12345u) tot[1] = 1;
+            lds_barrier();
+            for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0;
+            EVK_WAIT_VM0();
             lds_barrier();
             continue;
         }
         // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer;
-        //      the 8-byte record = normalised time | polarity | pixel in tile
+        //      the 8-byte record = normalised time | polarity | accumulator cell
         uint32_t wide_mask = 0;
 #pragma unroll
-        for (int s = 0; s < EPT; ++s) {
-            if (kl[s] != 0xFFFFFFFFu) {
-                const uint32_t pos = atomicAdd(&hist[kl[s] >> V2_LB], 1u);
-                const float tn = tv[s >> 2].v[s & 3];
-                const uint32_t pbits = __float_as_uint(pv[s >> 2].v[s & 3]);
+        for (int s2 = 0; s2 < EPT; ++s2) {
+            if (kl[s2] != 0xFFFFFFFFu) {
+                const uint32_t pos = atomicAdd(&hist[kl[s2] >> V2_LB], 1u);
+                const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
                 const bool wide = (pbits & ~V2_P_MASK) != 0u;
-                sorted[pos] = make_uint2(__float_as_uint(tn), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s] & V2_LOCAL_MASK));
-                if (wide) wide_mask |= 1u << s, kl[s] = pos;   // kl is dead from here on: keep the slot instead
+                sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
+                if (wide) wide_mask |= 1u << s2, kl[s2] = pos;   // kl is dead from here on: keep the slot instead
             }
         }
         if (__any(wide_mask != 0u)) {  // rare: exact float32 polarities go to the side array at the record's index
 #pragma unroll
-            for (int s = 0; s < EPT; ++s)
-                if (wide_mask >> s & 1u) pw[lo + kl[s]] = pv[s >> 2].v[s & 3], ++nwide;
+            for (int s2 = 0; s2 < EPT; ++s2)
+                if (wide_mask >> s2 & 1u) pw[lo + kl[s2]] = c.p_of(tpr + C::TPW * (s2 / G), s2 % G), ++nwide;
         }
         lds_barrier();
-        V2_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: see above
-        // ---- one contiguous, coalesced run of `kept` records
+        EVK_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: see above
+        // ---- one contiguous, coalesced run of `kept` records; hist back to zero for the next pass
         if (V2_ABLATE_A >= 4) {
             const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
             uint4 *dst = reinterpret_cast<uint4 *>(rec + lo);
             const int n16 = (int)((kept + 1) >> 1);
             for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
         }
-#pragma unroll
-        for (int k = 0; k < PER_MAX; ++k)
-            if (k < per && i0 + k < i1) trow[i0 + k] = tval[k];
+        for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0;
         lds_barrier();  // sorted / hist are rewritten by the next sub-chunk
     }
     if (dropped && oob) atomicAdd(oob, dropped);
     // ---- totals -> global; the last block to arrive builds the work-item plan
     uint32_t *gidx = index;
-#pragma unroll
-    for (int k = 0; k < PER_MAX; ++k) {
-        const int i = i0 + k;
-        if (k < per && i < i1 && mytot[k])
-            __hip_atomic_fetch_add(gidx + V2_TOTALS + i, mytot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int i = tid; i < ntiles; i += THREADS)
+        if (tot[i]) __hip_atomic_fetch_add(gidx + V2_TOTALS + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nwide) __hip_atomic_fetch_add(gidx + 3, nwide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0 && tid == 0 && n > 0) {
         __hip_atomic_store(gidx + 0, __float_as_uint(c.t1(0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -295,31 +306,30 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256 * BPC) k_part_sorted(co
     }
     __syncthreads();
     if (!is_last) return;
-    // ---- plan (as k_tile_scan_totals): part_start, per-tile combine counters, item -> tile; totals / ticket back to 0
+    // ---- plan: part_start, per-tile combine counters, item -> tile; totals / ticket back to 0.  A tile with more than `cap`
+    //      events is cut into pieces of at most `part` events (ranges of sub-chunks).
+    const int per = (ntiles + THREADS - 1) / THREADS;
+    const int i0 = tid * per, i1 = (i0 + per < ntiles) ? i0 + per : ntiles;
     uint32_t *part_start = index + V2_PART, *counters = index + V2_COUNTER(ntiles), *item_tile = index + V2_ITEM(ntiles);
-    uint32_t tot[PER_MAX];
+    uint32_t tt[PER_MAX];
     uint32_t np = 0;
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
         const int i = i0 + k;
-        tot[k] = 0;
+        tt[k] = 0;
         if (k < per && i < i1) {
-            tot[k] = __hip_atomic_load(gidx + V2_TOTALS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tt[k] = __hip_atomic_load(gidx + V2_TOTALS + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gidx + V2_TOTALS + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            np += tot[k] > cap ? (tot[k] + part - 1) / part : 1u;
+            np += tt[k] > cap ? (tt[k] + part - 1) / part : 1u;
         }
     }
-    // (The balanced plan of k_tile_scan_totals -- more, smaller items for non-uniform scenes -- was tried here and is
-    // slower: this kernel keeps only 2-3 workgroups per CU resident (52-72 KB of LDS each), so items beyond ~768 / 512
-    // run as a second round, and every part of a split tile pays the accumulator zeroing, a staging store and the
-    // combine.  Moving-edge scene, 10 M events / VGA: 66 -> 76 us; 50 M / 720p: 257 -> 278 us.)
     uint32_t total_parts;
     uint32_t prun = block_excl_scan<THREADS>(np, tmp, total_parts);
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
         const int i = i0 + k;
         if (k < per && i < i1) {
-            const uint32_t parts = tot[k] > cap ? (tot[k] + part - 1) / part : 1u;
+            const uint32_t parts = tt[k] > cap ? (tt[k] + part - 1) / part : 1u;
             part_start[i] = prun;
             counters[i] = 0;
             for (uint32_t jj = 0; jj < parts; ++jj) item_tile[prun + jj] = (uint32_t)i;
@@ -662,21 +672,21 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
 // e.g. an overlapped RCCL collective) and 1024 x 12 (12 K events: longer segments for the tile kernel, taken when there
 // are more than 680 tiles and the call need not share its CUs).  Measured and rejected (compiled
 // only with -DEVK_EXPERIMENTS, tools/exp_build.sh, and selected with EVK_V2_PART): 512x32 / 1024x16 (16 K events: the
-// whole register file, 67 / 74 us), 1024x8x2 / 512x16x2 / 768x12x2 (two workgroups per CU: spills, 75-150 us).
+// whole register file, 67 / 74 us), two workgroups per CU (1024x8 / 512x16 / 768x12: spills, 75-150 us).
 struct V2Config {
-    int threads, ept, blocks_per_cu;
+    int threads, ept;
 };
 #ifdef EVK_EXPERIMENTS
-#define V2_GEOMETRIES(X) X(1024, 8, 1) X(1024, 12, 1) X(512, 32, 1) X(1024, 16, 1) X(1024, 8, 2) X(512, 16, 2) X(768, 12, 2)
+#define V2_GEOMETRIES(X) X(1024, 8) X(1024, 12) X(1024, 16) X(512, 16)
 #else
-#define V2_GEOMETRIES(X) X(1024, 8, 1) X(1024, 12, 1)
+#define V2_GEOMETRIES(X) X(1024, 8) X(1024, 12)
 #endif
 static V2Config v2_config_env() {
-    V2Config c{0, 0, 0};
+    V2Config c{0, 0};
     const char *geo = getenv("EVK_V2_PART");
-    int t = 0, e = 0, b = 1;
-    if (geo && sscanf(geo, "%dx%dx%d", &t, &e, &b) >= 2) {
-#define X(T, E, BPC) if (t == T && e == E && b == BPC) c = V2Config{T, E, BPC};
+    int t = 0, e = 0;
+    if (geo && sscanf(geo, "%dx%d", &t, &e) == 2) {
+#define X(T, E) if (t == T && e == E) c = V2Config{T, E};
         V2_GEOMETRIES(X)
 #undef X
     }
@@ -684,7 +694,7 @@ static V2Config v2_config_env() {
 }
 static const V2Config &v2_config(bool share = false, int ntiles = 0) {
     static const V2Config forced = v2_config_env();
-    static const V2Config small{1024, 8, 1}, large{1024, 12, 1};
+    static const V2Config small{1024, 8}, large{1024, 12};
     if (share) return small;
     if (forced.threads) return forced;
     return ntiles > 680 ? large : small;
@@ -695,7 +705,7 @@ static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
     const V2Config &c = v2_config(share, ntiles);
     const int64_t smax = (int64_t)c.threads * c.ept;
     int64_t nblk = (n + V2_MIN_SUBCHUNK - 1) / V2_MIN_SUBCHUNK;
-    const int64_t maxblk = (int64_t)EVK_NUM_CU * c.blocks_per_cu;
+    const int64_t maxblk = (int64_t)EVK_NUM_CU * (1024 / c.threads);
     if (nblk > maxblk) nblk = maxblk;
     if (nblk < 1) nblk = 1;
     int64_t per_block = (n + nblk * smax - 1) / (nblk * smax);
@@ -784,23 +794,27 @@ extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
 extern "C" int evk_voxel2_max_tiles(void) {
     const int64_t budget = (int64_t)160 * 1024 - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
-    const int64_t t = budget / 4;
+    const int64_t t = budget / 8;   // a counter / cursor and a total per tile
     return (int)(t < V2_MAX_TILES ? (t > 0 ? t : 0) : V2_MAX_TILES);
 }
 
-template <int THREADS, int EPT, int BPC, typename C>
+static size_t v2_part_lds(int threads, int ept, int ntiles) {
+    return (size_t)threads * ept * 8 + 16 + 2 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
+}
+
+template <int THREADS, int EPT, typename C>
 static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part2 &q, float t_first, float t_last,
                         float bm1, int t_from_events, uint2 *rec, float *pw, uint32_t *table, uint32_t *index,
                         uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
-    const size_t lds = (size_t)THREADS * EPT * 8 + 16 + (size_t)((ntiles + 4) & ~3) * 4 + 65 * 4 + 16;
+    const size_t lds = v2_part_lds(THREADS, EPT, ntiles);
     static std::once_flag once[64];   // per device and instantiation: the attribute belongs to the loaded code object
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {   // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
-        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, BPC, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 256);
     });
-    k_part_sorted<THREADS, EPT, BPC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
+    k_part_sorted<THREADS, EPT, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
                                                                     rec, pw, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
                                                                     host_report, seq);
 }
@@ -852,9 +866,9 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
-#define X(T, E, BPC)                                                                                                  \
-    if (cfg.threads == T && cfg.ept == E && cfg.blocks_per_cu == BPC)                                                 \
-        launch_part<T, E, BPC>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+#define X(T, E)                                                                                                       \
+    if (cfg.threads == T && cfg.ept == E)                                                                             \
+        launch_part<T, E>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
         V2_GEOMETRIES(X)
 #undef X
     }
@@ -885,7 +899,7 @@ extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, co
                               uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
-    const ColsF32 c{x, y, t, p};
+    const SrcF32 c{x, y, t, p};
     return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }
@@ -895,10 +909,16 @@ extern "C" int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_
                                      int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                                      uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                                      uint32_t *host_report, uint32_t seq, void *stream) {
-    ColsNative c;
-    const int rc = native_cols(c, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
+    ColsNative v;
+    const int rc = native_cols(v, x, y, xy_stride, t, t_kind, t_offset, p, p_kind, n);
     if (rc != EVK_OK) return rc;
     if (!(aligned16(x) && (xy_stride == 2 || aligned16(y)) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    if (t_kind == EVK_T_F64) {   // two events per lane and load: every instruction contiguous over the wave (evk_part.h)
+        const SrcNative<true> c{v.x, v.y, v.t, v.p, v.t_offset, v.xy_stride, v.p_kind};
+        return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
+                      seq, stream);
+    }
+    const SrcNative<false> c{v.x, v.y, v.t, v.p, v.t_offset, v.xy_stride, v.p_kind};
     return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
 }

@@ -53,82 +53,6 @@ namespace evk {
 #define V3_TILES_MIN_WAVES 6  // waves per SIMD the tile kernel must fit (<= 80 registers): 3 workgroups of 8 waves per CU
 #endif
 
-// ---- column sources: G consecutive events per lane and load instruction, every instruction contiguous over the wave ----
-struct SrcF32 {  // four float32 SoA columns, 16 B / event
-    static constexpr int G = 4;
-    const float *x, *y, *t, *p;
-    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, float *xv, float *yv) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
-        xv[0] = __uint_as_float(a.x), xv[1] = __uint_as_float(a.y), xv[2] = __uint_as_float(a.z), xv[3] = __uint_as_float(a.w);
-        yv[0] = __uint_as_float(b.x), yv[1] = __uint_as_float(b.y), yv[2] = __uint_as_float(b.z), yv[3] = __uint_as_float(b.w);
-    }
-    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, int, float *tv, float *pv) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(t + ev0)[gl], b = reinterpret_cast<const uint4 *>(p + ev0)[gl];
-        tv[0] = __uint_as_float(a.x), tv[1] = __uint_as_float(a.y), tv[2] = __uint_as_float(a.z), tv[3] = __uint_as_float(a.w);
-        pv[0] = __uint_as_float(b.x), pv[1] = __uint_as_float(b.y), pv[2] = __uint_as_float(b.z), pv[3] = __uint_as_float(b.w);
-    }
-    __device__ __forceinline__ float t1(int64_t i) const { return t[i]; }
-};
-
-// The on-disk dtypes of the reference's event files (event_packagers.py:90-93, h5_to_memmap.py:119-121): x, y int16
-// (two columns or one interleaved (N, 2) array), t float64 or float32, p uint8 / bool / int8: 13 B / event.
-// With float64 t a lane takes TWO events per load (t: one 16-byte load, x / y: one dword each, p: 2 bytes): every
-// instruction reads one contiguous span over the wave.  (Round 2 took 4 events per lane, i.e. two 16-byte loads of t
-// 32 bytes apart in every lane -- half-used cache lines per instruction -- and was slower than the 16 B/event path.)
-template <bool T64>
-struct SrcNative {
-    static constexpr int G = T64 ? 2 : 4;
-    const int16_t *x, *y;
-    const void *t;
-    const uint8_t *p;
-    double t_offset;
-    int xy_stride, p_kind;
-    __device__ __forceinline__ float pol(uint32_t b) const {
-        return p_kind == EVK_P_U8_PM1 ? (float)(2 * (int)b - 1) : (p_kind == EVK_P_I8 ? (float)(int8_t)b : (float)b);
-    }
-    static __device__ __forceinline__ float lo16(uint32_t w) { return (float)(int16_t)(w & 0xffffu); }
-    static __device__ __forceinline__ float hi16(uint32_t w) { return (float)(int16_t)(w >> 16); }
-    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, float *xv, float *yv) const {
-        if constexpr (G == 2) {
-            if (xy_stride == 2) {
-                const uint2 w = reinterpret_cast<const uint2 *>(x + 2 * ev0)[gl];   // x0 y0 | x1 y1
-                xv[0] = lo16(w.x), yv[0] = hi16(w.x), xv[1] = lo16(w.y), yv[1] = hi16(w.y);
-            } else {
-                const uint32_t a = reinterpret_cast<const uint32_t *>(x + ev0)[gl], b = reinterpret_cast<const uint32_t *>(y + ev0)[gl];
-                xv[0] = lo16(a), xv[1] = hi16(a), yv[0] = lo16(b), yv[1] = hi16(b);
-            }
-        } else {
-            if (xy_stride == 2) {
-                const uint4 w = reinterpret_cast<const uint4 *>(x + 2 * ev0)[gl];
-                xv[0] = lo16(w.x), yv[0] = hi16(w.x), xv[1] = lo16(w.y), yv[1] = hi16(w.y);
-                xv[2] = lo16(w.z), yv[2] = hi16(w.z), xv[3] = lo16(w.w), yv[3] = hi16(w.w);
-            } else {
-                const uint2 a = reinterpret_cast<const uint2 *>(x + ev0)[gl], b = reinterpret_cast<const uint2 *>(y + ev0)[gl];
-                xv[0] = lo16(a.x), xv[1] = hi16(a.x), xv[2] = lo16(a.y), xv[3] = hi16(a.y);
-                yv[0] = lo16(b.x), yv[1] = hi16(b.x), yv[2] = lo16(b.y), yv[3] = hi16(b.y);
-            }
-        }
-    }
-    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, int, float *tv, float *pv) const {
-        if constexpr (G == 2) {
-            const double2 d = reinterpret_cast<const double2 *>(static_cast<const double *>(t) + ev0)[gl];
-            const uint32_t w = reinterpret_cast<const uint16_t *>(p + ev0)[gl];
-            tv[0] = (float)(d.x - t_offset), tv[1] = (float)(d.y - t_offset);
-            pv[0] = pol(w & 0xffu), pv[1] = pol(w >> 8);
-        } else {
-            const uint4 f = reinterpret_cast<const uint4 *>(static_cast<const float *>(t) + ev0)[gl];
-            const uint32_t w = reinterpret_cast<const uint32_t *>(p + ev0)[gl];
-            tv[0] = (float)((double)__uint_as_float(f.x) - t_offset), tv[1] = (float)((double)__uint_as_float(f.y) - t_offset);
-            tv[2] = (float)((double)__uint_as_float(f.z) - t_offset), tv[3] = (float)((double)__uint_as_float(f.w) - t_offset);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pv[k] = pol((w >> (8 * k)) & 0xffu);
-        }
-    }
-    __device__ __forceinline__ float t1(int64_t i) const {
-        return (float)((T64 ? static_cast<const double *>(t)[i] : (double)static_cast<const float *>(t)[i]) - t_offset);
-    }
-};
-
 struct Part3 {
     int S;          // events per sub-chunk (% 4 == 0, <= THREADS * EPT)
     int spad;       // record slots per run: S + 3 per tile of padding, % 4 == 0
@@ -180,7 +104,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
     // once (key, t, p) of j have been compressed to record words, and land during the placement + write-out.
     const int sc0 = blockIdx.x * q.per_block;
     const int sc_end = (sc0 + q.per_block < q.nsc) ? sc0 + q.per_block : q.nsc;
-    float xv[EPT], yv[EPT], tv[EPT], pv[EPT];
+    uint32_t xyr[NG * C::XYW], tpr[NG * C::TPW];   // RAW loaded words: decoded where they are used (evk_part.h)
     float tb = 0.0f;
     // (the loads are unconditional -- a group entirely outside the stream re-reads the sub-chunk's first group -- so that
     // the loop body is straight-line code: branches between the loads cost waits and registers)
@@ -193,12 +117,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
     auto load_xy = [&](int sc) {
 #pragma unroll
         for (int k = 0; k < NG; ++k)
-            c.load_xy(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xv + G * k, yv + G * k);
+            c.load_xy(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
     };
     auto load_tp = [&](int sc) {
 #pragma unroll
         for (int k = 0; k < NG; ++k)
-            c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, 0, tv + G * k, pv + G * k);
+            c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
         tb = c.t1((int64_t)sc * q.S);   // the sub-chunk's first event: base of the t_norm deltas (same address in every lane)
     };
     // Two schedules of one sub-chunk's phases (SCHED), measured against each other on the GPU (tools/v3_sweep.sh):
@@ -217,7 +141,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 uint32_t local = 0;
-                const int key = nearest_key_cell(xv[G * k + e], yv[G * k + e], g, local);   // (of a stale value beyond the stream)
+                const int key = c.key_of(xyr + C::XYW * k, e, g, local);   // (of stale words beyond the stream)
                 kl[G * k + e] = ((key >= 0) & (e < nv)) ? (((uint32_t)key << V3_LB) | local) : 0xFFFFFFFFu;
                 dropped += ((key < 0) & (e < nv)) ? 1u : 0u;
                 asm volatile("" : "+v"(dropped));   // counted HERE: sunk to the end of the loop body it kept a second copy of every key alive
@@ -266,8 +190,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
         for (int s = 0; s < EPT / 2; ++s) tl[s] = 0;
 #pragma unroll
         for (int s = 0; s < EPT; ++s) {
-            const float tn = (tv[s] - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
-            const uint32_t pb = __float_as_uint(pv[s]);
+            const float tn = (c.t_of(tpr + C::TPW * (s / G), s % G) - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+            const uint32_t pb = __float_as_uint(c.p_of(tpr + C::TPW * (s / G), s % G));
             const uint32_t d = __float_as_uint(tn) - bbits;
             // +1.0 -> 0, -1.0 -> 1, +0.0 -> 2, anything else -> 3 (written so that it stays two selects: a chain of equality
             // tests on one value becomes a switch with divergent branches)
@@ -339,7 +263,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
             else {
                 uint32_t sink = 0;
 #pragma unroll
-                for (int s = 0; s < EPT; ++s) sink += kl[s] ^ __float_as_uint(tv[s]) ^ __float_as_uint(pv[s]), w[s] = sink;
+                for (int s = 0; s < EPT; ++s) sink += kl[s] ^ tpr[s % (NG * C::TPW)], w[s] = sink;
 #pragma unroll
                 for (int s = 0; s < EPT / 2; ++s) tl[s] = sink == 0x12345u ? 0u : 0xFFFFFFFFu;
             }

@@ -1,8 +1,11 @@
 #!/bin/bash
-# voxel tests + stage timings of the default one-pass path (balanced tiles) against the old power-of-two tiling
+# voxel tests + stage timings of the default one-pass path
 mkdir -p gpurun_out; out=gpurun_out/v2_run.txt; : > $out
-timeout 900 python -m pytest tests/test_gpu_tiled.py tests/test_gpu_native.py -x -q -m gpu -k "voxel or native" 2>&1 | tail -15 >> $out
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "f3 or f16 or f15 or c2" 2>&1 | tail -5 >> $out
-EVK_VOXEL_PATH=v2 timeout 300 python tools/v3_sweep.py --scenes --big 2>&1 | grep "^v" | sed 's/^v3/v2 (balanced)/' >> $out
-EVK_VOXEL_PATH=v2 EVK_VOXEL2_TILE=32x16 timeout 300 python tools/v3_sweep.py --scenes 2>&1 | grep "^v" | sed 's/^v3/v2 (32x16)/' >> $out
+timeout 900 python -m pytest tests/test_gpu_tiled.py tests/test_gpu_native.py -x -q -m gpu -k "voxel or native" 2>&1 | tail -4 >> $out
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stress.py -x -q -m gpu -k "f3 or f16 or f15 or c2 or voxel" 2>&1 | tail -4 >> $out
+timeout 300 python tools/v3_sweep.py --scenes --big --native 2>&1 | grep "^v\|^native" | sed 's/^v3/v2/' >> $out
+for g in ${GEOS:-1024x12 1024x16 512x16}; do
+  echo "== EVK_V2_PART=$g" >> $out
+  EVK_LIB_PATH=$PWD/tools/exp/libevk_exp.so EVK_V2_PART=$g timeout 300 python tools/v3_sweep.py --big 2>&1 | grep "^v" | sed 's/^v3/v2/' >> $out
+done
 cat $out

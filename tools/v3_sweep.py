@@ -94,6 +94,21 @@ def timing(n, H, W, B, reps=20, paths=("v3",), kind="uniform"):
             k["kernels_ms"], k["impl"]), flush=True)
 
 
+def native_timing(n, H, W, B, reps=20):
+    """13 B/event (int16 x, y; float64 epoch-second t; uint8 p) against the same events as four float32 columns."""
+    from event_utils_amd.events import DeviceEvents
+    x, y, t, p = synth(1, n, H, W)
+    ev = DeviceEvents.from_native(x.astype(np.int16), y.astype(np.int16), 1.6e9 + t.astype(np.float64), ((p + 1) / 2).astype(np.uint8))
+    nat = ev.native
+    out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    t_first, t_last = ev.t_at(0), ev.t_at(-1)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    f32 = lambda: _voxel_f32_device(*cols, B, (H, W), t_first, t_last, out=out, check=False, impl="tiled", fresh=True)
+    nat_fn = lambda: _voxel_f32_device(None, None, None, None, B, (H, W), t_first, t_last, out=out, check=False, impl="tiled", fresh=True, native=nat)
+    a = tiled._time_ms(f32, reps); b = tiled._time_ms(nat_fn, reps); a2 = tiled._time_ms(f32, reps); b2 = tiled._time_ms(nat_fn, reps)
+    print("native n=%d %dx%dx%d: float32 columns (16 B/ev) %.4f / %.4f ms, on-disk dtypes (13 B/ev) %.4f / %.4f ms" % (n, H, W, B, a, a2, b, b2), flush=True)
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     print("variant: EVK_V3_GEO=%s LIB=%s" % (os.environ.get("EVK_V3_GEO", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
@@ -104,5 +119,9 @@ if __name__ == "__main__":
     if "--scenes" in sys.argv:
         timing(10_000_000, 480, 640, 5, paths=paths, kind="edges")
         timing(10_000_000, 480, 640, 5, paths=paths, kind="blob")
+    if "--native" in sys.argv:
+        native_timing(10_000_000, 480, 640, 5)
     if "--big" in sys.argv:
         timing(50_000_000, 720, 1280, 5, reps=10, paths=paths)
+        if "--native" in sys.argv:
+            native_timing(50_000_000, 720, 1280, 5, reps=10)
