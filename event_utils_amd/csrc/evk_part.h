@@ -62,11 +62,18 @@ struct TileGridG {
     int tw, th, pitch;     // tile size in pixels; accumulator row pitch in cells
     int tiles_x, tiles_y;
     int dom_w, dom_h;      // key domain in pixels
-    uint32_t mx, my, mp;   // ceil(2^32 / tw), ceil(2^32 / th), ceil(2^32 / (tw * th))
+    float ix, iy;          // 1 / tw, 1 / th (float32, rounded): tile of pixel u = floor((u + 0.5) * ix), see tile_of()
+    uint32_t mx, mp;       // ceil(2^32 / tw), ceil(2^32 / (tw * th)): the flush's divisions (a handful per thread)
 };
 __host__ __device__ inline uint32_t magic_div(uint32_t d) { return (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); }
 __device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t m) { return __umulhi(x, m); }   // x / d for x < 2^16
 #define EVK_GRIDG_MAX_CELLS 1024   // pitch * th: the pixel field of a record has 10 bits
+
+// u / d for 0 <= u < 2^16, 4 <= d <= 256 with full-rate instructions (32-bit integer multiplies run at quarter rate, and the
+// key of every event needs two divisions): (u + 0.5) / d is never an integer and lies at least 0.5 / d away from one, while
+// the float32 product (u + 0.5) * RN(1 / d) is off by less than 2^-22 * 2^16 / d = 2^-6 / d -- the floor is exact.
+// (measured against the multiply-high form, same box: partition kernel 58.4 -> 54.8 us at 10 M events)
+__device__ __forceinline__ int tile_of(int u, float inv) { return (int)(((float)u + 0.5f) * inv); }
 
 static inline int make_grid_g(TileGridG &g, int dom_h, int dom_w, int tw, int th) {
     if (dom_h <= 0 || dom_w <= 0 || dom_h > 65535 || dom_w > 65535 || tw < 4 || th < 4 || tw > 256 || th > 256 ||
@@ -76,26 +83,41 @@ static inline int make_grid_g(TileGridG &g, int dom_h, int dom_w, int tw, int th
     g.dom_w = dom_w, g.dom_h = dom_h;
     g.tiles_x = (dom_w + tw - 1) / tw;
     g.tiles_y = (dom_h + th - 1) / th;
-    g.mx = magic_div((uint32_t)tw), g.my = magic_div((uint32_t)th), g.mp = magic_div((uint32_t)(tw * th));
+    g.ix = 1.0f / (float)tw, g.iy = 1.0f / (float)th;
+    g.mx = magic_div((uint32_t)tw), g.mp = magic_div((uint32_t)(tw * th));
     return EVK_OK;
 }
 
 // Nearest-pixel key (EVK_KEY_NEAREST of tile_key): the tile of an event, and the accumulator cell inside the tile.
 // Branch-free: sixteen of these per thread with early returns became thirty-two divergent branches and the register
-// allocator spilled across them.
+// allocator spilled across them.  24-bit multiplies (full rate): every operand is below 2^16.
 __device__ __forceinline__ int nearest_key_cell_int(int xi, int yi, bool finite, const TileGridG &g, uint32_t &cell) {
     xi += xi < 0 ? g.dom_w : 0;     // negative indices wrap once, as index_put_ does
     yi += yi < 0 ? g.dom_h : 0;
     const bool ok = finite & ((uint32_t)xi < (uint32_t)g.dom_w) & ((uint32_t)yi < (uint32_t)g.dom_h);
-    const uint32_t ux = ok ? (uint32_t)xi : 0u, uy = ok ? (uint32_t)yi : 0u;   // (< 2^16: the magic division is exact)
-    const uint32_t tx = div_magic(ux, g.mx), ty = div_magic(uy, g.my);
-    cell = (uy - ty * (uint32_t)g.th) * (uint32_t)g.pitch + (ux - tx * (uint32_t)g.tw);
-    return ok ? (int)(ty * (uint32_t)g.tiles_x + tx) : -1;
+    const int ux = ok ? xi : 0, uy = ok ? yi : 0;
+    const int tx = tile_of(ux, g.ix), ty = tile_of(uy, g.iy);
+    cell = (uint32_t)(__mul24(uy - __mul24(ty, g.th), g.pitch) + (ux - __mul24(tx, g.tw)));
+    return ok ? __mul24(ty, g.tiles_x) + tx : -1;
 }
 __device__ __forceinline__ int nearest_key_cell(float x, float y, const TileGridG &g, uint32_t &cell) {
     // .long() truncation (saturating v_cvt_i32_f32; NaN -> 0, rejected explicitly: torch gives INT64_MIN -> IndexError)
     return nearest_key_cell_int((int)x, (int)y, (x == x) & (y == y), g, cell);
 }
+
+// Normalised time of voxel_grid.py:134, (t - t_first) / dt * (B - 1), in float32 with the reference's operation order and an
+// IEEE division (v_div_scale / v_rcp / fma ... / v_div_fixup): bit-identical to numpy / torch float32 arithmetic
+// (tests/test_gpu_parity.py compares evk_normalise_time_f32 with numpy on 10^8 samples, bit for bit).
+// (Measured alternative: dt is the same for every event, so y = RN(1 / dt) once and q = a * y corrected by two
+// fma(-dt, q, a) / fma(r, y, q) steps -- Markstein's division, the same bits on all 10^8 samples -- is 7 instructions
+// instead of 13, but with the range tests its premises need it ran 2 us SLOWER per 10 M events; tools/ab.sh.)
+struct TimeNorm {
+    float t_first, dt, bm1;
+};
+__host__ __device__ inline TimeNorm make_time_norm(float t_first, float t_last, float bm1) {
+    return TimeNorm{t_first, t_last - t_first, bm1};
+}
+__device__ __forceinline__ float time_norm(float t, const TimeNorm &k) { return (t - k.t_first) / k.dt * k.bm1; }
 
 // ---- column sources of the one-pass partition: G consecutive events per lane -------------------------------------------
 // A load returns RAW 32-bit words; the event's values are decoded where they are USED (x_of ... p_of).  Converting at the

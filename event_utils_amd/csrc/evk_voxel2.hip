@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t dropped = 0, nwide = 0;
     if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
-    const float dt = t_last - t_first;
+    const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
 
     // Group k of sub-chunk sc = G consecutive events of thread tid.  A group that is only partly inside the stream is
     // loaded whole (the over-read stays inside an aligned block; the extra events are ignored); a group entirely outside
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         // normalised time, in place (t has landed during the histogram and the scan), one division at a time
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2) {
-            tv[s2] = (c.t_of(tpr + C::TPW * (s2 / G), s2 % G) - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+            tv[s2] = time_norm(c.t_of(tpr + C::TPW * (s2 / G), s2 % G), tnorm);  // voxel_grid.py:134, bit-identical (evk_part.h)
             __builtin_amdgcn_sched_barrier(0);
         }
         // Nothing outstanding from here (t, p are in; the previous sub-chunk's stores are a histogram and a scan old) -- said
@@ -890,6 +890,21 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         V2_TILES(512, 2);
 #undef V2_TILES
     }
+    return launch_status();
+}
+
+// t_norm of voxel_grid.py:134 exactly as the partition kernel computes it (time_norm, evk_part.h) -- the parity hook of
+// its division shortcut, and the events' normalised time stamps for callers that want them
+__global__ void k_normalise_time(const float *__restrict__ t, int64_t n, float t_first, float t_last, float bm1,
+                                 float *__restrict__ out) {
+    const TimeNorm k = make_time_norm(t_first, t_last, bm1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = time_norm(t[i], k);
+}
+extern "C" int evk_normalise_time_f32(const float *t, int64_t n, float t_first, float t_last, int B, float *out, void *stream) {
+    if (n < 0 || B <= 0 || (n > 0 && (!t || !out))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_normalise_time<<<stream_grid(n), EVK_BLOCK, 0, (hipStream_t)stream>>>(t, n, t_first, t_last, (float)(B - 1), out);
     return launch_status();
 }
 

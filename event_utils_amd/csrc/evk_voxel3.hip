@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
     for (int k = 0; k < PER_MAX; ++k) mytot[k] = 0;
     uint32_t dropped = 0, nesc = 0;
     if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
-    const float dt = t_last - t_first;
+    const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
 
     // Group k of sub-chunk sc = G consecutive events of thread tid.  A group that is only partly inside the stream is
     // loaded whole (the over-read stays inside an aligned block; the extra events are ignored); a group entirely outside
@@ -185,12 +185,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part3(const C c, int64_t n, Tile
         }
     };
     auto do_compress = [&](int64_t slot0) {   // (key, t, p) -> record word + 16-bit tile
-        bbits = __float_as_uint((tb - t_first) / dt * bm1);
+        bbits = __float_as_uint(time_norm(tb, tnorm));
 #pragma unroll
         for (int s = 0; s < EPT / 2; ++s) tl[s] = 0;
 #pragma unroll
         for (int s = 0; s < EPT; ++s) {
-            const float tn = (c.t_of(tpr + C::TPW * (s / G), s % G) - t_first) / dt * bm1;  // voxel_grid.py:134 (float32, IEEE divide)
+            const float tn = time_norm(c.t_of(tpr + C::TPW * (s / G), s % G), tnorm);  // voxel_grid.py:134, bit-identical
             const uint32_t pb = __float_as_uint(c.p_of(tpr + C::TPW * (s / G), s % G));
             const uint32_t d = __float_as_uint(tn) - bbits;
             // +1.0 -> 0, -1.0 -> 1, +0.0 -> 2, anything else -> 3 (written so that it stays two selects: a chain of equality

@@ -344,6 +344,9 @@ int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *
                    int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                    uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                    uint32_t seq, void *stream);
+/* out[i] = (t[i] - t_first) / (t_last - t_first) * (B - 1) in float32: the normalised time of voxel_grid.py:134, by the very
+ * function the partition kernel calls -- bit-identical to numpy's float32 arithmetic; the tests compare it bit for bit. */
+int evk_normalise_time_f32(const float *t, int64_t n, float t_first, float t_last, int B, float *out, void *stream);
 /* the same from the reference's on-disk dtypes (see evk_bucket_events_native_f32) */
 int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind, double t_offset,
                           const void *p, int p_kind, int64_t n, int h, int wd, int tile_w, int tile_h, float t_first,

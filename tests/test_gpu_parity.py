@@ -224,6 +224,37 @@ def test_interpolate_primitives(E):
                                torch.tensor([1.]), torch.zeros(H, W))
 
 
+def test_normalised_time_is_bit_identical_to_float32_division():
+    """voxel_grid.py:134, t_norm = (ts - ts[0]) / dt * (B - 1) in float32: evk_normalise_time_f32 runs the very function the
+    partition kernel calls for every event (evk_part.h, time_norm).  10^8 samples over 40 (ts[0], dt) pairs -- ordinary streams,
+    tiny and huge dt, negative dt (unsorted ends), dt == 0, time stamps outside [ts[0], ts[-1]], subnormal quotients,
+    infinities and NaN -- against numpy's float32 arithmetic, bit for bit."""
+    from event_utils_amd import _lib, _device as D
+    rng = np.random.default_rng(11)
+    pairs = [(0.0, 0.1), (0.0, 1.0), (1.6e9, 1.6e9 + 64.0), (3.25, 3.25 + 2.0 ** -20), (0.0, 3e38), (0.0, 1e-38), (5.0, 5.0),
+             (1.0, -1.0), (-7.5, 12.25), (0.0, 2.0 ** -126), (0.0, float(np.float32(1) / np.float32(3)))]
+    while len(pairs) < 40:
+        a = float(rng.uniform(-10, 10)); pairs.append((a, a + float(10.0 ** rng.uniform(-6, 6))))
+    n = 2_500_000
+    bad = 0
+    for k, (t0, t1) in enumerate(pairs):
+        t0, t1 = np.float32(t0), np.float32(t1)
+        t = (t0 + (t1 - t0) * rng.random(n).astype(np.float32)).astype(np.float32)
+        t[::97] = (t0 + (t1 - t0) * np.float32(3.0) * rng.standard_normal(len(t[::97])).astype(np.float32))   # outside the range
+        t[1::1009] = t0; t[2::1009] = t1
+        t[3::5003] = t0 + np.float32(1e-45) * rng.integers(0, 50, len(t[3::5003])).astype(np.float32)            # tiny numerators
+        t[5:9] = [np.inf, -np.inf, np.nan, 0.0]
+        for B in (5, 2, 1, 16)[: 1 + (k % 4)]:
+            with np.errstate(all="ignore"):
+                ref = (t - t0) / (t1 - t0) * np.float32(B - 1)
+            td = torch.from_numpy(t).cuda(); out = torch.empty_like(td)
+            _lib.call("evk_normalise_time_f32", D.ptr(td), n, float(t0), float(t1), B, D.ptr(out), D.stream())
+            got = out.cpu().numpy()
+            same = (got.view(np.uint32) == ref.astype(np.float32).view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            bad += int(np.count_nonzero(~same))
+    assert bad == 0, "%d of 10^8 normalised time stamps differ from the float32 division" % bad
+
+
 # ------------------------------------------------------------------------------------------------ F5 warp
 def test_f5_warp_bit_exact(E, golden):
     g = golden("f5_warp")
