@@ -105,10 +105,32 @@ class _ErrorState:
         self.slot = 0
         self.pending = deque()
 
+    def _advance(self, value):
+        """Events dropped since the last report, given a snapshot `value` of the cumulative counter.  A snapshot OLDER than
+        what was already reported (a deferred entry polled after a later strict call) counts as 0: `seen` never moves
+        backwards, so nothing is reported twice and no wrapped difference masquerades as ~4e9 events."""
+        n = (value - self.seen) & 0xFFFFFFFF
+        if n >= 0x80000000:
+            return 0
+        self.seen = value & 0xFFFFFFFF
+        return n
+
     def _raise(self, value, exc_type, msg):
-        n, self.seen = (value - self.seen) & 0xFFFFFFFF, value
+        n = self._advance(value)
         if n:
             raise exc_type("%s (%d offending events)" % (msg, n))
+
+    def drain(self):
+        """Wait for every pending deferred report and fold it into `seen` WITHOUT raising -> events they dropped.  For callers
+        that must not raise on one rank alone (distributed.py: the count is summed over the ranks and all raise)."""
+        if not self.pending:
+            return 0
+        torch.cuda.synchronize()
+        n = 0
+        while self.pending:
+            ev, k, _, _ = self.pending.popleft()
+            n += self._advance((int(self.report_np[1]) if ev is None else int(self.host[k])) & 0xFFFFFFFF)
+        return n
 
     def poll(self, wait=False):
         while self.pending:
@@ -168,12 +190,32 @@ def check_errors():
         st.poll(wait=True)
 
 
+def _report_at_exit():
+    """A deferred report that nobody collected (no later event_utils_amd call, no check_errors()) must not vanish with the
+    process: say so on stderr.  (An exception cannot propagate out of an atexit hook.)"""
+    import sys
+    try:
+        if not torch.cuda.is_available():
+            return
+        check_errors()
+    except (IndexError, ValueError) as e:
+        sys.stderr.write("event_utils_amd: an earlier call dropped out-of-range events and the error was never collected "
+                         "(EVK_ERRORS=deferred; call check_errors() or set EVK_ERRORS=strict): %s\n" % (e,))
+    except Exception:   # noqa: BLE001  (interpreter shutdown: the device may already be gone)
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_report_at_exit)
+
+
 class OobCounter:
     """Device counter of events the reference would have rejected with an exception (see error_mode)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, poll=True):
         self.state = _error_state(device or require_gpu())
-        self.state.poll()                      # surface what earlier deferred calls on this stream left behind
+        if poll:                               # surface what earlier deferred calls on this stream left behind
+            self.state.poll()                  # (poll=False: sharded callers, which must raise on every rank together)
         self.seq = None                        # set by a call whose kernels report {seq, counter} to the host themselves
 
     def report_args(self):

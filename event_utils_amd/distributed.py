@@ -55,7 +55,7 @@ def collective():
 def evk_comm(group=None):
     """libevk communicator of `group` (created on first use: rank 0 makes the id, it is broadcast, every rank joins)."""
     from . import _lib
-    key = id(group) if group is not None else 0
+    key = group if group is not None else 0      # the group OBJECT: keeps it alive, so its identity cannot be recycled
     c = _comms.get(key)
     if c is None:
         dist = _dist()
@@ -80,7 +80,7 @@ def evk_comm(group=None):
 
 def evk_comm_destroy(group=None):
     from . import _lib
-    c = _comms.pop(id(group) if group is not None else 0, None)
+    c = _comms.pop(group if group is not None else 0, None)
     if c is not None:
         _lib.call("evk_comm_destroy", c)
 
@@ -98,11 +98,49 @@ def global_time_range(t_first_local, t_last_local, group=None, device=None):
     return -float(lo), float(hi)
 
 
-def all_reduce_sum_(grid, group=None, force=False):
-    """In-place SUM all-reduce of an output grid (no-op for a single process unless force=True)."""
+def voxel_collective():
+    """How the voxel grid is summed over the ranks: 'allreduce' (default: one RCCL all-reduce, the library picks ring / tree)
+    or 'rsag' (EVK_VOXEL_COLLECTIVE=rsag): an explicit reduce-scatter followed by an all-gather -- the all-links form of
+    SURVEY.md section 5 for the 18.4 MB grid of configs[4]: every rank reduces 1/N of the grid and all 7 xGMI links of a
+    GPU carry traffic in both phases.  bench.py --gpus N reports both."""
+    return os.environ.get("EVK_VOXEL_COLLECTIVE", "allreduce")
+
+
+def reduce_scatter_all_gather_sum_(grid, group=None):
+    """In-place SUM of `grid` over the ranks as reduce-scatter + all-gather (the grid is viewed flat and cut into
+    world_size equal chunks; a tail that does not divide is handled by a small all-reduce)."""
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    flat = grid.view(-1)
+    chunk = flat.numel() // world
+    if chunk:
+        body = flat[: chunk * world]
+        mine = torch.empty(chunk, dtype=flat.dtype, device=flat.device)
+        if dist.get_backend(group) == "nccl":
+            dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=group)
+            dist.all_gather_into_tensor(body, mine, group=group)
+        else:   # gloo (CPU tests) has no reduce-scatter: one reduce per destination rank is the same exchange
+            for j in range(world):
+                part = body[j * chunk:(j + 1) * chunk].clone()
+                dist.reduce(part, dst=dist.get_global_rank(group, j) if group is not None else j, op=dist.ReduceOp.SUM, group=group)
+                if j == rank:
+                    mine.copy_(part)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            body.copy_(torch.cat(parts))
+    if chunk * world < flat.numel():
+        dist.all_reduce(flat[chunk * world:], op=dist.ReduceOp.SUM, group=group)
+    return grid
+
+
+def all_reduce_sum_(grid, group=None, force=False, form=None):
+    """In-place SUM all-reduce of an output grid (no-op for a single process unless force=True).  form='rsag': as an explicit
+    reduce-scatter + all-gather (voxel_collective())."""
     dist = _dist()
     if not (dist.is_available() and dist.is_initialized()) or not (force or is_distributed(group)):
         return grid
+    if form == "rsag" and grid.is_contiguous():
+        return reduce_scatter_all_gather_sum_(grid, group)
     if collective() == "evk" and grid.is_cuda and grid.is_contiguous() and grid.dtype in (torch.float32, torch.int32):
         from . import _device as D
         from . import _lib
@@ -116,9 +154,10 @@ def all_reduce_sum_(grid, group=None, force=False):
 def _raise_everywhere(oob_state, exc_type, msg, group):
     """A data-dependent error must surface on EVERY rank (a rank that raised alone would leave the others waiting in the
     next collective): the per-rank counts of dropped events are summed over the ranks and all of them raise."""
-    cnt = (oob_state.counter.to(torch.int64) - oob_state.seen).reshape(1)
-    local = int(cnt.item())
-    oob_state.seen = (oob_state.seen + local) & 0xFFFFFFFF
+    # (earlier DEFERRED reports of this stream are folded in here, quietly: polling them in OobCounter's constructor could
+    # raise on this rank alone, between two collectives, and leave the other ranks waiting in the all-reduce)
+    local = oob_state.drain() + oob_state._advance(int(oob_state.counter.item()) & 0xFFFFFFFF)
+    cnt = torch.tensor([local], dtype=torch.int64, device=oob_state.counter.device)
     total = cnt.to(_collective_device(group)) if is_distributed(group) else cnt
     if is_distributed(group):
         _dist().all_reduce(total, op=_dist().ReduceOp.SUM, group=group)
@@ -150,11 +189,11 @@ def events_to_voxel_torch_sharded(xs, ys, ts, ps, B, sensor_size=(180, 240), gro
     t1 = float(ts[-1]) if n else -inf
     t_first, t_last = global_time_range(t0, t1, group)
     if local_fn is not None:
-        return all_reduce_sum_(local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last), group)
+        return all_reduce_sum_(local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last), group, form=voxel_collective())
     from . import _device as D
-    oob = D.OobCounter(D.require_gpu())
+    oob = D.OobCounter(D.require_gpu(), poll=False)
     part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
-    out = all_reduce_sum_(part, group)
+    out = all_reduce_sum_(part, group, form=voxel_collective())
     _raise_everywhere(oob.state, IndexError, "index out of range for voxel grid of size %s"
                       % ((B, int(sensor_size[0]), int(sensor_size[1])),), group)
     return out
@@ -180,7 +219,7 @@ def events_to_image_sharded(xs, ys, ps, sensor_size=(180, 240), group=None, loca
         from . import _lib
         dev = D.require_gpu()
         canvas = torch.zeros(shape, dtype=torch.int32, device=dev)
-        oob = D.OobCounter(dev)
+        oob = D.OobCounter(dev, poll=False)
         if xs.shape[0]:
             xd, yd, wd = (D.to_device(a, torch.int32) for a in (xs, ys, ps))
             _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd), xs.shape[0], shape[0], shape[1],

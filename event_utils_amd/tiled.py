@@ -308,7 +308,12 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
                    out, oob, fresh)
             return out
     if t_first is None:          # the other kernels take ts[0] / ts[-1] as host scalars
-        t_first, t_last = D.ends(td) if native is None else (None, None)
+        if native is None:
+            t_first, t_last = D.ends(td)
+        else:                    # the loaders' (ts - ts_0).float(): subtraction in float64, then float32
+            import numpy as np
+            a, b = D.ends(native.t)
+            t_first, t_last = float(np.float32(a - native.t_offset)), float(np.float32(b - native.t_offset))
     if tileable and B * 8 * 64 <= 65536:
         tw, th = voxel_tile_shape(H, W, B)
         if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:     # sensors beyond 8192 tiles: enlarge the tiles
@@ -445,14 +450,29 @@ _spill = {}
 
 def _spill_pair(device, planes, ch, cw):
     """The pair of spill images of the fused evaluation (include/evk.h, evk_cmax_variance_tiled_f32): zeroed once, kept
-    per stream and image shape, with the parity that alternates from call to call -> (tensor, parity for THIS call)."""
+    per stream and image shape -> [tensor, parity of the LAST successful call].  A call uses parity ^ 1 and commits it
+    through _spill_call only when it has been enqueued."""
     import torch
     key = (device.index, D.stream_id(device), planes, ch, cw)
     st = _spill.get(key)
     if st is None:
         st = _spill[key] = [torch.zeros(2 * planes * ch * cw, dtype=torch.float32, device=device), 0]
-    st[1] ^= 1
-    return st[0], st[1]
+    return st
+
+
+def _spill_call(st, call):
+    """Run one fused evaluation and toggle the spill parity only once it has been enqueued.  If the call fails (launch
+    error, argument error, KeyboardInterrupt) the gather that zeroes the other image never ran: both images are zeroed
+    and the parity reset, so that no stale out-of-window contributions leak into the next evaluation."""
+    try:
+        call()
+    except BaseException:
+        if st is not None:
+            st[0].zero_()
+            st[1] = 0
+        raise
+    if st is not None:
+        st[1] ^= 1
 
 
 def spill_enabled():
@@ -482,27 +502,27 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
             args[12], args[13] = vx, vy
             st = c["spill"]
             if st is not None:
-                st[1] ^= 1
-                args[c["i_parity"]] = st[1]
+                args[c["i_parity"]] = st[1] ^ 1
             args[-1] = D.stream()
-            _lib.check(c["fn"](*args), "evk_cmax_variance_tiled_f32")
+            _spill_call(st, lambda: _lib.check(c["fn"](*args), "evk_cmax_variance_tiled_f32"))
             return True
     plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
     if plan is None:
         return False
     planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
-    spill, parity = _spill_pair(buf.device, planes, ch, cw) if spill_enabled() else (None, 0)
+    sp_state = _spill_pair(buf.device, planes, ch, cw) if spill_enabled() else None
+    spill, parity = (sp_state[0], sp_state[1] ^ 1) if sp_state is not None else (None, 0)
     args = list(plan["head"]) + [D.host_ptr(weights) if weights is not None else None, radius, post_flags,
                                  D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
                                  scratch_bytes, D.ptr(spill), parity,
                                  D.host_ptr(host_out) if host_out is not None else None, D.stream()]
     fn = getattr(_lib.lib(), "evk_cmax_variance_tiled_f32")
-    _lib.check(fn(*args), "evk_cmax_variance_tiled_f32")
+    _spill_call(sp_state, lambda: _lib.check(fn(*args), "evk_cmax_variance_tiled_f32"))
     head = plan["head"]
     cache[ckey] = {"fn": fn, "args": args, "buf": buf, "out": out, "scratch": scratch, "weights": weights,
                    "host_out": host_out, "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
                    "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6], planes),
-                   "spill": _spill.get((buf.device.index, D.stream_id(buf.device), planes, ch, cw)) if spill is not None else None,
+                   "spill": sp_state,
                    "i_parity": len(args) - 3, "keep": (plan, spill)}
     return True
 
@@ -514,10 +534,12 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
         return False
-    spill, parity = _spill_pair(buf.device, 3, ch, cw) if spill_enabled() else (None, 0)
-    _lib.call("evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None,
-              radius, D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch),
-              scratch_bytes, D.ptr(spill), parity, D.host_ptr(host_out) if host_out is not None else None, D.stream())
+    st = _spill_pair(buf.device, 3, ch, cw) if spill_enabled() else None
+    spill, parity = (st[0], st[1] ^ 1) if st is not None else (None, 0)
+    _spill_call(st, lambda: _lib.call(
+        "evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
+        D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch), scratch_bytes, D.ptr(spill),
+        parity, D.host_ptr(host_out) if host_out is not None else None, D.stream()))
     return True
 
 

@@ -45,6 +45,16 @@ def _worker(rank, world, port, n, out_dir):
     vox = DD.events_to_voxel_torch_sharded(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi], B, (H, W), local_fn=_oracle_local)
     ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
     err = np.abs(vox.numpy().astype(np.float64) - ref).max()
+    # the same grid through the all-links form of the exchange (EVK_VOXEL_COLLECTIVE=rsag: reduce-scatter + all-gather;
+    # 5 * 24 * 32 = 3840 cells divide by 2, the (7,) buffer below exercises the tail that does not)
+    os.environ["EVK_VOXEL_COLLECTIVE"] = "rsag"
+    assert DD.voxel_collective() == "rsag"
+    vox2 = DD.events_to_voxel_torch_sharded(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi], B, (H, W), local_fn=_oracle_local)
+    os.environ.pop("EVK_VOXEL_COLLECTIVE")
+    err = max(err, np.abs(vox2.numpy().astype(np.float64) - ref).max())
+    odd = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    DD.reduce_scatter_all_gather_sum_(odd)
+    assert torch.equal(odd, torch.arange(7, dtype=torch.float32) * sum(range(1, world + 1)))
     # objective: every rank warps to the GLOBAL t_ref and all-reduces IWE+dIWE (here with the oracle as local kernel)
     obj = R.variance_objective()
     iwe_full, d_full = R.get_iwe(np.array([30., -20.]), *(a.astype(np.float64) for a in (x, y, t, p)), R.linvel_warp(),
