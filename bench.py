@@ -217,6 +217,38 @@ def main():
     if use_dist:
         result["rccl_ranks"] = dist.get_world_size()
         result.update(check_sharded(dist, dev, out if not overlap else outs[(args.steps - 1) % 2], pd, n, world))
+        # ---- what the step is made of, so that a 1 -> N curve can be read without re-running: the kernels alone, the grid
+        #      collective alone (same buffer shape, both forms), the two back to back, and the N = 1 entry point on this rank
+        from event_utils_amd import distributed as DD
+        zgrid = torch.zeros((B, H, W), dtype=torch.float32, device=dev)     # zeros stay zeros under repeated sums
+
+        def compute_only(i):
+            _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=outs[0], check=False, impl=impl, fresh=True)
+
+        def allreduce_only(i):
+            dist.all_reduce(zgrid, op=dist.ReduceOp.SUM)
+
+        def rsag_only(i):
+            DD.reduce_scatter_all_gather_sum_(zgrid)
+
+        def serial(i):
+            compute_only(i)
+            dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
+
+        def serial_rsag(i):
+            compute_only(i)
+            DD.reduce_scatter_all_gather_sum_(outs[0])
+        ms = lambda fn: round(timed(fn, args.steps, args.warmup) / args.steps * 1e3, 4)   # noqa: E731
+        result["breakdown"] = {
+            "overlap_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only), "allreduce_ms": ms(allreduce_only),
+            "reduce_scatter_all_gather_ms": ms(rsag_only), "serial_ms": ms(serial), "serial_rsag_ms": ms(serial_rsag),
+            "n1_equivalent_ms": ms(step_public), "grid_bytes": int(zgrid.numel() * 4),
+            "note": "max over ranks, barrier + synchronize on both sides like ms_per_step.  overlap_ms = the headline step "
+                    "(all-reduce of step i overlapped with the kernels of step i+1); compute_ms = this rank's kernels with "
+                    "no collective (internal entry, resident grid); allreduce_ms / reduce_scatter_all_gather_ms = the grid "
+                    "exchange alone; serial_* = kernels then exchange, not overlapped; n1_equivalent_ms = the public "
+                    "events_to_voxel_torch call BENCH's N = 1 `value` times, here on every rank at once without a "
+                    "collective (it allocates the grid and reads ts[0]/ts[-1] on the device: ~1 % above compute_ms)"}
     else:
         # the same work through the internal entry point (resident output, host-supplied ts[0]/ts[-1], no out-of-range
         # check) and through the public call with per-call synchronous error reporting
@@ -241,6 +273,11 @@ def main():
             result["c5_share"] = {"error": repr(e)}
         result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
                                                max(5, args.steps))
+        for key, fn in (("voxel_structured", bench_structured), ("image_c1", bench_image_c1)):
+            try:
+                result[key] = fn(E, tiled, dev, impl)
+            except Exception as e:  # noqa: BLE001
+                result[key] = {"error": repr(e)}
     if rank == 0 and world == 1 and not use_dist and not args.no_cmax:
         result["cmax"] = bench_cmax(E, DeviceEvents, dev, impl)
     if rank == 0 and world == 1 and not use_dist and not args.no_cpu:
@@ -345,22 +382,92 @@ def bench_native(DeviceEvents, voxel, x, y, t, p, B, H, W, impl, reps):
     return res
 
 
+def bench_structured(E, tiled, dev, impl):
+    """The headline call on scenes that are not uniform noise (real event data is edges and blobs): the moving-edge scene
+    of configs[3] at 10 M events / 640x480 and 50 M / 1280x720, and a blob holding half of the events in 100x100 pixels.
+    A launch of the tile kernel lasts as long as its busiest CU; hot tiles are cut into pieces (evk_voxel2.hip)."""
+    res = {"note": "events_to_voxel_torch, 5 bins, kernels of one call; ratio = total_ms / the uniform-random call of the same size"}
+    for (Hs, Ws, ns, reps) in ((H, W, N_PER_GPU, 10), (720, 1280, 50_000_000, 5)):
+        tag = "%dx%d_%dM" % (Ws, Hs, ns // 1_000_000)
+        base = None
+        for scene in ("uniform", "moving_edges", "hot_blob"):
+            if scene == "hot_blob" and ns > N_PER_GPU:
+                continue
+            rng = np.random.default_rng(2)
+            if scene == "moving_edges":
+                xs, ys, ts, ps = structured_scene(3, ns, Hs, Ws)
+                xs, ys = np.floor(xs), np.floor(ys)
+            else:
+                xs = rng.integers(0, Ws, ns).astype(np.float32)
+                ys = rng.integers(0, Hs, ns).astype(np.float32)
+                if scene == "hot_blob":
+                    hot = rng.random(ns) < 0.5
+                    xs[hot] = (Ws // 3 + rng.integers(0, 100, int(hot.sum()))).astype(np.float32)
+                    ys[hot] = (Hs // 3 + rng.integers(0, 100, int(hot.sum()))).astype(np.float32)
+                ts = np.sort(rng.uniform(0.0, 0.1, ns)).astype(np.float32)
+                ps = (rng.integers(0, 2, ns) * 2 - 1).astype(np.float32)
+            cols = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (xs, ys, ts, ps)]
+            k = tiled.time_voxel_kernels(*cols, float(ts[0]), float(ts[-1]), B, Hs, Ws, impl=impl, reps=reps)
+            base = k["total_ms"] if scene == "uniform" else base
+            res["%s_%s" % (tag, scene)] = {"total_ms": round(k["total_ms"], 4), "kernels_ms": k["kernels_ms"],
+                                          "Mevents_per_s": round(ns / k["total_ms"] / 1e3, 1),
+                                          "ratio_to_uniform": round(k["total_ms"] / base, 3)}
+            del cols
+        torch.cuda.empty_cache()
+    return res
+
+
+def bench_image_c1(E, tiled, dev, impl):
+    """configs[0]: 1 M events, 240x180, events_to_image (nearest pixel, integer count) -- the plumbing / bit-exactness
+    configuration (12 B/event at int32).  (a) the kernel on device-resident int32 columns, against the
+    12 B/event HBM roofline; (b) the public numpy-in / numpy-out call (host arrays: PCIe both ways, never a roofline figure)."""
+    from event_utils_amd import _lib, _device as D
+    n1, H1, W1 = 1_000_000, 180, 240
+    rng = np.random.default_rng(0)
+    xi = rng.integers(0, W1, n1).astype(np.int64)
+    yi = rng.integers(0, H1, n1).astype(np.int64)
+    pi = (rng.integers(0, 2, n1) * 2 - 1).astype(np.int64)
+    xd, yd, pd = (torch.from_numpy(a.astype(np.int32)).to(dev) for a in (xi, yi, pi))
+    canvas = torch.zeros((H1 + 1, W1 + 1), dtype=torch.int32, device=dev)
+    oob = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def kernel():
+        _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n1, H1 + 1, W1 + 1, D.ptr(canvas), D.ptr(oob),
+                  D.stream())
+    k_ms = tiled._time_ms(kernel, 50)
+    E.events_to_image(xi, yi, pi, sensor_size=(H1, W1))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        img = E.events_to_image(xi, yi, pi, sensor_size=(H1, W1))
+    pub_ms = (time.perf_counter() - t0) / 5 * 1e3
+    alg = 12.0 * n1 + (H1 + 1) * (W1 + 1) * 4.0
+    return {"workload": "configs[0]: 1M events, 240x180, events_to_image nearest (int32 accumulate, bit-exact)",
+            "kernel": "k_image_nearest_int (one global int32 atomic per event)", "kernel_ms": round(k_ms, 4),
+            "Mevents_per_s": round(n1 / k_ms / 1e3, 1), "algorithmic_bytes": alg,
+            "roofline_frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "bound": "global atomics (~21 G/s on this chip, profiles/r01_direct_atomics_probe.json): 1 M atomics = 48 us; "
+                     "1 M events are below the crossover where bucketing pays",
+            "public_numpy_call_ms": round(pub_ms, 3), "public_numpy_call_note": "host int64 arrays in, float64 image out",
+            "checksum_ok": bool(int(img.sum()) == int(pi.sum()))}
+
+
 def pmc_traffic(kernel, tag):
     """HBM bytes per launch of `kernel` (and of the whole call) from the committed rocprofv3 PMC passes
     (profiles/r02_pmc_traffic.json: separate --pmc passes for reads and writes of this same workload, gfx950 corrections
     applied as MI355X_MICROARCH.md prescribes; tools/profile_round.sh).  PMC counters cannot be collected from inside the
     timed process, so this is the recorded measurement of the workload `tag`; None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.isfile(path):
-        return None, None, None
-    try:
-        prof = json.load(open(path)).get(tag, {})
-        for name, v in prof.get("kernels", {}).items():
-            if kernel.split("(")[0] in name:
-                return (v["hbm_bytes_per_launch_corrected"], "profiles/r02_pmc_traffic.json[%s] (rocprofv3 --pmc, per launch)" % tag,
-                        prof.get("whole_call_bytes"))
-    except Exception:
-        pass
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)
+        if not os.path.isfile(path):
+            continue
+        try:
+            prof = json.load(open(path)).get(tag, {})
+            for name, v in prof.get("kernels", {}).items():
+                if kernel.split("(")[0] in name:
+                    return (v["hbm_bytes_per_launch_corrected"],
+                            "profiles/%s_pmc_traffic.json[%s] (rocprofv3 --pmc, per launch)" % (rnd, tag), prof.get("whole_call_bytes"))
+        except Exception:
+            pass
     return None, None, None
 
 
@@ -380,6 +487,22 @@ def _time_evals(obj, w, ev, prm, size, reps=10):
         res[name + "_ms"] = round(dt * 1e3, 4)
         res[name + "_Mevents_per_s"] = round(n / dt / 1e6, 1)
         res[name + "_hbm_frac"] = round((16.0 * n) / dt / 1e9 / HBM_PEAK_GBS, 4)
+        # device time of one evaluation: the same calls enqueued back to back without reading the scalars back (the host
+        # then never waits), between ONE pair of HIP events -- the difference to *_ms is the host's share (first-launch
+        # latency out of an idle queue, the poll of the pinned result, Python)
+        obj.enqueue_only = True
+        try:
+            fn(prm, ev, None, None, None, w, size, 1.0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4 * reps):
+                fn(prm, ev, None, None, None, w, size, 1.0)
+            e1.record()
+            torch.cuda.synchronize()
+            res[name + "_device_ms"] = round(e0.elapsed_time(e1) / (4 * reps), 4)
+        finally:
+            obj.enqueue_only = False
     return res
 
 
@@ -532,8 +655,29 @@ def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
         return run
     f_eval = lambda: obj.evaluate_function(prm, ev, None, None, None, w, (H5, W5), 1.0)      # noqa: E731
     g_eval = lambda: obj.evaluate_gradient(prm, ev, None, None, None, w, (H5, W5), 1.0)      # noqa: E731
+    # the parts of each line: this rank's kernels alone (same global reference time, no collective) and the collective
+    # alone (a zero buffer of the exchanged shape), so that a loss of linearity can be attributed to one of them
+    from event_utils_amd import distributed as DD
+    lobj = E.variance_objective()
+    lobj.sensor_size, lobj.impl, lobj.t_ref = (H5, W5), impl, t_last
+    zg = torch.zeros((B5, H5, W5), dtype=torch.float32, device=dev)
+    z1 = torch.zeros((1, H5 + 1, W5 + 1), dtype=torch.float32, device=dev)
+    z3 = torch.zeros((3, H5 + 1, W5 + 1), dtype=torch.float32, device=dev)
+
+    def voxel_rsag():
+        _voxel_f32_device(xi, yi, ev.t, ev.p, B5, (H5, W5), t_first, t_last, out=grid, check=False, impl=impl, fresh=True)
+        DD.reduce_scatter_all_gather_sum_(grid)
+    parts = (("voxel_rsag", voxel_rsag, 10),
+             ("voxel_compute", lambda: _voxel_f32_device(xi, yi, ev.t, ev.p, B5, (H5, W5), t_first, t_last, out=grid,
+                                                         check=False, impl=impl, fresh=True), 10),
+             ("voxel_allreduce", lambda: dist.all_reduce(zg, op=dist.ReduceOp.SUM), 10),
+             ("voxel_reduce_scatter_all_gather", lambda: DD.reduce_scatter_all_gather_sum_(zg), 10),
+             ("f_compute", lambda: lobj.evaluate_function(prm, ev, None, None, None, w, (H5, W5), 1.0), 10),
+             ("f_allreduce", lambda: dist.all_reduce(z1, op=dist.ReduceOp.SUM), 10),
+             ("grad_compute", lambda: lobj.evaluate_gradient(prm, ev, None, None, None, w, (H5, W5), 1.0), 10),
+             ("grad_allreduce", lambda: dist.all_reduce(z3, op=dist.ReduceOp.SUM), 10))
     for name, fn, reps in (("voxel", voxel, 10), ("f", f_eval, 10), ("grad", g_eval, 10),
-                           ("f_rows_post", rows(f_eval), 10), ("grad_rows_post", rows(g_eval), 10)):
+                           ("f_rows_post", rows(f_eval), 10), ("grad_rows_post", rows(g_eval), 10)) + parts:
         for _ in range(2):
             fn()
         dist.barrier()
@@ -547,9 +691,14 @@ def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dt = float(dt.item())
         res[name + "_ms"] = round(dt * 1e3, 4)
-        res[name + "_Mevents_per_s"] = round(n5 * world / dt / 1e6, 1)
-        if name != "voxel":
+        if name in ("voxel", "f", "grad", "f_rows_post", "grad_rows_post", "voxel_rsag"):
+            res[name + "_Mevents_per_s"] = round(n5 * world / dt / 1e6, 1)
+        if name in ("f", "grad", "f_rows_post", "grad_rows_post"):
             res[name + "_evals_per_s"] = round(1.0 / dt, 2)
+    res["parts"] = ("*_compute_ms: this rank's kernels alone (replicated post-pass included for f / grad, which then also "
+                    "return their scalars to the host); *_allreduce_ms / voxel_reduce_scatter_all_gather_ms: the collective "
+                    "alone on a zero buffer of the exchanged shape (grid %d B, IWE %d B, IWE+dIWE %d B); voxel_rsag = the "
+                    "voxel line with EVK_VOXEL_COLLECTIVE=rsag" % (zg.numel() * 4, z1.numel() * 4, z3.numel() * 4))
     return res
 
 
