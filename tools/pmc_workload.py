@@ -2,7 +2,7 @@
     python tools/pmc_workload.py c2        10 M events, 640x480x5   (configs[1], the headline)
     python tools/pmc_workload.py c5_share  50 M events, 1280x720x5  (one rank's share of configs[4])
 Runs the internal entry point (resident grid, no per-call checks) 8 times so that the counters see exactly the kernels
-of the call: k_part_sorted and k_voxel_tiles2."""
+of the call: k_part_sorted and k_voxel_tiles2 (evk_voxel2.hip)."""
 import os
 import sys
 

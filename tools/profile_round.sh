@@ -5,7 +5,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 timeout -s KILL 500 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
