@@ -89,6 +89,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t *tmp
     return tmp[32 + wave] + incl - mine;   // the caller puts a barrier before tmp is used again
 }
 
+// -DV2_PHASE_TIMING (experiments builds): every wave adds the shader cycles (s_memtime) it spends in each phase of a
+// sub-chunk pass to v2_phase_cycles[]; evk_debug_phase_cycles() reads and clears them (tools/phase_timing.py)
+#ifdef V2_PHASE_TIMING
+__device__ unsigned long long v2_phase_cycles[16];
+#define V2_T0()                                            \
+    unsigned long long pt_ = __builtin_readcyclecounter(); \
+    unsigned long long pa_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define V2_T(i)                                                     \
+    do {                                                            \
+        const unsigned long long n_ = __builtin_readcyclecounter(); \
+        pa_[i] += n_ - pt_;                                         \
+        pt_ = n_;                                                   \
+    } while (0)
+#define V2_TEND()                                                                   \
+    do {                                                                            \
+        if ((threadIdx.x & 63) == 0)                                                \
+            for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&v2_phase_cycles[i_], pa_[i_]); \
+    } while (0)
+#else
+#define V2_T0() do {} while (0)
+#define V2_T(i) do {} while (0)
+#define V2_TEND() do {} while (0)
+#endif
+
 struct Part2 {
     int S;          // events per sub-chunk (% 4 == 0, <= THREADS * EPT)
     int per_block;  // consecutive sub-chunks per partition block
@@ -111,9 +135,10 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2 *sorted = reinterpret_cast<uint2 *>(smem);                           // [THREADS * EPT] + 2 (trash slot)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts, then cursors
-    uint32_t *tot = hist + ((ntiles + 4) & ~3);                                 // [ntiles] this workgroup's totals
-    uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [65] scan scratch (plan); [66] = run length
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts of the current pass
+    uint32_t *cur = hist + ((ntiles + 4) & ~3);                                 // [ntiles] cursors of the current pass
+    uint32_t *tot = cur + ((ntiles + 4) & ~3);                                  // [ntiles] this workgroup's totals
+    uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [68] scan scratch
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t dropped = 0, nwide = 0;
@@ -165,9 +190,34 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     if (sc0 < sc_end) load_xy(sc0);
     EVK_WAIT_VM0();
     lds_barrier();
+    // One pass per sub-chunk.  Barriers: histogram | scan (wave totals) | cursors | placement -- four, and NONE at the end of
+    // a pass: the sorted sub-chunk is written out at the START of the next pass (its LDS reads come before this wave's
+    // keys; the buffer is rewritten only two barriers later), so the store burst -- 64 KB per CU, which the memory pipeline
+    // takes at ~10 B/clk -- overlaps the key computation of the waves that got their stores in, instead of every wave
+    // waiting for the last one at a closing barrier.  (Per-phase shader cycles of the round-2 order, tools/phase_timing.py:
+    // write-out 11.3 us + closing barrier 14.5 us of a 52 us kernel; a scan by one wave 13 us.)
+    uint32_t kept_prev = 0;   // records of the previous pass's run (uniform)
+    int64_t lo_prev = 0;
+    auto write_out = [&]() {   // one contiguous, coalesced run of records
+        if (V2_ABLATE_A >= 4) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
+            uint4 *dst = reinterpret_cast<uint4 *>(rec + lo_prev);
+            const int n16 = (int)((kept_prev + 1) >> 1);
+            // streaming stores: the run is read once, by the tile kernel, from the Infinity Cache or HBM -- kept out of this
+            // XCD's L2 the partition runs 3 % (10 M events) / 5 % (50 M) faster and the tile kernel within noise (tools/ab.sh)
+            for (int i = tid; i < n16; i += THREADS) {
+                const uint4 v = src[i];
+                __builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
+                __builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+            }
+        }
+    };
+    V2_T0();
     for (int sc = sc0; sc < sc_end; ++sc) {
         asm volatile("" : "+v"(tl_));
         const int64_t lo = (int64_t)sc * q.S;
+        if (sc > sc0) write_out();   // the previous pass's run (everything this wave loaded has landed: no load is in flight)
+        V2_T(0);
         // ---- tile key + accumulator cell of every event
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
@@ -187,12 +237,14 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2) asm volatile("" : "+v"(kl[s2])::"memory");  // keys first, the t, p loads after
         load_tp(sc);    // land during the histogram and the scan
-        // ---- histogram (no-return LDS atomics; hist is zero: the previous pass, or the prologue, left it so)
+        V2_T(1);
+        // ---- histogram (no-return LDS atomics; hist is zero: the scan of the previous pass left it so)
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2)
             if (kl[s2] != 0xFFFFFFFFu)
                 __hip_atomic_fetch_add(&hist[kl[s2] >> V2_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         lds_barrier();  // histogram complete
+        V2_T(2);
         if (V2_ABLATE_A < 2) {
             uint32_t sink = 0;
 #pragma unroll
@@ -204,14 +256,15 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             lds_barrier();
             continue;
         }
-        // ---- exclusive scan of the tile counts -> cursors, the table row, this workgroup's totals: ONE wave, 64 tiles per
-        //      step, no workgroup barrier inside (the three-barrier workgroup scan of round 2 made 7 barriers per pass of
-        //      16 waves; this makes 4)
-        if (tid < 64) {
+        // ---- exclusive scan of the tile counts -> cursors, the table row, this workgroup's totals; every wave scans 64
+        //      tiles, the wave totals meet in LDS (THREADS tiles per round: one round up to 1024 tiles)
+        uint32_t kept = 0;
+        {
             uint32_t *trow = table + (int64_t)sc * q.nt_pad;
-            uint32_t carry = 0;
-            for (int i0 = 0; i0 < ntiles; i0 += 64) {
-                const int i = i0 + lane;
+            constexpr int NWV = THREADS / 64;
+            const int wave = tid >> 6;
+            for (int base = 0; base < ntiles; base += THREADS) {
+                const int i = base + tid;
                 const uint32_t cnt = i < ntiles ? hist[i] : 0u;
                 uint32_t incl = cnt;
 #pragma unroll
@@ -219,27 +272,39 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                     const uint32_t v = __shfl_up(incl, off, 64);
                     if (lane >= off) incl += v;
                 }
+                if (lane == 63) tmp[wave] = incl;
+                lds_barrier();  // wave totals
+                const uint32_t wt = lane < NWV ? tmp[lane] : 0u;   // every wave scans the (<= 16) wave totals itself
+                uint32_t wi = wt;
+#pragma unroll
+                for (int off = 1; off < NWV; off <<= 1) {
+                    const uint32_t v = __shfl_up(wi, off, 64);
+                    if (lane >= off) wi += v;
+                }
+                const uint32_t carry = kept + __shfl(wi - wt, wave, 64);
                 if (i < ntiles) {
                     const uint32_t start = carry + incl - cnt;
-                    hist[i] = start;
+                    cur[i] = start;
+                    hist[i] = 0;            // zero again for the next pass (this thread is the only one touching it now)
                     tot[i] += cnt;
                     trow[i] = start | (cnt << 16);
                 }
-                carry += __shfl(incl, 63, 64);
+                kept += __shfl(wi, NWV - 1, 64);
+                if (base + THREADS < ntiles) lds_barrier();   // tmp is reused by the next round
             }
-            if (lane == 0) tmp[66] = carry;
         }
         lds_barrier();  // cursors complete
-        const uint32_t kept = tmp[66];
+        V2_T(3);
         // normalised time, in place (t has landed during the histogram and the scan), one division at a time
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2) {
-            tv[s2] = time_norm(c.t_of(tpr + C::TPW * (s2 / G), s2 % G), tnorm);  // voxel_grid.py:134, bit-identical (evk_part.h)
+            tv[s2] = time_norm(c.t_of(tpr + C::TPW * (s2 / G), s2 % G), tnorm);  // voxel_grid.py:134 (evk_part.h)
             __builtin_amdgcn_sched_barrier(0);
         }
-        // Nothing outstanding from here (t, p are in; the previous sub-chunk's stores are a histogram and a scan old) -- said
-        // with the builtin so that the placement's uses of t, p get no wait of their own: with x, y of the next sub-chunk
-        // just issued such a wait is a vmcnt(0), i.e. the full latency of those loads in every placement.
+        V2_T(4);
+        // Nothing outstanding from here (t, p are in; the previous run's stores are a histogram and a scan old) -- said with
+        // the builtin so that the placement's uses of t, p get no wait of their own: with x, y of the next sub-chunk just
+        // issued such a wait is a vmcnt(0), i.e. the full latency of those loads in every placement.
         EVK_WAIT_VM0();
         fence();
         if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement
@@ -250,9 +315,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             for (int s2 = 0; s2 < EPT; ++s2) sink += kl[s2] ^ __float_as_uint(tv[s2]) ^ __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
             if (sink == 0x12345u) tot[1] = 1;
             lds_barrier();
-            for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0;
             EVK_WAIT_VM0();
-            lds_barrier();
             continue;
         }
         // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer;
@@ -261,7 +324,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 #pragma unroll
         for (int s2 = 0; s2 < EPT; ++s2) {
             if (kl[s2] != 0xFFFFFFFFu) {
-                const uint32_t pos = atomicAdd(&hist[kl[s2] >> V2_LB], 1u);
+                const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
                 const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
                 const bool wide = (pbits & ~V2_P_MASK) != 0u;
                 sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
@@ -273,21 +336,22 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             for (int s2 = 0; s2 < EPT; ++s2)
                 if (wide_mask >> s2 & 1u) pw[lo + kl[s2]] = c.p_of(tpr + C::TPW * (s2 / G), s2 % G), ++nwide;
         }
-        lds_barrier();
-        EVK_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: see above
-        // ---- one contiguous, coalesced run of `kept` records; hist back to zero for the next pass
-        if (V2_ABLATE_A >= 4) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
-            uint4 *dst = reinterpret_cast<uint4 *>(rec + lo);
-            const int n16 = (int)((kept + 1) >> 1);
-            for (int i = tid; i < n16; i += THREADS) dst[i] = src[i];
-        }
-        for (int i = tid; i < ntiles; i += THREADS) hist[i] = 0;
-        lds_barrier();  // sorted / hist are rewritten by the next sub-chunk
+        V2_T(5);
+        lds_barrier();   // the sorted sub-chunk is complete
+        V2_T(6);
+        EVK_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: the stores below (next pass, or the
+                          // epilogue) then never sit between a load and its use
+        V2_T(7);
+        kept_prev = kept, lo_prev = lo;
     }
+    if (sc0 < sc_end) write_out();   // the last pass's run
+    V2_T(8);
+    V2_T(9);
+    V2_T(10);
     if (dropped && oob) atomicAdd(oob, dropped);
     // ---- totals -> global; the last block to arrive builds the work-item plan
     uint32_t *gidx = index;
+    // (131 K atomics at 10 M events / 512 tiles: 1.5 us of the kernel, measured by leaving them out)
     for (int i = tid; i < ntiles; i += THREADS)
         if (tot[i]) __hip_atomic_fetch_add(gidx + V2_TOTALS + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nwide) __hip_atomic_fetch_add(gidx + 3, nwide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -305,6 +369,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    V2_T(11);  // totals, ticket
+    V2_TEND();
     if (!is_last) return;
     // ---- plan: part_start, per-tile combine counters, item -> tile; totals / ticket back to 0.  A tile with more than `cap`
     //      events is cut into pieces of at most `part` events (ranges of sub-chunks).
@@ -672,7 +738,9 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
 // e.g. an overlapped RCCL collective) and 1024 x 12 (12 K events: longer segments for the tile kernel, taken when there
 // are more than 680 tiles and the call need not share its CUs).  Measured and rejected (compiled
 // only with -DEVK_EXPERIMENTS, tools/exp_build.sh, and selected with EVK_V2_PART): 512x32 / 1024x16 (16 K events: the
-// whole register file, 67 / 74 us), two workgroups per CU (1024x8 / 512x16 / 768x12: spills, 75-150 us).
+// whole register file, 67 / 74 us), two workgroups per CU (round 2: 1024x8 / 512x16 / 768x12, spills, 75-150 us; round 3,
+// without spills: 512x16 56.0 and 768x8 56.8 against 48 us -- the kernel moves its 240 MB at 5 TB/s, a second workgroup per
+// CU only makes the sub-chunks shorter).
 struct V2Config {
     int threads, ept;
 };
@@ -794,12 +862,12 @@ extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
 extern "C" int evk_voxel2_max_tiles(void) {
     const int64_t budget = (int64_t)160 * 1024 - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
-    const int64_t t = budget / 8;   // a counter / cursor and a total per tile
+    const int64_t t = budget / 12;   // a counter, a cursor and a total per tile
     return (int)(t < V2_MAX_TILES ? (t > 0 ? t : 0) : V2_MAX_TILES);
 }
 
-static size_t v2_part_lds(int threads, int ept, int ntiles) {
-    return (size_t)threads * ept * 8 + 16 + 2 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
+static size_t v2_part_lds(int threads, int ept, int ntiles) {   // sorted records | counts | cursors | totals | scan scratch
+    return (size_t)threads * ept * 8 + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
 }
 
 template <int THREADS, int EPT, typename C>
@@ -907,6 +975,14 @@ extern "C" int evk_normalise_time_f32(const float *t, int64_t n, float t_first, 
     k_normalise_time<<<stream_grid(n), EVK_BLOCK, 0, (hipStream_t)stream>>>(t, n, t_first, t_last, (float)(B - 1), out);
     return launch_status();
 }
+
+#ifdef V2_PHASE_TIMING
+extern "C" int evk_debug_phase_cycles(unsigned long long *host16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(v2_phase_cycles), sizeof(z)) != hipSuccess) return EVK_EINVAL;
+    return hipMemcpyToSymbol(HIP_SYMBOL(v2_phase_cycles), z, sizeof(z)) == hipSuccess ? EVK_OK : EVK_EINVAL;
+}
+#endif
 
 extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
                               int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
