@@ -61,6 +61,32 @@ def test_sharded_voxel_and_objective_with_rccl_group(pg):
     assert abs(f - fr) <= 1e-5 * abs(fr) and np.abs(g - gr).max() <= 1e-5 * np.abs(gr).max() + 1e-9
 
 
+def test_voxel_exchange_as_reduce_scatter_all_gather_and_errors_on_every_rank(pg, monkeypatch):
+    """EVK_VOXEL_COLLECTIVE=rsag (RCCL reduce_scatter_tensor + all_gather_into_tensor on the flat grid, tail by all-reduce) gives
+    the grid of the plain all-reduce; an out-of-range event -- also one that an EARLIER deferred call dropped -- raises from the
+    sharded call itself, after its collectives (it must never raise between them on one rank alone)."""
+    import event_utils_amd as E
+    from event_utils_amd import distributed as DD
+    H, W, B, n = 120, 161, 5, 400_000          # 5 * 120 * 161 cells: any world size leaves a tail or not -- both paths run
+    x, y, t, p = _events(5, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (np.floor(x), np.floor(y), t, p)]
+    plain = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
+    monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "rsag")
+    rsag = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
+    assert torch.equal(plain, rsag)
+    odd = torch.arange(1001, dtype=torch.float32, device="cuda")
+    assert torch.equal(DD.reduce_scatter_all_gather_sum_(odd.clone()), odd)
+    # a deferred report left behind by an earlier call on this stream is folded into the sharded call's own check
+    monkeypatch.setenv("EVK_ERRORS", "deferred")
+    bad = [c.clone() for c in cols]
+    bad[0][7] = W + 3.0
+    E.events_to_voxel_torch(*bad, B, sensor_size=(H, W))          # enqueues; the IndexError is pending
+    with pytest.raises(IndexError):
+        DD.events_to_voxel_torch_sharded(*cols, B, (H, W))        # clean events, but the pending report surfaces HERE
+    DD.events_to_voxel_torch_sharded(*cols, B, (H, W))            # ... once
+    E.check_errors()
+
+
 def test_c_abi_collective_and_sharded_integer_image(pg, monkeypatch):
     """libevk's own RCCL binding (evk_comm_*, evk_allreduce_f32 / _i32: what a caller without torch uses) on a 1-rank
     communicator, the sharded integer event image and the sharded voxel grid through it."""

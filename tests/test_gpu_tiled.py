@@ -121,6 +121,21 @@ def test_voxel_deterministic_mode_is_bit_reproducible_at_full_size(E, monkeypatc
                                 sensor_size=(H, W))
 
 
+def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):
+    """Split-polarity tile kernel with fixed-point cells: both grids bit-reproducible and equal to the float64 accumulation
+    (unit weights: every partial sum is exactly representable either way)."""
+    n, H, W, B = 600_000, 260, 346, 5
+    x, y, t, p = _events(9, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    a = E.events_to_neg_pos_voxel_torch(*cols, B, sensor_size=(H, W))
+    monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
+    b = E.events_to_neg_pos_voxel_torch(*cols, B, sensor_size=(H, W))
+    c = E.events_to_neg_pos_voxel_torch(*cols, B, sensor_size=(H, W))
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(v, w)
+        close(v.cpu().numpy(), u.cpu().numpy(), 1e-6)
+
+
 def test_voxel_tiling_is_balanced_over_the_cus(E):
     """The one-pass path tiles the sensor so that every CU gets the same number of tiles (the tile kernel runs one
     workgroup per tile, all resident): 512 tiles at 640x480, a multiple of 256 within 1 % at 1280x720."""
