@@ -97,18 +97,6 @@ _SPECIAL = {
 }
 
 
-# entry points of experiments builds only (-DEVK_EXPERIMENTS, csrc/evk_experiments.h): bound when the loaded library has them
-_OPTIONAL = {
-    "evk_voxel3_f32": ([P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, c_int64,
-                        P, P, c_uint32, P], c_int),
-    "evk_voxel3_native_f32": ([P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
-                               c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P], c_int),
-    "evk_voxel3_max_tiles": ([], c_int),
-    "evk_voxel3_index_len": ([c_int, c_int64], c_int64),
-    "evk_voxel3_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
-}
-
-
 class EvkError(RuntimeError):
     pass
 
@@ -135,11 +123,6 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = restype
-        for name, (argtypes, restype) in _OPTIONAL.items():
-            fn = getattr(L, name, None)
-            if fn is not None:
-                fn.argtypes = argtypes
-                fn.restype = restype
         _lib = L
     return _lib
 

@@ -1,54 +1,13 @@
-// Pieces shared by the one-pass partition kernels (evk_voxel3.hip; the round-2 kernels of evk_voxel2.hip keep their own
-// copies behind EVK_EXPERIMENTS): an LDS-only workgroup barrier, the workgroup exclusive scan, the nearest-pixel tile key
-// with the pixel inside the tile, and the layout of the self-resetting index buffer.
+// Pieces of the one-pass voxel path (evk_voxel2.hip): the tile grid with tiles of any size and the nearest-pixel key, the
+// normalised time, the column sources (float32 SoA / the reference's on-disk dtypes, raw words decoded at use), an LDS-only
+// workgroup barrier and a workgroup scan.
 #pragma once
 #include "evk_tiles.h"
 
 namespace evk {
 
-// index buffer (uint32 words, zeroed ONCE by the caller; every call leaves the counters it used zero again)
-#define VP_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] escaped records (info), [4] fixed-point range errors
-#define VP_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
-#define VP_TOTALS VP_HDR
-#define VP_PART (VP_HDR + VP_MAX_TILES)            // part_start[T + 1]
-#define VP_COUNTER(T) (VP_PART + (T) + 1)          // counters[T]   (split-tile combine)
-#define VP_ITEM(T) (VP_PART + 2 * (T) + 1)         // item_tile[max_items]
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release, for which the
-// compiler drains this wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)): a full store round trip at every barrier,
-// and no load can be in flight across it.  Inside the partition kernels only LDS is shared between the waves.
-__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // vmcnt(0), expcnt / lgkmcnt untouched -- as a BUILTIN, so that the compiler's wait-count pass knows the loads are in
 #define EVK_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
-
-template <int THREADS>
-__device__ __forceinline__ uint32_t wg_excl_scan(uint32_t mine, uint32_t *tmp, uint32_t &total) {
-    constexpr int NW = THREADS / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) tmp[wave] = incl;
-    lds_only_barrier();
-    if (wave == 0) {
-        const uint32_t w = lane < NW ? tmp[lane] : 0u;
-        uint32_t wi = w;
-#pragma unroll
-        for (int off = 1; off < NW; off <<= 1) {
-            const uint32_t v = __shfl_up(wi, off, 64);
-            if (lane >= off) wi += v;
-        }
-        if (lane < NW) tmp[32 + lane] = wi - w;
-        if (lane == NW - 1) tmp[64] = wi;
-    }
-    lds_only_barrier();
-    total = tmp[64];
-    return tmp[32 + wave] + incl - mine;   // the caller puts a barrier before tmp is used again
-}
 
 // Tile grid of the one-pass voxel paths: tiles of ANY width and height (pixels), not only powers of two, so that the
 // tile COUNT can be chosen: the tile kernel runs one workgroup per tile, all resident at once, and a launch lasts as long

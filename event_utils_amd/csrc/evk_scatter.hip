@@ -332,11 +332,16 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_warp_flow_field_f32(const float *
 // ---------------------------------------------------------------------------------------------------------
 
 // Adds p*max(0, 1-|t_norm-b|) for every bin b where it is non-zero (b = floor(t_norm), floor(t_norm)+1); a NaN
-// t_norm (dt == 0, quirk Q9) poisons all B bins of the pixel exactly as the reference does.
+// t_norm (dt == 0, quirk Q9) poisons all B bins of the pixel exactly as the reference does, and so does a polarity that is
+// not finite: the reference adds p * weight to EVERY bin (voxel_grid.py:138-142), and NaN * 0 = inf * 0 = NaN.
 template <typename T>
 __device__ __forceinline__ void voxel_bins(T *__restrict__ vox, int64_t plane, int64_t pix, int B, T tn, T p) {
     if (tn != tn) {
         for (int b = 0; b < B; ++b) atomic_add(vox + b * plane + pix, tn * p);
+        return;
+    }
+    if (p - p != (T)0) {   // NaN or +-inf (finite p: p - p == 0)
+        for (int b = 0; b < B; ++b) atomic_add(vox + b * plane + pix, p * fmax((T)0, (T)1 - fabs(tn - (T)b)));
         return;
     }
     const T fl = floor(tn);

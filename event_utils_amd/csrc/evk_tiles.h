@@ -151,6 +151,10 @@ __device__ __forceinline__ void voxel_bins_lds(acc_t *acc, int tpix, int local, 
         for (int b = 0; b < B; ++b) lds_add(acc + b * tpix + local, tn * p);
         return;
     }
+    if (!(fabsf(p) <= 3.0e38f)) {  // a polarity that is not finite reaches EVERY bin (p * 0 = NaN), as in the reference
+        for (int b = 0; b < B; ++b) lds_add(acc + b * tpix + local, p * fmaxf(0.0f, 1.0f - fabsf(tn - (float)b)));
+        return;
+    }
     const float fl = floorf(tn);
     const int b0 = (int)fmaxf(fminf(fl, (float)(B + 1)), -2.0f);
 #pragma unroll

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "evk_part.h"
 
@@ -123,13 +124,32 @@ struct Part2 {
 
 // C = column source (evk_part.h): SrcF32, or SrcNative<.> for the reference's on-disk dtypes.  G = C::G consecutive events
 // per lane and load instruction.
-template <int THREADS, int EPT, typename C>
+//
+// REC = bytes per record.  8: {t_norm, polarity | cell} as described at the top.  4 (round 3): ONE word,
+//     [31:12] t_norm as a bit-pattern DELTA from the sub-chunk's first event   [11:10] polarity code   [9:0] cell
+// * t_norm is carried exactly: the events of a sub-chunk are consecutive in a time-sorted stream, so their t_norm values lie
+//   within a few thousand float32 steps of the first one's (`bases[sub-chunk]` holds its bit pattern); delta < 2^20.
+// * polarity code 0 / 1 / 2 = +1.0 / -1.0 / +0.0 -- what the reference's loaders and the bool / uint8 files produce.
+// * anything else (another polarity, a delta out of range: unsorted or sparse streams, the first events of a stream where
+//   float32 steps are tiny, NaN from dt == 0) ESCAPES: code 3, the delta field holds the index of an exact 8-byte
+//   {t_norm bits, polarity bits} entry in the sub-chunk's slice of the side array.  Exact for any float32 input.
+// The partition is bound by the bytes it moves (5 TB/s of 240 MB): 20 B/event instead of 24 is worth 5 us of 47 at 10 M
+// events and 36 of 248 us at 50 M (measured by writing half of every run), the tile kernel then reads 4 B/event instead of 8.
+#define V2_DELTA_SHIFT 12
+#define V2_DELTA_LIMIT (1u << 20)
+#define V2_CODE_SHIFT 10
+template <int THREADS, int EPT, int REC, typename C>
 __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q, float t_first,
                                                             float t_last, float bm1, int t_from_events,
-                                                            uint2 *__restrict__ rec, float *__restrict__ pw,
+                                                            void *__restrict__ rec_, void *__restrict__ side_,
+                                                            uint32_t *__restrict__ bases,
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                             uint32_t cap, uint32_t part, uint32_t *oob, uint32_t *host_report,
                                                             uint32_t seq) {
+    static_assert(REC == 8 || REC == 4, "record size");
+    uint2 *const rec = static_cast<uint2 *>(rec_);            // REC 8: 8-byte records | REC 4: viewed as uint32 below
+    float *const pw = static_cast<float *>(side_);            // REC 8: exact polarity at the record's index
+    uint2 *const wide2 = static_cast<uint2 *>(side_);         // REC 4: exact {t_norm, polarity} of an escaped record
     constexpr int G = C::G, NG = EPT / G;
     static_assert(EPT % G == 0, "events per thread");
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
@@ -138,10 +158,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts of the current pass
     uint32_t *cur = hist + ((ntiles + 4) & ~3);                                 // [ntiles] cursors of the current pass
     uint32_t *tot = cur + ((ntiles + 4) & ~3);                                  // [ntiles] this workgroup's totals
-    uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [68] scan scratch
+    uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [68] scan scratch; [67] escapes of the pass
+    uint32_t *sorted4 = reinterpret_cast<uint32_t *>(smem);                     // REC 4: the same buffer, one word per record
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t dropped = 0, nwide = 0;
+    float tb = 0.0f;   // REC 4: time stamp of the sub-chunk's first event
     if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
     const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
 
@@ -181,6 +203,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     auto load_tp = [&](int sc) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
+        if constexpr (REC == 4) tb = c.t1((int64_t)sc * q.S);   // base of the t_norm deltas (same address in every lane)
     };
     auto fence = [&]() {   // for the compiler: loads hoisted above a compute phase keep their 2 * EPT registers live through it
         asm volatile("" ::: "memory");
@@ -201,8 +224,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     auto write_out = [&]() {   // one contiguous, coalesced run of records
         if (V2_ABLATE_A >= 4) {
             const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
-            uint4 *dst = reinterpret_cast<uint4 *>(rec + lo_prev);
-            const int n16 = (int)((kept_prev + 1) >> 1);
+            uint4 *dst = REC == 8 ? reinterpret_cast<uint4 *>(rec + lo_prev)
+                                  : reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev);
+            const int n16 = REC == 8 ? (int)((kept_prev + 1) >> 1) : (int)((kept_prev + 3) >> 2);
             // streaming stores: the run is read once, by the tile kernel, from the Infinity Cache or HBM -- kept out of this
             // XCD's L2 the partition runs 3 % (10 M events) / 5 % (50 M) faster and the tile kernel within noise (tools/ab.sh)
             for (int i = tid; i < n16; i += THREADS) {
@@ -292,6 +316,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 kept += __shfl(wi, NWV - 1, 64);
                 if (base + THREADS < ntiles) lds_barrier();   // tmp is reused by the next round
             }
+            if (REC == 4 && tid == 0) tmp[67] = 0;   // escapes of this pass
         }
         lds_barrier();  // cursors complete
         V2_T(3);
@@ -318,23 +343,51 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             EVK_WAIT_VM0();
             continue;
         }
-        // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer;
-        //      the 8-byte record = normalised time | polarity | accumulator cell
-        uint32_t wide_mask = 0;
+        // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer, where
+        //      its record is built
+        if constexpr (REC == 8) {
+            uint32_t wide_mask = 0;
 #pragma unroll
-        for (int s2 = 0; s2 < EPT; ++s2) {
-            if (kl[s2] != 0xFFFFFFFFu) {
-                const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
-                const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
-                const bool wide = (pbits & ~V2_P_MASK) != 0u;
-                sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
-                if (wide) wide_mask |= 1u << s2, kl[s2] = pos;   // kl is dead from here on: keep the slot instead
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                if (kl[s2] != 0xFFFFFFFFu) {
+                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
+                    const bool wide = (pbits & ~V2_P_MASK) != 0u;
+                    sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
+                    if (wide) wide_mask |= 1u << s2, kl[s2] = pos;   // kl is dead from here on: keep the slot instead
+                }
             }
-        }
-        if (__any(wide_mask != 0u)) {  // rare: exact float32 polarities go to the side array at the record's index
+            if (__any(wide_mask != 0u)) {  // rare: exact float32 polarities go to the side array at the record's index
 #pragma unroll
-            for (int s2 = 0; s2 < EPT; ++s2)
-                if (wide_mask >> s2 & 1u) pw[lo + kl[s2]] = c.p_of(tpr + C::TPW * (s2 / G), s2 % G), ++nwide;
+                for (int s2 = 0; s2 < EPT; ++s2)
+                    if (wide_mask >> s2 & 1u) pw[lo + kl[s2]] = c.p_of(tpr + C::TPW * (s2 / G), s2 % G), ++nwide;
+            }
+        } else {
+            const uint32_t bbits = __float_as_uint(time_norm(tb, tnorm));
+            if (tid == 0) bases[sc] = bbits;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                const uint32_t tbits = __float_as_uint(tv[s2]), pb = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
+                const uint32_t d = tbits - bbits;
+                // +1.0 -> 0, -1.0 -> 1, +0.0 -> 2, anything else -> 3 (two selects: a chain of equality tests on one value
+                // becomes a switch with divergent branches)
+                const uint32_t code = (pb & 0x7FFFFFFFu) == 0x3F800000u ? pb >> 31 : 3u - (uint32_t)(pb == 0u);
+                const bool live = kl[s2] != 0xFFFFFFFFu;
+                const bool esc = live & ((code == 3u) | (d >= V2_DELTA_LIMIT));
+                uint32_t word = (d << V2_DELTA_SHIFT) | (code << V2_CODE_SHIFT) | (kl[s2] & V2_LOCAL_MASK);
+                if (__any(esc)) {   // rare, wave-uniform test: the exact pair to the side array, its index into the record
+                    if (esc) {
+                        const uint32_t e = atomicAdd(&tmp[67], 1u);
+                        wide2[lo + e] = make_uint2(tbits, pb);
+                        word = (e << V2_DELTA_SHIFT) | (3u << V2_CODE_SHIFT) | (kl[s2] & V2_LOCAL_MASK);
+                        ++nwide;
+                    }
+                }
+                if (live) {
+                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    sorted4[pos] = word;
+                }
+            }
         }
         V2_T(5);
         lds_barrier();   // the sorted sub-chunk is complete
@@ -427,12 +480,19 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 // grid is bit-identical from run to run and for any order of the events.  |contribution| < 2^30 and finite, else it is
 // counted in index[4] and left out (the wrapper raises).
 #define V2_FIXED_ONE 4294967296.0
-template <int WG, int U, bool SPLIT, bool FIXED>
-__global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const uint2 *__restrict__ rec, const float *__restrict__ pw,
+template <int WG, int U, bool SPLIT, bool FIXED, int REC>
+__global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const void *__restrict__ rec_, const void *__restrict__ side_,
+                                                     const uint32_t *__restrict__ bases,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGridG g, Part2 q, int B, int flags, float *__restrict__ vox,
                                                      float *__restrict__ staging) {
     constexpr int NW = WG / 64;
+    // REC 8: a lane takes 16 bytes = 2 records {t_norm, polarity | cell}; REC 4: 8 bytes = 2 one-word records (k_part_sorted),
+    // decoded with the base of their sub-chunk, which travels with the chunk list
+    typedef typename std::conditional<REC == 8, uint4, uint2>::type Pair;
+    const Pair *const recp = static_cast<const Pair *>(rec_);           // indexed in PAIRS of records
+    const float *const pw = static_cast<const float *>(side_);
+    const uint2 *const wide2 = static_cast<const uint2 *>(side_);
     const int overwrite = flags & EVK_VOXEL_OVERWRITE;
     constexpr bool split = SPLIT;
     const int NB = split ? 2 * B : B;
@@ -443,6 +503,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     // by a ds_bpermute of the table entry put two dependent LDS round trips, queued behind other waves' atomics, in front
     // of every load)
     __shared__ uint2 cseg[NW][V2_CHUNK_CAP];
+    __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP : 1];   // REC 4: t_norm base of the chunk's sub-chunk
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
     const uint32_t nitems = part_start[ntiles];
@@ -493,6 +554,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             for (int b = 0; b < B; ++b) add(base + b * ppix + local, tn * p);
             return;
         }
+        if (!(fabsf(p) <= 3.0e38f)) {  // a polarity that is not finite reaches EVERY bin (p * 0 = NaN), as in the reference
+            for (int b = 0; b < B; ++b) add(base + b * ppix + local, p * fmaxf(0.0f, 1.0f - fabsf(tn - (float)b)));
+            return;
+        }
         const float fl = floorf(tn);
         const int b0 = (int)fmaxf(fminf(fl, (float)(B + 1)), -2.0f);
 #pragma unroll
@@ -504,19 +569,35 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         }
     };
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
-        const int local = (int)(hi_w & V2_LOCAL_MASK);   // row * pitch + column
-        float p = __uint_as_float(hi_w & V2_P_MASK);
-        if (hi_w & V2_WIDE) {   // rare: the exact float32 polarity from the side array.  The wait stays INSIDE the branch
-            p = pw[ridx];       // (builtin: the compiler's scoreboard sees it) -- at the join it would be a vmcnt(0) on
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // every event, i.e. the next round's record loads could never stay in flight
+        // REC 8: lo_w = t_norm bits, hi_w = polarity | cell.  REC 4: lo_w = the record word, hi_w = its sub-chunk's base.
+        int local;
+        float p, tn;
+        if constexpr (REC == 8) {
+            local = (int)(hi_w & V2_LOCAL_MASK);   // row * pitch + column
+            p = __uint_as_float(hi_w & V2_P_MASK);
+            if (hi_w & V2_WIDE) {   // rare: the exact float32 polarity from the side array.  The wait stays INSIDE the branch
+                p = pw[ridx];       // (builtin: the compiler's scoreboard sees it) -- at the join it would be a vmcnt(0) on
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // every event, i.e. the next round's record loads could never stay in flight
+            }
+            tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
+        } else {
+            local = (int)(lo_w & V2_LOCAL_MASK);
+            const uint32_t code = (lo_w >> V2_CODE_SHIFT) & 3u;
+            if (code == 3u) {       // rare: escaped record, the exact pair from the side array (same wait discipline)
+                const uint2 e = wide2[(uint64_t)(ridx / (uint32_t)q.S) * (uint32_t)q.S + (lo_w >> V2_DELTA_SHIFT)];
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                tn = __uint_as_float(e.x), p = __uint_as_float(e.y);
+            } else {
+                tn = __uint_as_float(hi_w + (lo_w >> V2_DELTA_SHIFT));
+                p = __uint_as_float(code == 2u ? 0u : (0x3F800000u | (code << 31)));
+            }
         }
-        const float tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
         if (V2_ABLATE_B < 3) {
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
-        if (__builtin_expect(tn >= 0.0f && tn <= bm1, 1)) {
-            // the common case, straight-line: t inside [ts[0], ts[-1]].  Bins b0 = floor(t_norm) and b0 + 1 with the
+        if (__builtin_expect(tn >= 0.0f && tn <= bm1 && (SPLIT || fabsf(p) <= 3.0e38f), 1)) {
+            // the common case, straight-line: t inside [ts[0], ts[-1]] (and a finite polarity: any other reaches every bin).  Bins b0 = floor(t_norm) and b0 + 1 with the
             // weights of voxel_grid.py:138 -- 1 - |t_norm - b| evaluated exactly as there (for b0 the absolute value is
             // the identity; max(0, .) cannot bind for these two bins).  A zero weight is added like any other (x + 0 = x;
             // the reference's index_put_ adds it too): skipping it cost a compare and a branch per bin on every event.
@@ -543,13 +624,14 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
             bins_general(acc + B * ppix, local, tn, 1.0f);
         }
     };
-    auto pair = [&](const uint4 &v, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
-        if (V2_ABLATE_B < 2) {
-            if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345u) acc[1] = 1.0;
-            return;
+    auto pair = [&](const Pair &v, uint32_t bbits, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
+        if constexpr (REC == 8) {
+            if (pos >= beg) one(v.x, v.y, pos);
+            if (pos + 1 < end) one(v.z, v.w, pos + 1);
+        } else {
+            if (pos >= beg) one(v.x, bbits, pos);
+            if (pos + 1 < end) one(v.y, bbits, pos + 1);
         }
-        if (pos >= beg) one(v.x, v.y, pos);
-        if (pos + 1 < end) one(v.z, v.w, pos + 1);
     };
     // Entries go to the threads in equal batches, INTERLEAVED over the waves (slot = lane * NW + wave): a short range -- the
     // last batch of a tile, or one of the many parts of a hot tile -- then still gives every wave its share instead of
@@ -557,16 +639,21 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
     const int range = sc_hi - sc_lo, nbatch = (range + WG - 1) / WG;
     const int bsz = nbatch ? ((range + nbatch - 1) / nbatch + NW - 1) / NW * NW : NW;  // <= WG, a multiple of NW
     const int slot = lane * NW + wave;
-    uint32_t ent_next = 0;
+    uint32_t ent_next = 0, bb_next = 0;
     {
         const int my = sc_lo + slot;
-        if (slot < bsz && my < sc_hi) ent_next = col[(int64_t)my * q.nt_pad];
+        if (slot < bsz && my < sc_hi) {
+            ent_next = col[(int64_t)my * q.nt_pad];
+            if constexpr (REC == 4) bb_next = bases[my];
+        }
     }
     for (int base = sc_lo; base < sc_hi; base += bsz) {
-        const uint32_t ent = ent_next;
+        const uint32_t ent = ent_next, bb = bb_next;
         {   // next batch's entries: in flight while this batch is processed
             const int my = base + bsz + slot;
-            ent_next = (slot < bsz && my < sc_hi) ? col[(int64_t)my * q.nt_pad] : 0u;
+            const bool have = slot < bsz && my < sc_hi;
+            ent_next = have ? col[(int64_t)my * q.nt_pad] : 0u;
+            if constexpr (REC == 4) bb_next = have ? bases[my] : 0u;
         }
         if (V2_ABLATE_B < 1) {
             if (ent == 0xFFFFFFFFu) acc[0] = 1.0;
@@ -587,7 +674,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
         {
             const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + (start & ~1u), e0 = rb + start + cnt;
-            for (uint32_t k = 0; k < mych; ++k) cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
+            for (uint32_t k = 0; k < mych; ++k) {
+                cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
+                if constexpr (REC == 4) cbase[wave][excl + k] = bb;
+            }
         }
         __syncthreads();
         // Chunk rounds, software-pipelined in three stages: list entries of round r + 2 (LDS) | record loads of round r + 1
@@ -597,54 +687,48 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
         // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
         // while its 600 segments are pulled
-        auto meta = [&](uint32_t j0, uint2(&cs)[U]) {
+        auto meta = [&](uint32_t j0, uint2(&cs)[U], uint32_t(&cb_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t j = j0 + 16u * u + grp;
                 cs[u] = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
+                if constexpr (REC == 4) cb_[u] = j < total ? cbase[wave][j] : 0u;
             }
         };
-        auto fire = [&](const uint2(&cs)[U], uint4(&v)[U]) {
+        auto fire = [&](const uint2(&cs)[U], Pair(&v)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
-                v[u] = *reinterpret_cast<const uint4 *>(rec + (pos < cs[u].y ? pos : 2u * sub));
+                v[u] = recp[(pos < cs[u].y ? pos : 2u * sub) >> 1];
             }
         };
-        auto eat = [&](const uint2(&cs)[U], const uint4(&v)[U]) {
+        auto eat = [&](const uint2(&cs)[U], const uint32_t(&cb_)[U], const Pair(&v)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
                 // beg == the segment's first record when it lies inside this chunk
-                if (pos < cs[u].y) pair(v[u], pos, (cs[u].x & ~1u) + (cs[u].x & 1u), cs[u].y);
+                if (pos < cs[u].y) pair(v[u], cb_[u], pos, (cs[u].x & ~1u) + (cs[u].x & 1u), cs[u].y);
             }
         };
         constexpr uint32_t step = 16u * U;
-        if (V2_PIPE) {
+        {
             uint2 ca[U], cb[U], cn[U];
-            uint4 va[U], vb[U];
-            meta(0u, ca);
+            uint32_t ba[U] = {}, bbv[U] = {}, bn[U] = {};
+            Pair va[U], vb[U];
+            meta(0u, ca, ba);
             fire(ca, va);
-            meta(step, cb);
+            meta(step, cb, bbv);
             for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
                 fire(cb, vb);               // round j0 + step
-                meta(j0 + 2u * step, cn);
-                eat(ca, va);                // round j0
+                meta(j0 + 2u * step, cn, bn);
+                eat(ca, ba, va);            // round j0
                 fire(cn, va);               // round j0 + 2 step
 #pragma unroll
-                for (int u = 0; u < U; ++u) ca[u] = cn[u];
-                meta(j0 + 3u * step, cn);
-                eat(cb, vb);                // round j0 + step
+                for (int u = 0; u < U; ++u) ca[u] = cn[u], ba[u] = bn[u];
+                meta(j0 + 3u * step, cn, bn);
+                eat(cb, bbv, vb);           // round j0 + step
 #pragma unroll
-                for (int u = 0; u < U; ++u) cb[u] = cn[u];
-            }
-        } else {
-            uint2 ca[U];
-            uint4 va[U];
-            for (uint32_t j0 = 0; j0 < total; j0 += step) {
-                meta(j0, ca);
-                fire(ca, va);
-                eat(ca, va);
+                for (int u = 0; u < U; ++u) cb[u] = cn[u], bbv[u] = bn[u];
             }
         }
         // long segments (> 7 chunks = 56 records): the whole wave streams each of them, 16 bytes per lane
@@ -652,23 +736,23 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const u
         while (m) {
             const int s = __builtin_ctzll(m);
             m &= m - 1;
-            const uint32_t e2 = __shfl(ent, s, 64);
+            const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
             const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
             const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
             const uint32_t b2 = rb + st, e3 = b2 + cn;
             // four loads per lane in flight (the parts of a hot tile are all long segments: with one dependent load at a
             // time a part was a chain of ~2 us round trips)
             for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 512u) {
-                uint4 v[4];
+                Pair v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t pu = p2 + 128u * u;
-                    v[u] = *reinterpret_cast<const uint4 *>(rec + (pu < e3 ? pu : p2));
+                    v[u] = recp[(pu < e3 ? pu : p2) >> 1];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t pu = p2 + 128u * u;
-                    if (pu < e3) pair(v[u], pu, b2, e3);
+                    if (pu < e3) pair(v[u], b2b, pu, b2, e3);
                 }
             }
         }
@@ -821,17 +905,32 @@ static int64_t v2_part(int64_t n, int ntiles) {   // ... into pieces of at most 
 }
 static int v2_max_items(int64_t n, int ntiles) { return ntiles + (int)(n / v2_part(n, ntiles)) + 1; }
 
+// Record size of a call.  4-byte compact records (k_part_sorted) once the call's streams no longer fit the 256 MB Infinity
+// Cache (more than 16 M events): there the partition is bound by HBM bytes and 20 instead of 24 B/event make it 15 % faster
+// (50 M events: 245 -> 208 us, whole call 0.397 -> 0.366 ms, same box).  Below, the streams are cache-resident and the delta /
+// code / escape arithmetic costs what the bytes save, the tile kernel's extra decode 6 % (10 M events: 0.0838 against
+// 0.0792 ms): 8-byte records.  EVK_V2_REC=4|8 forces one (measurements, tests).
+static int v2_rec_bytes(int64_t n) {
+    static const int forced = [] {
+        const char *s = getenv("EVK_V2_REC");
+        const int v = s ? atoi(s) : 0;
+        return (v == 4 || v == 8) ? v : 0;
+    }();
+    if (forced) return forced;
+    return n * 16 > ((int64_t)256 << 20) ? 4 : 8;
+}
 struct V2Layout {
-    int64_t table, rec, pw, staging, total;
+    int64_t table, bases, rec, pw, staging, total;
 };
 static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw, int th, bool share = false) {
     const Part2 q = v2_geometry(n, ntiles, share);
     const int64_t slots = (int64_t)q.nsc * q.S;
     V2Layout L;
     L.table = 0;
-    L.rec = al256((int64_t)q.nsc * q.nt_pad * 4);
-    L.pw = L.rec + al256(slots * 8);
-    L.staging = L.pw + al256(slots * 4);
+    L.bases = al256((int64_t)q.nsc * q.nt_pad * 4);
+    L.rec = L.bases + al256((int64_t)q.nsc * 4);
+    L.pw = L.rec + al256(slots * 8);        // (sized for either record format: 8 + 4 or 4 + 8 bytes per slot)
+    L.staging = L.pw + al256(slots * 8);
     L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * ((int64_t)planes * tw * th) * 4);
     return L;
 }
@@ -870,37 +969,38 @@ static size_t v2_part_lds(int threads, int ept, int ntiles) {   // sorted record
     return (size_t)threads * ept * 8 + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
 }
 
-template <int THREADS, int EPT, typename C>
+template <int THREADS, int EPT, int REC, typename C>
 static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part2 &q, float t_first, float t_last,
-                        float bm1, int t_from_events, uint2 *rec, float *pw, uint32_t *table, uint32_t *index,
+                        float bm1, int t_from_events, void *rec, void *pw, uint32_t *bases, uint32_t *table, uint32_t *index,
                         uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
     const size_t lds = v2_part_lds(THREADS, EPT, ntiles);
     static std::once_flag once[64];   // per device and instantiation: the attribute belongs to the loaded code object
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {   // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
-        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, REC, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 256);
     });
-    k_part_sorted<THREADS, EPT, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
-                                                                    rec, pw, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
+    k_part_sorted<THREADS, EPT, REC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
+                                                                    rec, pw, bases, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
                                                                     host_report, seq);
 }
 
 // Tile kernel: 512 threads, 2 chunk loads per lane in flight (256 / 1024 threads, 4 / 8 loads: 48-69 us against 34,
 // DESIGN.md section 3; EVK_EXPERIMENTS builds keep them, EVK_V2_WG / EVK_V2_U).  `lds_dyn` >= the accumulators: asking for
 // more LDS than they need is how the launch fixes the number of workgroups a CU holds (below).
-template <int WG, int U, bool SPLIT, bool FIXED>
-static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const uint2 *rec, const float *pw, const uint32_t *table,
-                         uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox, float *staging) {
+template <int WG, int U, bool SPLIT, bool FIXED, int REC>
+static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *rec, const void *pw, const uint32_t *bases,
+                         const uint32_t *table, uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox,
+                         float *staging) {
     static std::once_flag once[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {
-        (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - (int)sizeof(uint2) * (WG / 64) * V2_CHUNK_CAP - 256);
+        (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED, REC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP - 256);
     });
-    k_voxel_tiles2<WG, U, SPLIT, FIXED><<<items, WG, lds_dyn, s>>>(rec, pw, table, index, g, q, B, kf, vox, staging);
+    k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging);
 }
 
 template <typename C>
@@ -917,7 +1017,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
-    const size_t lds_static = sizeof(uint2) * 8 * V2_CHUNK_CAP + 64;        // the tile kernel's chunk lists (512 threads)
+    const size_t lds_static = 12 * 8 * V2_CHUNK_CAP + 64;                  // the tile kernel's chunk lists (512 threads)
     if (lds_acc + lds_static > 150 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const V2Layout L = v2_layout(ntiles, n, planes, tile_w, tile_h, share);
@@ -925,18 +1025,22 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     if (!aligned16(scratch)) return EVK_EALIGN;
     const Part2 q = v2_geometry(n, ntiles, share);
     char *sb = (char *)scratch;
-    uint32_t *table = (uint32_t *)(sb + L.table);
-    uint2 *rec = (uint2 *)(sb + L.rec);
-    float *pw = (float *)(sb + L.pw);
+    uint32_t *table = (uint32_t *)(sb + L.table), *bases = (uint32_t *)(sb + L.bases);
+    void *rec = sb + L.rec, *pw = sb + L.pw;
     float *staging = (float *)(sb + L.staging);
     hipStream_t s = (hipStream_t)stream;
     const V2Config &cfg = v2_config(share, ntiles);
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
+    const int recb = v2_rec_bytes(n);
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
-#define X(T, E)                                                                                                       \
-    if (cfg.threads == T && cfg.ept == E)                                                                             \
-        launch_part<T, E>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, table, index, oob, host_report, seq, s);
+#define X(T, E)                                                                                                              \
+    if (cfg.threads == T && cfg.ept == E) {                                                                                  \
+        if (recb == 4)                                                                                                       \
+            launch_part<T, E, 4>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, bases, table, index, oob, host_report, seq, s); \
+        else                                                                                                                 \
+            launch_part<T, E, 8>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, bases, table, index, oob, host_report, seq, s); \
+    }
         V2_GEOMETRIES(X)
 #undef X
     }
@@ -948,14 +1052,15 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // 81 against 68 us, its many pieces then waiting for slots)
         const size_t lds_dyn = lds_acc;
         const bool sp = flags & EVK_VOXEL_SPLIT_POLARITY, fx = flags & EVK_VOXEL_DETERMINISTIC;
-#define V2_TILES(WG, U)                                                                                                   \
-    do {                                                                                                                  \
-        if (sp && fx) launch_tiles<WG, U, true, true>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
-        else if (sp) launch_tiles<WG, U, true, false>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
-        else if (fx) launch_tiles<WG, U, false, true>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);    \
-        else launch_tiles<WG, U, false, false>(items, lds_dyn, s, rec, pw, table, index, g, q, B, kf, vox, staging);           \
+#define V2_TILES(R)                                                                                                        \
+    do {                                                                                                                   \
+        if (sp && fx) launch_tiles<512, 2, true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (sp) launch_tiles<512, 2, true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (fx) launch_tiles<512, 2, false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else launch_tiles<512, 2, false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
     } while (0)
-        V2_TILES(512, 2);
+        if (recb == 4) V2_TILES(4);
+        else V2_TILES(8);
 #undef V2_TILES
     }
     return launch_status();

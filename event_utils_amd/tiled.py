@@ -170,8 +170,7 @@ def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
 
 
 def voxel_path():
-    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip); 'v3' = the
-    4-byte-record variant of the one-pass path (evk_voxel3.hip), present in experiments builds only (tools/exp_build.sh)."""
+    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip)."""
     return os.environ.get("EVK_VOXEL_PATH", "v2")
 
 
@@ -182,7 +181,7 @@ def voxel_deterministic():
 
 
 _NUM_CU = 256
-_TILE_LIST_BYTES = 8 * 448 * 8 + 64      # the tile kernel's chunk lists (static LDS, 512 threads)
+_TILE_LIST_BYTES = 12 * 448 * 8 + 64     # the tile kernel's chunk lists (static LDS, 512 threads; 4-byte records: + a base per entry)
 _shape_cache = {}
 
 
@@ -198,7 +197,7 @@ def voxel2_shape(H, W, planes):
     if key in _shape_cache:
         return _shape_cache[key]
     L = _lib.lib()
-    max_tiles = L.evk_voxel3_max_tiles() if voxel_path() == "v3" else L.evk_voxel2_max_tiles()
+    max_tiles = L.evk_voxel2_max_tiles()
     env = os.environ.get("EVK_VOXEL2_TILE")
     best = None
     if env:
@@ -227,12 +226,11 @@ def voxel2_shape(H, W, planes):
 
 
 def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
-    """evk_voxel3_f32 / evk_voxel3_native_f32 (or the round-2 evk_voxel2_* under EVK_VOXEL_PATH=v2): partition + tile
-    kernel from ONE library call.  t_first None = ts[0] and ts[-1] are read on the device (no transfer before the
-    launch)."""
+    """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
+    ts[-1] are read on the device (no transfer before the launch)."""
     L = _lib.lib()
     dev = out.device
-    ver = "voxel3" if voxel_path() == "v3" else "voxel2"
+    ver = "voxel2"
     planes = 2 * B if split_polarity else B
     ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
     key = (ver, ntiles, n, planes, tw, th)
@@ -279,7 +277,7 @@ def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=N
     if not (can_tile((xd, yd, td, pd), impl) and 2 * B * 8 * 64 <= 65536):
         return None
     out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
-    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() in ("v2", "v3") else None
+    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() == "v2" else None
     if shape2 is not None:
         voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
         return out
@@ -301,7 +299,7 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
     else:
         tileable = can_tile((xd, yd, td, pd), impl)
-    if tileable and voxel_path() in ("v2", "v3"):
+    if tileable and voxel_path() == "v2":
         shape2 = voxel2_shape(H, W, B)
         if shape2 is not None:
             voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
@@ -572,11 +570,11 @@ def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps
                 "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
     total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True),
                      reps)
-    shape2 = voxel2_shape(H, W, B) if voxel_path() in ("v2", "v3") else None
+    shape2 = voxel2_shape(H, W, B) if voxel_path() == "v2" else None
     if shape2 is not None:
         n = xd.shape[0]
         run2 = lambda stage: voxel2((xd, yd, td, pd), None, n, t_first, t_last, B, H, W, *shape2, out, None, True, stage=stage)
-        kp, kt = ("k_part3", "k_voxel_tiles3") if voxel_path() == "v3" else ("k_part_sorted", "k_voxel_tiles2")
+        kp, kt = "k_part_sorted", "k_voxel_tiles2"
         ms = {kp: _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
               kt: _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
         dom = max(ms, key=ms.get)

@@ -77,11 +77,13 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
 
 @pytest.mark.parametrize("knobs", [{"EVK_SHARE_CU": "1"}, {"EVK_V2_XCD_ORDER": "0"}, {"EVK_VOXEL_PATH": "v1"},
                                    {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}, {"EVK_VOXEL2_TILE": "32x16"},
-                                   {"EVK_VOXEL2_TILE": "31x33"}, {"EVK_VOXEL_DETERMINISTIC": "1"}])
+                                   {"EVK_VOXEL2_TILE": "31x33"}, {"EVK_VOXEL_DETERMINISTIC": "1"}, {"EVK_V2_REC": "4"},
+                                   {"EVK_V2_REC": "4", "EVK_VOXEL_DETERMINISTIC": "1", "EVK_SHARE_CU": "1"}, {"EVK_V2_REC": "8"}])
 def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
     """The voxel fast path under its run-time switches: the partition geometry a multi-rank job gets (8 K-event
     sub-chunks, room for a collective's workgroups), plain work-item order, the round-1 three-pass path, power-of-two and
-    odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation."""
+    odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation, 4-byte compact records (the
+    default above 16 M events) and 8-byte records."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     for (n, H, W, B, seed) in ((700_001, 480, 640, 5, 3), (90_000, 100, 130, 3, 4)):
@@ -119,6 +121,44 @@ def test_voxel_deterministic_mode_is_bit_reproducible_at_full_size(E, monkeypatc
     with pytest.raises(ValueError):
         E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x[:400_000], y[:400_000], t[:400_000], p4)), B,
                                 sensor_size=(H, W))
+
+
+@pytest.mark.parametrize("kind", ["wide", "zero_one", "unsorted", "mixed", "early", "nan"])
+def test_compact_records_are_exact_for_any_input(E, monkeypatch, kind):
+    """4-byte records (t_norm delta | polarity code | cell): whatever does not fit -- polarities other than +-1 / 0, time
+    stamps that are unsorted, sparse or so close to ts[0] that float32 steps are tiny, NaN -- escapes to the exact side array;
+    the grid equals the oracle's, and the 8-byte-record grid of the same events bit for bit wherever no NaN is involved."""
+    n, H, W, B = 500_003, 260, 346, 5
+    x, y, t, p = _events(21, n, H, W)
+    rng = np.random.default_rng(5)
+    if kind == "wide":
+        p = (p * rng.uniform(0.1, 3.0, n)).astype(np.float32)
+    elif kind == "zero_one":
+        p = rng.integers(0, 2, n).astype(np.float32)
+    elif kind == "unsorted":
+        t = rng.permutation(t); t[0], t[-1] = 0.0, 0.1
+    elif kind == "mixed":
+        p[::7] = 0.25
+        t[n // 2: n // 2 + 4000] = t[n // 2: n // 2 + 4000][::-1]
+    elif kind == "early":
+        t = np.sort(np.concatenate([rng.uniform(0, 1e-9, n // 3), rng.uniform(0, 0.1, n - n // 3)])).astype(np.float32)
+        t[0] = 0.0
+    elif kind == "nan":       # the reference multiplies EVERY bin's weight by p: NaN * 0 = inf * 0 = NaN reach all B bins
+        p[5::1001] = np.nan
+        p[6::1013] = np.inf
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    monkeypatch.setenv("EVK_V2_REC", "4")
+    v4 = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
+    monkeypatch.setenv("EVK_V2_REC", "8")
+    v8 = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        for v in (v4, v8):
+            assert np.array_equal(np.isnan(v), np.isnan(ref)) and np.array_equal(np.isposinf(v), np.isposinf(ref))
+    ok = np.isfinite(ref)
+    scale = max(np.abs(ref[ok]).max(), 1e-30)
+    assert np.abs(v4[ok] - ref[ok]).max() <= TOL * scale and np.abs(v8[ok] - ref[ok]).max() <= TOL * scale
+    assert np.abs(v4[ok].astype(np.float64) - v8[ok]).max() <= 1e-6 * scale    # same per-event values, float64 sums
 
 
 def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):

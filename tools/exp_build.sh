@@ -1,6 +1,6 @@
 #!/bin/bash
-# Experiments build of libevk.so (-DEVK_EXPERIMENTS: every partition geometry of evk_voxel3.hip, the round-2 variants of
-# evk_voxel2.hip), loaded with EVK_LIB_PATH=tools/exp/libevk_exp.so.  Extra -D flags may be passed as arguments.
+# Experiments build of libevk.so (-DEVK_EXPERIMENTS: the partition geometries of evk_voxel2.hip that the product does not
+# ship, selected with EVK_V2_PART), loaded with EVK_LIB_PATH=tools/exp/libevk_exp.so.  Extra -D flags may be passed.
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/exp

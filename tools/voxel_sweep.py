@@ -1,6 +1,6 @@
-"""One-pass voxel path with 4-byte records (evk_voxel3.hip): correctness against the oracle on the cases that stress the
-record format (escapes: arbitrary polarities, unsorted / sparse time stamps, dt == 0; padding; hot tiles), then stage
-timings of one geometry (EVK_V3_EPT is read when the library first runs, so every variant is its own process)."""
+"""One-pass voxel path (evk_voxel2.hip): correctness against the oracle on the cases that stress the record formats (escapes
+of the 4-byte records: arbitrary polarities, unsorted / sparse time stamps; hot tiles; deterministic mode), then stage
+timings (EVK_V2_REC, EVK_V2_PART, EVK_V2_SPLIT ... are read when the library first runs: one process per variant)."""
 import os
 import sys
 
@@ -39,12 +39,11 @@ def check():
         x, y, t, p = synth(n, n, H, W, kind)
         cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
         ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
-        os.environ["EVK_VOXEL_PATH"] = "v3"
         a = _voxel_f32_device(*cols, B, (H, W), None, None, impl="tiled").cpu().numpy().astype(np.float64)
         b = _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), impl="tiled").cpu().numpy().astype(np.float64)
         tol = 1e-5 * np.abs(ref).max()
         ea, eb = np.abs(a - ref).max(), np.abs(b - ref).max()
-        print("check n=%d %dx%dx%d %-8s: v3(dev t) %.2e  v3 %.2e  tol %.2e  mass %.6f/%.6f  nan %d/%d" % (
+        print("check n=%d %dx%dx%d %-8s: device ts[0]/ts[-1] %.2e  host %.2e  tol %.2e  mass %.6f/%.6f  nan %d/%d" % (
             n, H, W, B, kind, ea, eb, tol, np.nansum(a), np.nansum(ref), np.isnan(a).sum(), np.isnan(ref).sum()), flush=True)
         assert ea <= tol and eb <= tol
     # repeated calls on the same persistent index (self-resetting counters) and a clustered scene (split hot tiles)
@@ -81,7 +80,7 @@ def scene(kind, n, H, W):
     return x, y, t, p
 
 
-def timing(n, H, W, B, reps=20, paths=("v3",), kind="uniform"):
+def timing(n, H, W, B, reps=20, paths=("v2",), kind="uniform"):
     x, y, t, p = synth(1, n, H, W) if kind == "uniform" else scene(kind, n, H, W)
     cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
     for path in paths:
@@ -111,10 +110,10 @@ def native_timing(n, H, W, B, reps=20):
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    print("variant: EVK_V3_GEO=%s LIB=%s" % (os.environ.get("EVK_V3_GEO", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
+    print("variant: EVK_V2_REC=%s EVK_V2_PART=%s LIB=%s" % (os.environ.get("EVK_V2_REC", "-"), os.environ.get("EVK_V2_PART", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
     if "--check" in sys.argv:
         check()
-    paths = ("v3", "v2") if "--v2" in sys.argv else ("v3",)
+    paths = ("v2", "v1") if "--v1" in sys.argv else ("v2",)
     timing(10_000_000, 480, 640, 5, paths=paths)
     if "--scenes" in sys.argv:
         timing(10_000_000, 480, 640, 5, paths=paths, kind="edges")
