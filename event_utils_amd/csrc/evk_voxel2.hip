@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 if (kl[s2] != 0xFFFFFFFFu) {
                     const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
                     const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
-                    const bool wide = (pbits & ~V2_P_MASK) != 0u;
+                    // (a polarity that is not finite is always "wide": the tile kernel treats it in its rare branch)
+                    const bool wide = ((pbits & ~V2_P_MASK) != 0u) | ((pbits & 0x7F800000u) == 0x7F800000u);
                     sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
                     if (wide) wide_mask |= 1u << s2, kl[s2] = pos;   // kl is dead from here on: keep the slot instead
                 }
@@ -549,12 +550,14 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
             lds_add(a, v);
         }
     };
-    auto bins_general = [&](acc_t *base, int local, float tn, float p) {   // any t_norm: voxel_bins_lds with `add`
-        if (tn != tn) {  // dt == 0 (Q9): NaN in every bin of the pixel
+    // any t_norm, any polarity (voxel_bins_lds with `add`): NaN t_norm (dt == 0, Q9) and a polarity that is not finite reach
+    // EVERY bin, as in the reference -- its p * weight is added for all B bins, and NaN * 0 = inf * 0 = NaN
+    auto bins_general = [&](acc_t *base, int local, float tn, float p) {
+        if (tn != tn) {
             for (int b = 0; b < B; ++b) add(base + b * ppix + local, tn * p);
             return;
         }
-        if (!(fabsf(p) <= 3.0e38f)) {  // a polarity that is not finite reaches EVERY bin (p * 0 = NaN), as in the reference
+        if (!(fabsf(p) <= 3.0e38f)) {
             for (int b = 0; b < B; ++b) add(base + b * ppix + local, p * fmaxf(0.0f, 1.0f - fabsf(tn - (float)b)));
             return;
         }
@@ -568,27 +571,35 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
             if (val != 0.0f) add(base + b * ppix + local, val);
         }
     };
+    // (The hot loop holds eight inlined copies of this per-record code, and its size matters: an extra inlined copy of the
+    // general path in the rare branch cost 4 %, an out-of-line function for the rare cases -- the call's register saves
+    // need scratch -- 15 %; a flag joining the range test 10 %.  A polarity that is not finite is therefore only looked for in
+    // the rare branches, where such records always end up because the partition marks them wide / escaped, and sends the
+    // record down the general path by POISONING the value the range test reads: the hot path is the two compares it was.)
     auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
         // REC 8: lo_w = t_norm bits, hi_w = polarity | cell.  REC 4: lo_w = the record word, hi_w = its sub-chunk's base.
         int local;
         float p, tn;
+        float tr;   // t_norm as the range test below sees it: poisoned (-1) in the rare branches for a polarity that is not finite
         if constexpr (REC == 8) {
             local = (int)(hi_w & V2_LOCAL_MASK);   // row * pitch + column
             p = __uint_as_float(hi_w & V2_P_MASK);
+            tn = tr = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
             if (hi_w & V2_WIDE) {   // rare: the exact float32 polarity from the side array.  The wait stays INSIDE the branch
                 p = pw[ridx];       // (builtin: the compiler's scoreboard sees it) -- at the join it would be a vmcnt(0) on
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // every event, i.e. the next round's record loads could never stay in flight
+                if (!SPLIT && !(fabsf(p) <= 3.0e38f)) tr = -1.0f;
             }
-            tn = __uint_as_float(lo_w);  // normalised time, computed by the partition kernel
         } else {
             local = (int)(lo_w & V2_LOCAL_MASK);
             const uint32_t code = (lo_w >> V2_CODE_SHIFT) & 3u;
             if (code == 3u) {       // rare: escaped record, the exact pair from the side array (same wait discipline)
                 const uint2 e = wide2[(uint64_t)(ridx / (uint32_t)q.S) * (uint32_t)q.S + (lo_w >> V2_DELTA_SHIFT)];
                 __builtin_amdgcn_s_waitcnt(0x0F70);
-                tn = __uint_as_float(e.x), p = __uint_as_float(e.y);
+                tn = tr = __uint_as_float(e.x), p = __uint_as_float(e.y);
+                if (!SPLIT && !(fabsf(p) <= 3.0e38f)) tr = -1.0f;
             } else {
-                tn = __uint_as_float(hi_w + (lo_w >> V2_DELTA_SHIFT));
+                tn = tr = __uint_as_float(hi_w + (lo_w >> V2_DELTA_SHIFT));
                 p = __uint_as_float(code == 2u ? 0u : (0x3F800000u | (code << 31)));
             }
         }
@@ -596,8 +607,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
-        if (__builtin_expect(tn >= 0.0f && tn <= bm1 && (SPLIT || fabsf(p) <= 3.0e38f), 1)) {
-            // the common case, straight-line: t inside [ts[0], ts[-1]] (and a finite polarity: any other reaches every bin).  Bins b0 = floor(t_norm) and b0 + 1 with the
+        if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
+            // the common case, straight-line: t inside [ts[0], ts[-1]].  Bins b0 = floor(t_norm) and b0 + 1 with the
             // weights of voxel_grid.py:138 -- 1 - |t_norm - b| evaluated exactly as there (for b0 the absolute value is
             // the identity; max(0, .) cannot bind for these two bins).  A zero weight is added like any other (x + 0 = x;
             // the reference's index_put_ adds it too): skipping it cost a compare and a branch per bin on every event.

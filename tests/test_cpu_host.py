@@ -279,3 +279,31 @@ def test_bench_with_more_gpus_than_the_box_has_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
+
+
+def test_voxel_kernels_compile_without_register_spills(tmp_path):
+    """The kernels the default voxel dispatch can reach -- k_part_sorted<1024, 8 | 12, 4 | 8, Src*> and k_voxel_tiles2<512, 2, *, *,
+    4 | 8> -- must not spill: scratch accesses share the load / store counter (gfx9 has ONE) and stall the software pipelines.
+    Cross-compiles evk_voxel2.hip for gfx950 (no GPU needed) and reads the code object's metadata."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.isfile(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    from event_utils_amd.csrc import build as B
+    src = os.path.join(B.HERE, "evk_voxel2.hip")
+    flags = [f for f in B.FLAGS if f not in ("-shared", "-ldl")]
+    subprocess.run([hipcc] + flags + ["-c", src, "-o", str(tmp_path / "v2.o"), "-save-temps=obj"], check=True, cwd=B.HERE,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert asm, os.listdir(tmp_path)
+    text = open(tmp_path / asm[0]).read()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    seen = {n: (int(v), int(sp)) for n, v, sp in kernels if "k_part_sorted" in n or "k_voxel_tiles2" in n}
+    assert len(seen) >= 12, sorted(seen)
+    spilled = {n: vs for n, vs in seen.items() if vs[1]}
+    assert not spilled, spilled
+    assert "Folded Spill" not in "".join(l for l in text.splitlines(True) if "scratch_" in l)
+    assert all(v <= 80 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n)       # three workgroups of 8 waves per CU
+    assert all(v <= 128 for n, (v, _) in seen.items() if "k_part_sorted" in n)
