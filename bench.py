@@ -153,7 +153,7 @@ def main():
     def timed(fn, steps, warm):
         # device wake-up (clocks, first-touch of every buffer, RCCL channel setup), then the W warm-up steps asked for:
         # with a small W the first timed steps would otherwise still be ramping
-        for i in range(30):
+        for i in range(300):     # ~25 ms: 30 steps (2.5 ms) left the first timed loop 5 % slower than the later ones
             fn(i)
         drain()
         for i in range(warm):
