@@ -44,8 +44,13 @@ namespace evk {
 // ablation builds (tools/v2_ablate.sh): stop the partition kernel's per-sub-chunk work after stage A (0 loads, 1 ranks,
 // 2 scan + table, 3 placement, 4 = everything) / the tile kernel's after stage B (0 table entries, 1 record loads,
 // 2 decode, 3 = everything).  Results are wrong below the last stage; timing only.
-#ifndef V2_TILES_MIN_WAVES
-#define V2_TILES_MIN_WAVES 6  // waves per SIMD the tile kernel must fit (<= 80 registers): 3 workgroups of 8 waves per CU
+// waves per SIMD the tile kernel must fit: 6 (<= 80 registers; 3 workgroups of 8 waves per CU) with 8-byte records, 4 (128
+// registers) with 4-byte records, and the table entries a lane takes per batch (see the kernel)
+#ifndef V2_TILES_WAVES
+#define V2_TILES_WAVES(REC) ((REC) == 4 ? 4 : 6)
+#endif
+#ifndef V2_ENT
+#define V2_ENT(REC) ((REC) == 4 ? 3 : 1)
 #endif
 #ifndef V2_XY_PREFETCH
 #define V2_XY_PREFETCH 1   // load x, y of sub-chunk j + 1 before the placement of j (else at the top of j + 1)
@@ -108,10 +113,20 @@ __device__ unsigned long long v2_phase_cycles[16];
         if ((threadIdx.x & 63) == 0)                                                \
             for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&v2_phase_cycles[i_], pa_[i_]); \
     } while (0)
+// (the same for the tile kernel's phases, v2_tile_cycles[])
+__device__ unsigned long long v2_tile_cycles[16];
+#define V2_U(i) V2_T(i)
+#define V2_UEND()                                                                  \
+    do {                                                                           \
+        if ((threadIdx.x & 63) == 0)                                               \
+            for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&v2_tile_cycles[i_], pa_[i_]); \
+    } while (0)
 #else
 #define V2_T0() do {} while (0)
 #define V2_T(i) do {} while (0)
 #define V2_TEND() do {} while (0)
+#define V2_U(i) do {} while (0)
+#define V2_UEND() do {} while (0)
 #endif
 
 struct Part2 {
@@ -154,8 +169,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     static_assert(EPT % G == 0, "events per thread");
     constexpr int PER_MAX = (V2_MAX_TILES + THREADS - 1) / THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint2 *sorted = reinterpret_cast<uint2 *>(smem);                           // [THREADS * EPT] + 2 (trash slot)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(sorted + THREADS * EPT + 2);  // [ntiles] counts of the current pass
+    uint2 *sorted = reinterpret_cast<uint2 *>(smem);                           // [THREADS * EPT] records + a trash slot
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + (size_t)THREADS * EPT * REC + 16);  // [ntiles] counts of the current pass
     uint32_t *cur = hist + ((ntiles + 4) & ~3);                                 // [ntiles] cursors of the current pass
     uint32_t *tot = cur + ((ntiles + 4) & ~3);                                  // [ntiles] this workgroup's totals
     uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [68] scan scratch; [67] escapes of the pass
@@ -474,7 +489,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 // in LDS (wave scan of the chunk counts) and hands them out to groups of 4 lanes, 16 bytes per lane: all lanes stay busy
 // whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 56
 // records (clustered scenes) are streamed by the whole wave instead.
+#ifndef V2_MAX_CHUNKS
 #define V2_MAX_CHUNKS 7    // chunks of a listed segment (longer ones are streamed by the whole wave)
+#endif
 #define V2_CHUNK_CAP (64 * V2_MAX_CHUNKS)  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
                                            // workgroups still fit a CU's 160 KB
 // FIXED (EVK_VOXEL_DETERMINISTIC): the cells are int64 multiples of 2^-32 instead of float64 -- integer adds commute, so the
@@ -482,12 +499,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 // counted in index[4] and left out (the wrapper raises).
 #define V2_FIXED_ONE 4294967296.0
 template <int WG, int U, bool SPLIT, bool FIXED, int REC>
-__global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const void *__restrict__ rec_, const void *__restrict__ side_,
+__global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const void *__restrict__ rec_, const void *__restrict__ side_,
                                                      const uint32_t *__restrict__ bases,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGridG g, Part2 q, int B, int flags, float *__restrict__ vox,
                                                      float *__restrict__ staging) {
-    constexpr int NW = WG / 64;
+    constexpr int NW = WG / 64, E = V2_ENT(REC);
     // REC 8: a lane takes 16 bytes = 2 records {t_norm, polarity | cell}; REC 4: 8 bytes = 2 one-word records (k_part_sorted),
     // decoded with the base of their sub-chunk, which travels with the chunk list
     typedef typename std::conditional<REC == 8, uint4, uint2>::type Pair;
@@ -507,6 +524,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
     __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP : 1];   // REC 4: t_norm base of the chunk's sub-chunk
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
+    V2_T0();
     const uint32_t nitems = part_start[ntiles];
     if (blockIdx.x >= nitems) return;
     // XCD-aware work-item order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), and the segments of NEIGHBOURING
@@ -533,7 +551,9 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
     // (64-bit fixed-point cells as in k_iwe_tiled -- ds_add_u64 is the faster LDS atomic -- with the scale from a max |p|
     // the partition kernel collects: no faster here (33.9 vs 34.6 us at 10 M events, 152.6 vs 148 us at 50 M) and the
     // extra bookkeeping in the placement pushed the partition kernel from 48 to 91 us.  Float64 cells stay.)
+    V2_U(0);
     for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
+    V2_U(1);
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
     const uint32_t *col = table + tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 3, grp = lane >> 2;
@@ -603,7 +623,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
                 p = __uint_as_float(code == 2u ? 0u : (0x3F800000u | (code << 31)));
             }
         }
-        if (V2_ABLATE_B < 3) {
+        if (V2_ABLATE_B < 2) {
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
@@ -621,9 +641,16 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
             }
             const int b0 = (int)tn;
             const float v0 = w * (1.0f - (tn - (float)b0)), v1 = w * (1.0f - fabsf(tn - (float)(b0 + 1)));
-            a += b0 * ppix;
+            // (b0 + 1 == B only for t_norm == B - 1, where v1 is a zero: added to bin B - 1, which it does not change, rather
+            // than branched around)
+            a += __mul24(b0, ppix);
+            if (V2_ABLATE_B < 3) {   // (timing builds) weights and addresses, no atomics
+                if (v0 + v1 == 1.2345e-30f) a[b0 + 1 < B ? ppix : 0] = 1.0;
+                return;
+            }
             add(a, v0);
-            if (b0 + 1 < B) add(a + ppix, v1);
+            if (V2_ABLATE_B < 4) return;   // (timing builds) one atomic per event
+            add(a + (b0 + 1 < B ? ppix : 0), v1);
         } else if (!split) {
             bins_general(acc, local, tn, p);
         } else if (tn != tn) {
@@ -635,69 +662,28 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
             bins_general(acc + B * ppix, local, tn, 1.0f);
         }
     };
-    auto pair = [&](const Pair &v, uint32_t bbits, uint32_t pos, uint32_t beg, uint32_t end) {  // records pos, pos + 1 of [beg, end)
+    // A lane's load: records pos, pos + 1 -- 16 (8) bytes at ANY record boundary: the chunks of a segment start at its first
+    // record, not at the 16-byte boundary below it (global loads need no more than dword alignment; with aligned chunks the
+    // first one of every other segment began with a record of the neighbouring tile: one lane idle and a test per pair)
+    typedef typename std::conditional<REC == 8, uint2, uint32_t>::type Rec1;
+    struct __attribute__((packed, aligned(REC))) PairU {
+        Pair v;
+    };
+    auto load_pair = [&](uint32_t pos) -> Pair { return reinterpret_cast<const PairU *>(static_cast<const Rec1 *>(rec_) + pos)->v; };
+    auto pair = [&](const Pair &v, uint32_t bbits, uint32_t pos, uint32_t end) {  // records pos, pos + 1 of a segment ending at `end`
         if constexpr (REC == 8) {
-            if (pos >= beg) one(v.x, v.y, pos);
+            one(v.x, v.y, pos);
             if (pos + 1 < end) one(v.z, v.w, pos + 1);
         } else {
-            if (pos >= beg) one(v.x, bbits, pos);
+            one(v.x, bbits, pos);
             if (pos + 1 < end) one(v.y, bbits, pos + 1);
         }
     };
-    // Entries go to the threads in equal batches, INTERLEAVED over the waves (slot = lane * NW + wave): a short range -- the
-    // last batch of a tile, or one of the many parts of a hot tile -- then still gives every wave its share instead of
-    // filling wave 0 first (1221 sub-chunks: 3 batches of 408 = 51 entries per wave, not 64, 64, 64 / 64, 5, 0 ...).
-    const int range = sc_hi - sc_lo, nbatch = (range + WG - 1) / WG;
-    const int bsz = nbatch ? ((range + nbatch - 1) / nbatch + NW - 1) / NW * NW : NW;  // <= WG, a multiple of NW
-    const int slot = lane * NW + wave;
-    uint32_t ent_next = 0, bb_next = 0;
-    {
-        const int my = sc_lo + slot;
-        if (slot < bsz && my < sc_hi) {
-            ent_next = col[(int64_t)my * q.nt_pad];
-            if constexpr (REC == 4) bb_next = bases[my];
-        }
-    }
-    for (int base = sc_lo; base < sc_hi; base += bsz) {
-        const uint32_t ent = ent_next, bb = bb_next;
-        {   // next batch's entries: in flight while this batch is processed
-            const int my = base + bsz + slot;
-            const bool have = slot < bsz && my < sc_hi;
-            ent_next = have ? col[(int64_t)my * q.nt_pad] : 0u;
-            if constexpr (REC == 4) bb_next = have ? bases[my] : 0u;
-        }
-        if (V2_ABLATE_B < 1) {
-            if (ent == 0xFFFFFFFFu) acc[0] = 1.0;
-            continue;
-        }
-        const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
-        const uint32_t span = cnt ? (start + cnt) - (start & ~1u) : 0u;  // records from the aligned start
-        const uint32_t nch = (span + 7u) >> 3;
-        const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
-        const uint32_t mych = is_long ? 0u : nch;
-        uint32_t incl = mych;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
-        __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
-        {
-            const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + (start & ~1u), e0 = rb + start + cnt;
-            for (uint32_t k = 0; k < mych; ++k) {
-                cseg[wave][excl + k] = make_uint2((p0 + 8u * k) | (k == 0 ? (start & 1u) : 0u), e0);
-                if constexpr (REC == 4) cbase[wave][excl + k] = bb;
-            }
-        }
-        __syncthreads();
-        // Chunk rounds, software-pipelined in three stages: list entries of round r + 2 (LDS) | record loads of round r + 1
-        // (global) | accumulation of round r.  The loads are UNCONDITIONAL -- a lane group without a chunk reads the head
-        // of the record buffer -- so that nothing but arithmetic sits between them and the compiler can wait for the
-        // older round alone (`vmcnt(U)`).  V2_PIPE=0 restores the plain issue / wait / accumulate rounds.
-        // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
-        // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
-        // while its 600 segments are pulled
+    // Chunk rounds over a wave's list of `total` chunks, software-pipelined in three stages: list entries of round r + 2
+    // (LDS) | record loads of round r + 1 (global) | accumulation of round r.  The loads are UNCONDITIONAL -- a lane group
+    // without a chunk reads the head of the record buffer -- so that nothing but arithmetic sits between them and the
+    // compiler can wait for the older round alone (`vmcnt(U)`).
+    auto rounds = [&](const uint32_t total) {
         auto meta = [&](uint32_t j0, uint2(&cs)[U], uint32_t(&cb_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -709,66 +695,225 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
         auto fire = [&](const uint2(&cs)[U], Pair(&v)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
-                v[u] = recp[(pos < cs[u].y ? pos : 2u * sub) >> 1];
+                const uint32_t pos = cs[u].x + 2u * sub;
+                v[u] = load_pair(pos < cs[u].y ? pos : 2u * sub);
             }
         };
         auto eat = [&](const uint2(&cs)[U], const uint32_t(&cb_)[U], const Pair(&v)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t pos = (cs[u].x & ~1u) + 2u * sub;
-                // beg == the segment's first record when it lies inside this chunk
-                if (pos < cs[u].y) pair(v[u], cb_[u], pos, (cs[u].x & ~1u) + (cs[u].x & 1u), cs[u].y);
+                const uint32_t pos = cs[u].x + 2u * sub;
+                if (pos < cs[u].y) pair(v[u], cb_[u], pos, cs[u].y);
             }
         };
         constexpr uint32_t step = 16u * U;
-        {
-            uint2 ca[U], cb[U], cn[U];
-            uint32_t ba[U] = {}, bbv[U] = {}, bn[U] = {};
-            Pair va[U], vb[U];
-            meta(0u, ca, ba);
-            fire(ca, va);
-            meta(step, cb, bbv);
-            for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
-                fire(cb, vb);               // round j0 + step
-                meta(j0 + 2u * step, cn, bn);
-                eat(ca, ba, va);            // round j0
-                fire(cn, va);               // round j0 + 2 step
+        uint2 ca[U], cb[U], cn[U];
+        uint32_t ba[U] = {}, bbv[U] = {}, bn[U] = {};
+        Pair va[U], vb[U];
+        meta(0u, ca, ba);
+        fire(ca, va);
+        meta(step, cb, bbv);
+        for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
+            fire(cb, vb);               // round j0 + step
+            meta(j0 + 2u * step, cn, bn);
+            eat(ca, ba, va);            // round j0
+            fire(cn, va);               // round j0 + 2 step
 #pragma unroll
-                for (int u = 0; u < U; ++u) ca[u] = cn[u], ba[u] = bn[u];
-                meta(j0 + 3u * step, cn, bn);
-                eat(cb, bbv, vb);           // round j0 + step
+            for (int u = 0; u < U; ++u) ca[u] = cn[u], ba[u] = bn[u];
+            meta(j0 + 3u * step, cn, bn);
+            eat(cb, bbv, vb);           // round j0 + step
 #pragma unroll
-                for (int u = 0; u < U; ++u) cb[u] = cn[u], bbv[u] = bn[u];
+            for (int u = 0; u < U; ++u) cb[u] = cn[u], bbv[u] = bn[u];
+        }
+    };
+    // A long segment [b2, e3) (> 7 chunks = 56 records; clustered scenes, the parts of a hot tile): the whole wave streams it,
+    // 16 bytes per lane, four loads per lane in flight (with one dependent load at a time a part was a chain of ~2 us round
+    // trips)
+    auto stream_segment = [&](const uint32_t b2, const uint32_t e3, const uint32_t b2b) {
+        for (uint32_t p2 = b2 + 2u * lane; p2 < e3; p2 += 512u) {
+            Pair v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t pu = p2 + 128u * u;
+                v[u] = load_pair(pu < e3 ? pu : p2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t pu = p2 + 128u * u;
+                if (pu < e3) pair(v[u], b2b, pu, e3);
             }
         }
-        // long segments (> 7 chunks = 56 records): the whole wave streams each of them, 16 bytes per lane
-        uint64_t m = __ballot(is_long);
-        while (m) {
-            const int s = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
-            const uint32_t st = e2 & 0xFFFFu, cn = e2 >> 16;
-            const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
-            const uint32_t b2 = rb + st, e3 = b2 + cn;
-            // four loads per lane in flight (the parts of a hot tile are all long segments: with one dependent load at a
-            // time a part was a chain of ~2 us round trips)
-            for (uint32_t p2 = rb + (st & ~1u) + 2u * lane; p2 < e3; p2 += 512u) {
-                Pair v[4];
+    };
+    auto wave_scan = [&](uint32_t v) {   // inclusive
+        uint32_t incl = v;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t pu = p2 + 128u * u;
-                    v[u] = recp[(pu < e3 ? pu : p2) >> 1];
-                }
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        return incl;
+    };
+    const int range = sc_hi - sc_lo;
+    if constexpr (E > 1) {
+        // E table entries per lane and batch (HBM-resident calls, whose 4-byte records come with two workgroups per CU anyway
+        // -- 80 KB of LDS at 720p -- so the registers of E entries are free): a tile's column of ~4000 sub-chunks is 3 batches
+        // instead of 8, each with one list build and one fill and drain of the load pipeline (50 M events: 154 -> 143 us;
+        // at 10 M events / VGA nothing, and the 128-register budget costs the structured scenes their third workgroup per
+        // CU: E = 1 there).  Entry i of a batch goes to wave i % NW, there to lane (i / NW) % 64, register (i / NW) / 64.  When
+        // a wave's chunks do not fit its list (clustered scenes: many segments of 5-7 chunks) it takes its registers one at a
+        // time.  The lists are wave-private and a wave's LDS operations execute in order: no barrier inside the batch.
+        const int nbatch = (range + WG * E - 1) / (WG * E);
+        const int bsz = nbatch ? ((range + nbatch - 1) / nbatch + NW - 1) / NW * NW : NW;  // <= WG * E, a multiple of NW
+        auto fetch = [&](int base, uint32_t(&en)[E], uint32_t(&bn)[E]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t pu = p2 + 128u * u;
-                    if (pu < e3) pair(v[u], b2b, pu, b2, e3);
+            for (int e = 0; e < E; ++e) {
+                const int idx = (e * 64 + lane) * NW + wave, my = base + idx;
+                const bool have = idx < bsz && my < sc_hi;
+                en[e] = have ? col[(int64_t)my * q.nt_pad] : 0u;
+                bn[e] = 0u;
+                if constexpr (REC == 4) bn[e] = have ? bases[my] : 0u;
+            }
+        };
+        __syncthreads();  // the accumulators are zero before the first adds
+        for (int base = sc_lo; base < sc_hi; base += bsz) {
+            // (no prefetch of the next batch's entries, and entries are fetched again where a rare path needs them after
+            // the rounds: their registers are what the hot loop needs)
+            uint32_t ent[E], bb[E];
+            uint32_t sum = 0, longs = 0, packed = 0;   // packed: chunks of entry e in bits [4e, 4e + 4)
+            fetch(base, ent, bb);
+            auto mych_of = [&](int e) { return (packed >> (4 * e)) & 15u; };
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t start = ent[e] & 0xFFFFu, cnt = ent[e] >> 16;
+                const uint32_t nch = (cnt + 7u) >> 3;
+                const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
+                packed |= (is_long ? 0u : nch) << (4 * e);
+                sum += is_long ? 0u : nch;
+                longs |= is_long ? (1u << e) : 0u;
+            }
+            const uint32_t incl_all = wave_scan(sum);
+            const bool fits = __shfl(incl_all, 63, 64) <= (uint32_t)V2_CHUNK_CAP;
+            const int npass = fits ? 1 : E;
+            V2_U(2);
+            V2_U(3);
+            for (int pass = 0; pass < npass; ++pass) {
+                uint32_t mine = sum, incl = incl_all;
+                if (pass > 0) fetch(base, ent, bb);
+                if (!fits) {
+                    mine = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) mine = e == pass ? mych_of(e) : mine;
+                    incl = wave_scan(mine);
                 }
+                const uint32_t total = __shfl(incl, 63, 64);
+                uint32_t w = incl - mine;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (!fits && e != pass) continue;
+                    const uint32_t start = ent[e] & 0xFFFFu, cnt = ent[e] >> 16;
+                    const uint32_t rb = (uint32_t)(base + (e * 64 + lane) * NW + wave) * (uint32_t)q.S, p0 = rb + start, e0 = p0 + cnt;
+                    const uint32_t mc = mych_of(e);
+                    for (uint32_t k = 0; k < mc; ++k) {
+                        cseg[wave][w + k] = make_uint2(p0 + 8u * k, e0);
+                        if constexpr (REC == 4) cbase[wave][w + k] = bb[e];
+                    }
+                    w += mc;
+                }
+                V2_U(4);
+                V2_U(5);
+                rounds(total);
+            }
+            V2_U(6);
+            // long segments: listed in the (consumed) chunk list, then streamed one after the other
+            uint32_t nlong = 0;
+            if (__ballot(longs != 0u)) {
+                uint32_t ent2[E], bb2[E];
+                fetch(base, ent2, bb2);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool il = (longs >> e) & 1u;
+                    const uint64_t m = __ballot(il);
+                    if (il) {
+                        const uint32_t st = ent2[e] & 0xFFFFu, cn = ent2[e] >> 16;
+                        const uint32_t rb = (uint32_t)(base + (e * 64 + lane) * NW + wave) * (uint32_t)q.S;
+                        const uint32_t at = nlong + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        cseg[wave][at] = make_uint2(rb + st, rb + st + cn);
+                        if constexpr (REC == 4) cbase[wave][at] = bb2[e];
+                    }
+                    nlong += (uint32_t)__builtin_popcountll(m);
+                }
+            }
+            for (uint32_t i = 0; i < nlong; ++i) {
+                const uint2 sg = cseg[wave][i];
+                uint32_t b2b = 0u;
+                if constexpr (REC == 4) b2b = cbase[wave][i];
+                stream_segment(sg.x, sg.y, b2b);
+            }
+        }
+    } else {
+        // Entries go to the threads in equal batches, INTERLEAVED over the waves (slot = lane * NW + wave): a short range --
+        // the last batch of a tile, or one of the many parts of a hot tile -- then still gives every wave its share instead
+        // of filling wave 0 first (1221 sub-chunks: 3 batches of 408 = 51 entries per wave, not 64, 64, 64 / 64, 5, 0 ...).
+        const int nbatch = (range + WG - 1) / WG;
+        const int bsz = nbatch ? ((range + nbatch - 1) / nbatch + NW - 1) / NW * NW : NW;  // <= WG, a multiple of NW
+        const int slot = lane * NW + wave;
+        uint32_t ent_next = 0, bb_next = 0;
+        {
+            const int my = sc_lo + slot;
+            if (slot < bsz && my < sc_hi) {
+                ent_next = col[(int64_t)my * q.nt_pad];
+                if constexpr (REC == 4) bb_next = bases[my];
+            }
+        }
+        for (int base = sc_lo; base < sc_hi; base += bsz) {
+            const uint32_t ent = ent_next, bb = bb_next;
+            {   // next batch's entries: in flight while this batch is processed
+                const int my = base + bsz + slot;
+                const bool have = slot < bsz && my < sc_hi;
+                ent_next = have ? col[(int64_t)my * q.nt_pad] : 0u;
+                if constexpr (REC == 4) bb_next = have ? bases[my] : 0u;
+            }
+            if (V2_ABLATE_B < 1) {
+                if (ent == 0xFFFFFFFFu) acc[0] = 1.0;
+                continue;
+            }
+            const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
+            const uint32_t nch = (cnt + 7u) >> 3;
+            const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
+            const uint32_t mych = is_long ? 0u : nch;
+            const uint32_t incl = wave_scan(mych);
+            const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
+            V2_U(2);
+            __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
+            V2_U(3);
+            {
+                const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + start, e0 = p0 + cnt;
+                for (uint32_t k = 0; k < mych; ++k) {
+                    cseg[wave][excl + k] = make_uint2(p0 + 8u * k, e0);
+                    if constexpr (REC == 4) cbase[wave][excl + k] = bb;
+                }
+            }
+            V2_U(4);
+            // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
+            // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
+            // while its 600 segments are pulled
+            __syncthreads();
+            V2_U(5);
+            rounds(total);
+            V2_U(6);
+            uint64_t m = __ballot(is_long);
+            while (m) {
+                const int s = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
+                const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
+                stream_segment(rb + (e2 & 0xFFFFu), rb + (e2 & 0xFFFFu) + (e2 >> 16), b2b);
             }
         }
     }
+    V2_U(7);
     __syncthreads();
+    V2_U(8);
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
     auto split_cell = [&](int c, int &b, int &row, int &col) {   // dense cell c = (plane, row, column) of the tile
         b = (int)div_magic((uint32_t)c, g.mp);
@@ -797,6 +942,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_MIN_WAVES) k_voxel_tiles2(const v
     };
     if (nparts == 1) {
         flush(lds_cell);
+        V2_U(9);
+        V2_UEND();
         return;
     }
     // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
@@ -863,6 +1010,11 @@ static const V2Config &v2_config(bool share = false, int ntiles = 0) {
     return ntiles > 680 ? large : small;
 }
 #define V2_MIN_SUBCHUNK 8192
+#define V2_LDS_LIMIT (160 * 1024 - 512)   // (the partition kernel also has a few bytes of static LDS)
+// LDS of the partition kernel: sorted records | counts | cursors | totals | scan scratch
+static size_t v2_part_lds(int threads, int ept, int rec, int ntiles) {
+    return (size_t)threads * ept * rec + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
+}
 
 static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
     const V2Config &c = v2_config(share, ntiles);
@@ -971,20 +1123,17 @@ extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
 
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
 extern "C" int evk_voxel2_max_tiles(void) {
-    const int64_t budget = (int64_t)160 * 1024 - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
+    const int64_t budget = (int64_t)V2_LDS_LIMIT - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
     const int64_t t = budget / 12;   // a counter, a cursor and a total per tile
     return (int)(t < V2_MAX_TILES ? (t > 0 ? t : 0) : V2_MAX_TILES);
 }
 
-static size_t v2_part_lds(int threads, int ept, int ntiles) {   // sorted records | counts | cursors | totals | scan scratch
-    return (size_t)threads * ept * 8 + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 68 * 4 + 16;
-}
 
 template <int THREADS, int EPT, int REC, typename C>
 static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part2 &q, float t_first, float t_last,
                         float bm1, int t_from_events, void *rec, void *pw, uint32_t *bases, uint32_t *table, uint32_t *index,
                         uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
-    const size_t lds = v2_part_lds(THREADS, EPT, ntiles);
+    const size_t lds = v2_part_lds(THREADS, EPT, REC, ntiles);
     static std::once_flag once[64];   // per device and instantiation: the attribute belongs to the loaded code object
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1063,12 +1212,19 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // 81 against 68 us, its many pieces then waiting for slots)
         const size_t lds_dyn = lds_acc;
         const bool sp = flags & EVK_VOXEL_SPLIT_POLARITY, fx = flags & EVK_VOXEL_DETERMINISTIC;
+#ifndef V2_U4
+#define V2_U4 2   // chunk loads per lane in flight, 4-byte records
+#endif
+#ifndef V2_U8
+#define V2_U8 2   // ... 8-byte records
+#endif
+#define V2_UU(R) ((R) == 4 ? V2_U4 : V2_U8)
 #define V2_TILES(R)                                                                                                        \
     do {                                                                                                                   \
-        if (sp && fx) launch_tiles<512, 2, true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (sp) launch_tiles<512, 2, true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (fx) launch_tiles<512, 2, false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else launch_tiles<512, 2, false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
+        if (sp && fx) launch_tiles<512, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (sp) launch_tiles<512, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (fx) launch_tiles<512, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else launch_tiles<512, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
     } while (0)
         if (recb == 4) V2_TILES(4);
         else V2_TILES(8);
@@ -1097,6 +1253,11 @@ extern "C" int evk_debug_phase_cycles(unsigned long long *host16) {
     unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(v2_phase_cycles), sizeof(z)) != hipSuccess) return EVK_EINVAL;
     return hipMemcpyToSymbol(HIP_SYMBOL(v2_phase_cycles), z, sizeof(z)) == hipSuccess ? EVK_OK : EVK_EINVAL;
+}
+extern "C" int evk_debug_tile_cycles(unsigned long long *host16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(v2_tile_cycles), sizeof(z)) != hipSuccess) return EVK_EINVAL;
+    return hipMemcpyToSymbol(HIP_SYMBOL(v2_tile_cycles), z, sizeof(z)) == hipSuccess ? EVK_OK : EVK_EINVAL;
 }
 #endif
 

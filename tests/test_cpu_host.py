@@ -305,5 +305,8 @@ def test_voxel_kernels_compile_without_register_spills(tmp_path):
     spilled = {n: vs for n, vs in seen.items() if vs[1]}
     assert not spilled, spilled
     assert "Folded Spill" not in "".join(l for l in text.splitlines(True) if "scratch_" in l)
-    assert all(v <= 80 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n)       # three workgroups of 8 waves per CU
+    # 8-byte records: three workgroups of 8 waves per CU; 4-byte records (HBM-resident calls, two workgroups per CU by their
+    # LDS): 128 registers, three table entries per lane and batch (evk_voxel2.hip, k_voxel_tiles2)
+    assert all(v <= 80 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n and "ELi8EEEv" in n)
+    assert all(v <= 128 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n)
     assert all(v <= 128 for n, (v, _) in seen.items() if "k_part_sorted" in n)
