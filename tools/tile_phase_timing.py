@@ -14,10 +14,16 @@ from event_utils_amd.representations.voxel_grid import _voxel_f32_device  # noqa
 
 torch.cuda.set_device(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "uniform"       # uniform | edges | blob (tools/voxel_sweep.py)
 H, W, B = (480, 640, 5) if n <= 20_000_000 else (720, 1280, 5)
-rng = np.random.default_rng(1)
-x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
-t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+if kind == "uniform":
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+else:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import voxel_sweep
+    x, y, t, p = [np.ascontiguousarray(a) for a in voxel_sweep.scene(kind, n, H, W)]
 cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
 out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
 run = lambda: _voxel_f32_device(*cols, B, (H, W), float(t[0]), float(t[-1]), out=out, check=False, impl="tiled", fresh=True)
@@ -35,7 +41,9 @@ L.evk_debug_tile_cycles(buf)
 names = ["plan loads", "zero accumulators", "table entry wait + scan", "barrier 1", "list build", "barrier 2", "chunk rounds",
          "long segments", "final barrier", "flush"]
 tw, th = tiled.voxel2_shape(H, W, B)
+
 waves = L.evk_voxel2_num_tiles(H, W, tw, th) * 8
+print("scene %s, %d tiles" % (kind, waves // 8))
 tot = 0.0
 for i, nm in enumerate(names):
     cyc = buf[i] / reps / waves        # average cycles per wave per call
