@@ -1057,6 +1057,13 @@ static const V2Split &v2_split() {
     }();
     return f;
 }
+static int v2_tiles_wg() {   // EVK_V2_TILES_WG=512 keeps the 512-thread tile workgroups everywhere (A/B measurements)
+    static const int v = [] {
+        const char *s = getenv("EVK_V2_TILES_WG");
+        return s ? atoi(s) : 0;
+    }();
+    return v;
+}
 static int64_t v2_mean(int64_t n, int ntiles) { return n / (ntiles > 0 ? ntiles : 1); }
 static int64_t v2_cap(int64_t n, int ntiles) {   // a tile with more events than this is cut ...
     const int64_t c = (int64_t)(v2_split().at * (double)v2_mean(n, ntiles));
@@ -1219,15 +1226,22 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
 #define V2_U8 2   // ... 8-byte records
 #endif
 #define V2_UU(R) ((R) == 4 ? V2_U4 : V2_U8)
-#define V2_TILES(R)                                                                                                        \
+#define V2_TILES(W, R)                                                                                                     \
     do {                                                                                                                   \
-        if (sp && fx) launch_tiles<512, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (sp) launch_tiles<512, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (fx) launch_tiles<512, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else launch_tiles<512, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
+        if (sp && fx) launch_tiles<W, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (sp) launch_tiles<W, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else if (fx) launch_tiles<W, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
+        else launch_tiles<W, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
     } while (0)
-        if (recb == 4) V2_TILES(4);
-        else V2_TILES(8);
+        // Threads per tile workgroup.  8-byte records (cache-resident calls): 768 -- twelve waves per tile -- while TWO such
+        // workgroups fit a CU's LDS (accumulators + 12 chunk lists <= 80 KB: VGA at 5 bins; not split polarities or 720p
+        // tiles).  Uniform events do not care (29.5 us either way, 512 tiles in one generation); the pieces of a hot tile are
+        // done sooner: blob scene 57 -> 49 us, i.e. 1.25 x the uniform call end to end.  4-byte records (HBM-resident calls, three
+        // table entries per lane, 128 registers): 512 (768: 151-158 against 132-142 us at 50 M events).
+        const bool wide_wg = recb == 8 && 2 * (lds_acc + (size_t)12 * 8 * V2_CHUNK_CAP + 256) <= (size_t)160 * 1024 && v2_tiles_wg() != 512;
+        if (recb == 4) V2_TILES(512, 4);
+        else if (wide_wg) V2_TILES(768, 8);
+        else V2_TILES(512, 8);
 #undef V2_TILES
     }
     return launch_status();
