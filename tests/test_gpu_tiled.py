@@ -161,6 +161,35 @@ def test_compact_records_are_exact_for_any_input(E, monkeypatch, kind):
     assert np.abs(v4[ok].astype(np.float64) - v8[ok]).max() <= 1e-6 * scale    # same per-event values, float64 sums
 
 
+@pytest.mark.parametrize("scene", ["band", "blob"])
+def test_compact_records_with_three_entries_per_lane_on_structured_scenes(E, scene, monkeypatch):
+    """4-byte records take three table entries per lane and batch (k_voxel_tiles2, E = 3).  13 M events make a tile's column
+    longer than one wave's first 64 entries, and a structured scene then exercises what uniform events never do: a band at
+    three times the mean density gives every entry 4-7 chunks -- a wave's three entries per lane overflow its chunk list and it
+    falls back to one entry at a time -- and a blob gives long segments (streamed by the whole wave) and cut tiles."""
+    n, H, W, B = 13_000_000, 480, 640, 5
+    x, y, t, p = _events(41, n, H, W)
+    rng = np.random.default_rng(8)
+    hot = rng.random(n) < (0.45 if scene == "band" else 0.6)
+    if scene == "band":
+        # 45 % of the events in a fifth of the rows: 2.75 x the mean per tile -- below the cut at 3 x, so a tile keeps its whole
+        # column of ~1590 entries, ~44 records = 6 chunks each: ~1190 chunks per wave against a list of 448
+        y[hot] = rng.integers(200, 296, hot.sum()).astype(np.float32)
+    else:
+        x[hot] = (W // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
+        y[hot] = (H // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    monkeypatch.setenv("EVK_V2_REC", "4")
+    for _ in range(2):
+        close(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy(), ref)
+    monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
+    a = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    b = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    assert torch.equal(a, b)
+    close(a.cpu().numpy(), ref)
+
+
 def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):
     """Split-polarity tile kernel with fixed-point cells: both grids bit-reproducible and equal to the float64 accumulation
     (unit weights: every partial sum is exactly representable either way)."""
