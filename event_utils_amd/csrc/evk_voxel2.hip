@@ -544,8 +544,14 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // wave's events share a column and differ in the row (moving-edge scene: 66 us against 36 us on uniform events).
     // The records carry row * pitch + column (evk_part.h): the cell index itself.
     const int tpitch = g.pitch, ppix = tpitch * th;   // cells per accumulator plane
-    const int tile = (int)item_tile[item];
-    const uint32_t first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
+    // (no tile cut <=> as many items as tiles: the plan is the identity, and two dependent loads -- ~1.3 us at the head of
+    // every workgroup of a launch whose workgroups all start together -- are not made)
+    int tile = (int)item;
+    uint32_t first_item = item, nparts = 1u;
+    if (nitems != (uint32_t)ntiles) {
+        tile = (int)item_tile[item];
+        first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
+    }
     const uint32_t part_id = item - first_item;
     const int tx0 = (tile % g.tiles_x) * tw, ty0 = (tile / g.tiles_x) * th;
     // (64-bit fixed-point cells as in k_iwe_tiled -- ds_add_u64 is the faster LDS atomic -- with the scale from a max |p|
