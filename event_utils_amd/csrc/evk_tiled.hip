@@ -489,31 +489,29 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
         return;
     }
     // Split (hot) tile: every part stores its partial tile, the LAST part to arrive sums them in part order
-    // (deterministic) and writes the output.  Hand-off per cdna_hip_programming.md G16: drained plain stores ->
-    // barrier -> one-lane agent release -> counter; last arriver: one-lane agent acquire -> barrier -> plain loads.
+    // (deterministic) and writes the output.  Hand-off with agent-scope (sc1) stores and loads on both sides
+    // (MI355X_MICROARCH.md, valid forms): every wave drains its stores -> barrier -> one lane takes the ticket; the last
+    // arriver reads the partial tiles with agent-scope loads.  No release / acquire fence (= a write-back of the XCD's L2).
     const int cells = NB * tpix;
     float *mine = staging + (int64_t)blockIdx.x * cells;
-    for (int c = threadIdx.x; c < cells; c += EVK_BLOCK) mine[c] = (float)acc[c];
+    for (int c = threadIdx.x; c < cells; c += EVK_BLOCK)
+        __hip_atomic_store(mine + c, (float)acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int is_last;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t *counter = index + IDX_COUNTER(ntiles) + tile;
         const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (prev == nparts - 1);
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        }
+        if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
     if (!is_last) return;
     const float *parts = staging + (int64_t)first_item * cells;
     flush([&](int c) {
         float sum = 0.0f;
-        for (uint32_t p = 0; p < nparts; ++p) sum += parts[(int64_t)p * cells + c];
+        for (uint32_t p = 0; p < nparts; ++p)
+            sum += __hip_atomic_load(parts + (int64_t)p * cells + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return sum;
     });
 }
