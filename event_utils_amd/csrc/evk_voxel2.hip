@@ -29,7 +29,9 @@ namespace evk {
 #ifndef V2_PIPE
 #define V2_PIPE 1
 #endif
-#define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info)
+#define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info),
+                             // [4] contributions the deterministic mode refused, [5] events whose polarity is not +1, -1 or
+                             // +0 (cumulative), [6] its value after the previous call, [7] 1 if THIS call had any
 #define V2_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
 #define V2_TOTALS V2_HDR
 #define V2_PART (V2_HDR + V2_MAX_TILES)            // part_start[T + 1]
@@ -38,6 +40,7 @@ namespace evk {
 #ifndef V2_LB
 #define V2_LB 10  // bits of the pixel-in-tile field (tiles of <= 2^V2_LB pixels); the polarity keeps 32 - V2_LB - 1 bits
 #endif
+#define EVK_VOXEL2_COUNT (1 << 20)   // kernel-internal flag: the launch has the LDS of the counting mode (k_voxel_tiles2)
 #define V2_LOCAL_MASK ((1u << V2_LB) - 1u)
 #define V2_WIDE (1u << V2_LB)
 #define V2_P_MASK (~((2u << V2_LB) - 1u))
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t *sorted4 = reinterpret_cast<uint32_t *>(smem);                     // REC 4: the same buffer, one word per record
     __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63;
-    uint32_t dropped = 0, nwide = 0;
+    uint32_t dropped = 0, nwide = 0;   // nwide: wide / escaped records in the low half, polarities other than +-1, +0 in the high
     float tb = 0.0f;   // REC 4: time stamp of the sub-chunk's first event
     if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
     const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
@@ -369,6 +372,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                     const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
                     // (a polarity that is not finite is always "wide": the tile kernel treats it in its rare branch)
                     const bool wide = ((pbits & ~V2_P_MASK) != 0u) | ((pbits & 0x7F800000u) == 0x7F800000u);
+                    nwide += (((pbits & 0x7FFFFFFFu) == 0x3F800000u) | (pbits == 0u)) ? 0u : 0x10000u;
                     sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
                     if (wide) wide_mask |= 1u << s2, kl[s2] = pos;   // kl is dead from here on: keep the slot instead
                 }
@@ -389,6 +393,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 // becomes a switch with divergent branches)
                 const uint32_t code = (pb & 0x7FFFFFFFu) == 0x3F800000u ? pb >> 31 : 3u - (uint32_t)(pb == 0u);
                 const bool live = kl[s2] != 0xFFFFFFFFu;
+                nwide += (live & (code == 3u)) ? 0x10000u : 0u;
                 const bool esc = live & ((code == 3u) | (d >= V2_DELTA_LIMIT));
                 uint32_t word = (d << V2_DELTA_SHIFT) | (code << V2_CODE_SHIFT) | (kl[s2] & V2_LOCAL_MASK);
                 if (__any(esc)) {   // rare, wave-uniform test: the exact pair to the side array, its index into the record
@@ -420,7 +425,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     // (131 K atomics at 10 M events / 512 tiles: 1.5 us of the kernel, measured by leaving them out)
     for (int i = tid; i < ntiles; i += THREADS)
         if (tot[i]) __hip_atomic_fetch_add(gidx + V2_TOTALS + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (nwide) __hip_atomic_fetch_add(gidx + 3, nwide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nwide & 0xFFFFu) __hip_atomic_fetch_add(gidx + 3, nwide & 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nwide >> 16) __hip_atomic_fetch_add(gidx + 5, nwide >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (sc0 < sc_end) write_out();   // the last pass's run
     V2_T(8);
     V2_T(9);
@@ -478,6 +484,11 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     if (tid == 0) {
         part_start[ntiles] = total_parts;
         __hip_atomic_store(gidx + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {   // did THIS call see a polarity other than +1, -1, +0?  (the tile kernel counts unit polarities with integers)
+            const uint32_t now = __hip_atomic_load(gidx + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gidx[7] = now != gidx[6] ? 1u : 0u;
+            gidx[6] = now;
+        }
         if (host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
                             // in pinned memory, so that a deferred error check costs no copy and no event on the stream
             const uint32_t cnt = oob ? __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -496,9 +507,11 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 // whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 56
 // records (clustered scenes) are streamed by the whole wave instead.
 #ifndef V2_MAX_CHUNKS
-#define V2_MAX_CHUNKS 7    // chunks of a listed segment (longer ones are streamed by the whole wave)
+// chunks of a listed segment (longer ones are streamed by the whole wave): 7 = 56 records; 6 with 768-thread workgroups, whose
+// twelve lists then leave room for the counting mode's accumulators of TWO workgroups per CU (VGA, 5 bins: 2 x 78.7 KB)
+#define V2_MAX_CHUNKS(WG) ((WG) == 768 ? 6 : 7)
 #endif
-#define V2_CHUNK_CAP (64 * V2_MAX_CHUNKS)  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
+#define V2_CHUNK_CAP(WG) (64 * V2_MAX_CHUNKS(WG))  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
                                            // workgroups still fit a CU's 160 KB
 // FIXED (EVK_VOXEL_DETERMINISTIC): the cells are int64 multiples of 2^-32 instead of float64 -- integer adds commute, so the
 // grid is bit-identical from run to run and for any order of the events.  |contribution| < 2^30 and finite, else it is
@@ -526,8 +539,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // segment}: ONE LDS read gives a lane group everything it needs for its load (a 2-byte (segment, chunk) entry followed
     // by a ds_bpermute of the table entry put two dependent LDS round trips, queued behind other waves' atomics, in front
     // of every load)
-    __shared__ uint2 cseg[NW][V2_CHUNK_CAP];
-    __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP : 1];   // REC 4: t_norm base of the chunk's sub-chunk
+    __shared__ uint2 cseg[NW][V2_CHUNK_CAP(WG)];
+    __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP(WG) : 1];   // REC 4: t_norm base of the chunk's sub-chunk
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
     V2_T0();
@@ -563,8 +576,25 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // (64-bit fixed-point cells as in k_iwe_tiled -- ds_add_u64 is the faster LDS atomic -- with the scale from a max |p|
     // the partition kernel collects: no faster here (33.9 vs 34.6 us at 10 M events, 152.6 vs 148 us at 50 M) and the
     // extra bookkeeping in the placement pushed the partition kernel from 48 to 91 us.  Float64 cells stay.)
+    // UNIT-POLARITY COUNTING (round 3).  When every polarity of the call is +1, -1 or +0 (what the reference's loaders
+    // produce; the partition kernel reports it in index[7]) an event's two contributions p (1 - f) and p f to bins b0 and
+    // b0 + 1 (f = t_norm - b0) are not added as two float64 LDS atomics: the event adds p to an INTEGER count S0[b0] and
+    // p f to ONE float64 cell G[b0], and the flush forms  grid[b] = S0[b] - G[b] + G[b - 1].  An int32 LDS atomic costs a
+    // fraction of a float64 one (and the second weight is never computed): tile kernel 29.5 -> 24.5 us at 10 M events.  The
+    // sums differ from the reference's only in that p (1 - f) is not rounded to float32 per event (< 6e-8 per event, random
+    // sign; the bar is 1e-5 of the grid's maximum).  Events outside [ts[0], ts[-1]] touch an edge bin only: bin 0 through
+    // G[-1] (the planes are G[-1 .. B-1]), bin B - 1 through -G[B - 1]; a NaN t_norm goes to every G.  Costs LDS: (B + 1)
+    // float64 + B int32 planes -- the host enables it (EVK_VOXEL2_COUNT in `flags`) where two workgroups still fit a CU.
+    constexpr bool COUNTING = !SPLIT && !FIXED;
+    const bool unit = COUNTING && (flags & EVK_VOXEL2_COUNT) && index[7] == 0u;
+    int *const s0 = reinterpret_cast<int *>(acc + (B + 1) * ppix);   // unit mode: acc = G[-1 .. B-1], then S0[0 .. B-1]
     V2_U(0);
-    for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
+    if (unit) {
+        for (int i = threadIdx.x; i < (B + 1) * ppix; i += WG) acc[i] = 0.0;
+        for (int i = threadIdx.x; i < B * ppix; i += WG) s0[i] = 0;
+    } else {
+        for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
+    }
     V2_U(1);
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
     const uint32_t *col = table + tile;
@@ -608,7 +638,21 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // need scratch -- 15 %; a flag joining the range test 10 %.  A polarity that is not finite is therefore only looked for in
     // the rare branches, where such records always end up because the partition marks them wide / escaped, and sends the
     // record down the general path by POISONING the value the range test reads: the hot path is the two compares it was.)
-    auto one = [&](uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
+    // unit mode, t_norm outside [0, B - 1] or NaN: see above
+    auto unit_general = [&](int local, float tn, float p) {
+        acc_t *gp = acc + local;   // plane k holds G[k - 1]
+        if (tn != tn) {
+            for (int k = 0; k <= B; ++k) add(gp + k * ppix, tn * p);
+        } else if (tn < 0.0f) {
+            const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - 0.0f));
+            if (val != 0.0f) add(gp, val);
+        } else {
+            const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - bm1));
+            if (val != 0.0f) add(gp + B * ppix, -val);
+        }
+    };
+    auto one = [&](auto unit_tag, uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
+        constexpr bool UNIT = decltype(unit_tag)::value;
         // REC 8: lo_w = t_norm bits, hi_w = polarity | cell.  REC 4: lo_w = the record word, hi_w = its sub-chunk's base.
         int local;
         float p, tn;
@@ -637,6 +681,17 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         }
         if (V2_ABLATE_B < 2) {
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
+            return;
+        }
+        if constexpr (UNIT) {
+            if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
+                const int b0 = (int)tn;
+                const int off = __mul24(b0, ppix) + local;
+                add(acc + ppix + off, p * (tn - (float)b0));                                      // G[b0] += p f
+                __hip_atomic_fetch_add(s0 + off, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // S0[b0] += p
+            } else {
+                unit_general(local, tn, p);
+            }
             return;
         }
         if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
@@ -682,20 +737,20 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         Pair v;
     };
     auto load_pair = [&](uint32_t pos) -> Pair { return reinterpret_cast<const PairU *>(static_cast<const Rec1 *>(rec_) + pos)->v; };
-    auto pair = [&](const Pair &v, uint32_t bbits, uint32_t pos, uint32_t end) {  // records pos, pos + 1 of a segment ending at `end`
+    auto pair = [&](auto unit_tag, const Pair &v, uint32_t bbits, uint32_t pos, uint32_t end) {  // records pos, pos + 1 of a segment ending at `end`
         if constexpr (REC == 8) {
-            one(v.x, v.y, pos);
-            if (pos + 1 < end) one(v.z, v.w, pos + 1);
+            one(unit_tag, v.x, v.y, pos);
+            if (pos + 1 < end) one(unit_tag, v.z, v.w, pos + 1);
         } else {
-            one(v.x, bbits, pos);
-            if (pos + 1 < end) one(v.y, bbits, pos + 1);
+            one(unit_tag, v.x, bbits, pos);
+            if (pos + 1 < end) one(unit_tag, v.y, bbits, pos + 1);
         }
     };
     // Chunk rounds over a wave's list of `total` chunks, software-pipelined in three stages: list entries of round r + 2
     // (LDS) | record loads of round r + 1 (global) | accumulation of round r.  The loads are UNCONDITIONAL -- a lane group
     // without a chunk reads the head of the record buffer -- so that nothing but arithmetic sits between them and the
     // compiler can wait for the older round alone (`vmcnt(U)`).
-    auto rounds = [&](const uint32_t total) {
+    auto rounds = [&](auto unit_tag, const uint32_t total) {
         auto meta = [&](uint32_t j0, uint2(&cs)[U], uint32_t(&cb_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -715,7 +770,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t pos = cs[u].x + 2u * sub;
-                if (pos < cs[u].y) pair(v[u], cb_[u], pos, cs[u].y);
+                if (pos < cs[u].y) pair(unit_tag, v[u], cb_[u], pos, cs[u].y);
             }
         };
         constexpr uint32_t step = 16u * U;
@@ -741,7 +796,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // A long segment [b2, e3) (> 7 chunks = 56 records; clustered scenes, the parts of a hot tile): the whole wave streams it,
     // 16 bytes per lane, four loads per lane in flight (with one dependent load at a time a part was a chain of ~2 us round
     // trips)
-    auto stream_segment = [&](const uint32_t b2, const uint32_t e3, const uint32_t b2b) {
+    auto stream_segment = [&](auto unit_tag, const uint32_t b2, const uint32_t e3, const uint32_t b2b) {
         for (uint32_t p2 = b2 + 2u * lane; p2 < e3; p2 += 512u) {
             Pair v[4];
 #pragma unroll
@@ -752,7 +807,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t pu = p2 + 128u * u;
-                if (pu < e3) pair(v[u], b2b, pu, e3);
+                if (pu < e3) pair(unit_tag, v[u], b2b, pu, e3);
             }
         }
     };
@@ -766,6 +821,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         return incl;
     };
     const int range = sc_hi - sc_lo;
+    auto batches = [&](auto unit_tag) {
     if constexpr (E > 1) {
         // E table entries per lane and batch (HBM-resident calls, whose 4-byte records come with two workgroups per CU anyway
         // -- 80 KB of LDS at 720p -- so the registers of E entries are free): a tile's column of ~4000 sub-chunks is 3 batches
@@ -798,13 +854,13 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             for (int e = 0; e < E; ++e) {
                 const uint32_t start = ent[e] & 0xFFFFu, cnt = ent[e] >> 16;
                 const uint32_t nch = (cnt + 7u) >> 3;
-                const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
+                const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
                 packed |= (is_long ? 0u : nch) << (4 * e);
                 sum += is_long ? 0u : nch;
                 longs |= is_long ? (1u << e) : 0u;
             }
             const uint32_t incl_all = wave_scan(sum);
-            const bool fits = __shfl(incl_all, 63, 64) <= (uint32_t)V2_CHUNK_CAP;
+            const bool fits = __shfl(incl_all, 63, 64) <= (uint32_t)V2_CHUNK_CAP(WG);
             const int npass = fits ? 1 : E;
             V2_U(2);
             V2_U(3);
@@ -833,7 +889,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 }
                 V2_U(4);
                 V2_U(5);
-                rounds(total);
+                rounds(unit_tag, total);
             }
             V2_U(6);
             // long segments: listed in the (consumed) chunk list, then streamed one after the other
@@ -859,7 +915,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 const uint2 sg = cseg[wave][i];
                 uint32_t b2b = 0u;
                 if constexpr (REC == 4) b2b = cbase[wave][i];
-                stream_segment(sg.x, sg.y, b2b);
+                stream_segment(unit_tag, sg.x, sg.y, b2b);
             }
         }
     } else {
@@ -891,7 +947,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             }
             const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
             const uint32_t nch = (cnt + 7u) >> 3;
-            const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS;
+            const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
             const uint32_t mych = is_long ? 0u : nch;
             const uint32_t incl = wave_scan(mych);
             const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
@@ -911,7 +967,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             // while its 600 segments are pulled
             __syncthreads();
             V2_U(5);
-            rounds(total);
+            rounds(unit_tag, total);
             V2_U(6);
             uint64_t m = __ballot(is_long);
             while (m) {
@@ -919,9 +975,16 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 m &= m - 1;
                 const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
                 const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
-                stream_segment(rb + (e2 & 0xFFFFu), rb + (e2 & 0xFFFFu) + (e2 >> 16), b2b);
+                stream_segment(unit_tag, rb + (e2 & 0xFFFFu), rb + (e2 & 0xFFFFu) + (e2 >> 16), b2b);
             }
         }
+    }
+    };
+    if constexpr (COUNTING) {
+        if (unit) batches(std::true_type{});
+        else batches(std::false_type{});
+    } else {
+        batches(std::false_type{});
     }
     V2_U(7);
     __syncthreads();
@@ -948,7 +1011,9 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     auto lds_cell = [&](int c) -> float {   // dense cell c -> padded LDS layout
         int b, row, col;
         split_cell(c, b, row, col);
-        const acc_t a = acc[b * ppix + row * tpitch + col];
+        const int l = row * tpitch + col;
+        if (unit) return (float)(((double)s0[b * ppix + l] - acc[(b + 1) * ppix + l]) + acc[b * ppix + l]);
+        const acc_t a = acc[b * ppix + l];
         if constexpr (FIXED) return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V2_FIXED_ONE));
         return (float)a;
     };
@@ -1071,12 +1136,15 @@ static const V2Split &v2_split() {
     }();
     return f;
 }
+// (the three switches below are read on EVERY call -- a getenv costs nothing next to a launch --, so that one process can
+// run the variants side by side: the tests do)
+static bool v2_count_enabled() {   // EVK_V2_COUNT=0: no unit-polarity counting in the tile kernel (A/B measurements, tests)
+    const char *s = getenv("EVK_V2_COUNT");
+    return !(s && s[0] == '0');
+}
 static int v2_tiles_wg() {   // EVK_V2_TILES_WG=512 keeps the 512-thread tile workgroups everywhere (A/B measurements)
-    static const int v = [] {
-        const char *s = getenv("EVK_V2_TILES_WG");
-        return s ? atoi(s) : 0;
-    }();
-    return v;
+    const char *s = getenv("EVK_V2_TILES_WG");
+    return s ? atoi(s) : 0;
 }
 static int64_t v2_mean(int64_t n, int ntiles) { return n / (ntiles > 0 ? ntiles : 1); }
 static int64_t v2_cap(int64_t n, int ntiles) {   // a tile with more events than this is cut ...
@@ -1095,12 +1163,9 @@ static int v2_max_items(int64_t n, int ntiles) { return ntiles + (int)(n / v2_pa
 // code / escape arithmetic costs what the bytes save, the tile kernel's extra decode 6 % (10 M events: 0.0838 against
 // 0.0792 ms): 8-byte records.  EVK_V2_REC=4|8 forces one (measurements, tests).
 static int v2_rec_bytes(int64_t n) {
-    static const int forced = [] {
-        const char *s = getenv("EVK_V2_REC");
-        const int v = s ? atoi(s) : 0;
-        return (v == 4 || v == 8) ? v : 0;
-    }();
-    if (forced) return forced;
+    const char *s = getenv("EVK_V2_REC");
+    const int forced = s ? atoi(s) : 0;
+    if (forced == 4 || forced == 8) return forced;
     return n * 16 > ((int64_t)256 << 20) ? 4 : 8;
 }
 struct V2Layout {
@@ -1179,7 +1244,7 @@ static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *r
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {
         (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED, REC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP - 256);
+                                  160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP(WG) - 256);
     });
     k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging);
 }
@@ -1199,7 +1264,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
-    const size_t lds_static = 12 * 8 * V2_CHUNK_CAP + 64;                  // the tile kernel's chunk lists (512 threads)
+    const size_t lds_static = 12 * 8 * V2_CHUNK_CAP(512) + 64;             // the tile kernel's chunk lists (512 threads, either record size)
     if (lds_acc + lds_static > 150 * 1024) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const V2Layout L = v2_layout(ntiles, n, planes, tile_w, tile_h, share);
@@ -1228,12 +1293,19 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int items = v2_max_items(n, ntiles);
-        const int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
+        int kf = flags & (EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_NO_XCD_ORDER);
         // (512 tiles on 768 workgroup slots: the dispatcher spreads them evenly by itself -- asking for more LDS than the
         // accumulators need, so that a CU holds exactly its share, changed nothing for uniform events and cost the blob scene
         // 81 against 68 us, its many pieces then waiting for slots)
-        const size_t lds_dyn = lds_acc;
         const bool sp = flags & EVK_VOXEL_SPLIT_POLARITY, fx = flags & EVK_VOXEL_DETERMINISTIC;
+        // LDS of a tile workgroup: its accumulators (dynamic) + one chunk list per wave (static).  The counting mode
+        // (k_voxel_tiles2: B + 1 float64 and B int32 planes instead of B float64 planes) and the 768-thread workgroups are taken
+        // while TWO workgroups still fit a CU -- that is what the 512 tiles of a VGA call need.
+        const size_t lds_count = ((size_t)(B + 1) * sizeof(acc_t) + (size_t)B * 4) * g.pitch * g.th;
+        auto two_fit = [](size_t acc_bytes, int wg, int rec) {
+            return 2 * (acc_bytes + (size_t)(rec == 4 ? 12 : 8) * (wg / 64) * V2_CHUNK_CAP(wg) + 256) <= (size_t)160 * 1024;
+        };
+        const bool may_count = !sp && !fx && v2_count_enabled() && n < ((int64_t)1 << 31);   // (int32 counts)
 #ifndef V2_U4
 #define V2_U4 2   // chunk loads per lane in flight, 4-byte records
 #endif
@@ -1253,7 +1325,15 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // tiles).  Uniform events do not care (29.5 us either way, 512 tiles in one generation); the pieces of a hot tile are
         // done sooner: blob scene 57 -> 49 us, i.e. 1.25 x the uniform call end to end.  4-byte records (HBM-resident calls, three
         // table entries per lane, 128 registers): 512 (768: 151-158 against 132-142 us at 50 M events).
-        const bool wide_wg = recb == 8 && 2 * (lds_acc + (size_t)12 * 8 * V2_CHUNK_CAP + 256) <= (size_t)160 * 1024 && v2_tiles_wg() != 512;
+        const bool may_wide = recb == 8 && v2_tiles_wg() != 512;
+        int wg = 512;
+        bool count = false;
+        if (may_wide && may_count && two_fit(lds_count, 768, recb)) wg = 768, count = true;
+        else if (may_count && two_fit(lds_count, 512, recb)) count = true;
+        else if (may_wide && two_fit(lds_acc, 768, recb)) wg = 768;
+        const size_t lds_dyn = count ? lds_count : lds_acc;
+        if (count) kf |= EVK_VOXEL2_COUNT;
+        const bool wide_wg = wg == 768;
         if (recb == 4) V2_TILES(512, 4);
         else if (wide_wg) V2_TILES(768, 8);
         else V2_TILES(512, 8);

@@ -310,7 +310,10 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  * (float32 t | 21-bit polarity | pixel in tile; polarities that need more bits go, exactly, to a side array) with a
  * (tile, sub-chunk) table, and a tile kernel that pulls every tile's segments and accumulates in LDS (float64) --
  * the events are read once and written once (24 B/event + the grid instead of 56).  Same per-event arithmetic and
- * results as evk_voxel_f32 / evk_voxel_tiled_f32.
+ * results as evk_voxel_f32 / evk_voxel_tiled_f32 -- with one exception: a call all of whose polarities are +1, -1 or +0
+ * (and whose accumulators fit, see DESIGN.md K2') is accumulated as an integer count and one float64 sum per bin,
+ * grid[b] = S0[b] - G[b] + G[b-1], i.e. without rounding p (1 - f) to float32 per event (differences < 6e-8 per event,
+ * the parity bar is 1e-5 of the grid's maximum); EVK_V2_COUNT=0 in the environment keeps the two float64 atomics.
  *   index    evk_voxel2_index_len(ntiles, n) uint32, ZEROED ONCE by the caller when it is allocated; the library
  *            leaves its counters at zero after every call (persistent across calls on one stream)
  *   scratch  evk_voxel2_scratch_bytes(...) bytes, 16-byte aligned, uninitialised

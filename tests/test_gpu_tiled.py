@@ -78,12 +78,15 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
 @pytest.mark.parametrize("knobs", [{"EVK_SHARE_CU": "1"}, {"EVK_V2_XCD_ORDER": "0"}, {"EVK_VOXEL_PATH": "v1"},
                                    {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}, {"EVK_VOXEL2_TILE": "32x16"},
                                    {"EVK_VOXEL2_TILE": "31x33"}, {"EVK_VOXEL_DETERMINISTIC": "1"}, {"EVK_V2_REC": "4"},
-                                   {"EVK_V2_REC": "4", "EVK_VOXEL_DETERMINISTIC": "1", "EVK_SHARE_CU": "1"}, {"EVK_V2_REC": "8"}])
+                                   {"EVK_V2_REC": "4", "EVK_VOXEL_DETERMINISTIC": "1", "EVK_SHARE_CU": "1"}, {"EVK_V2_REC": "8"},
+                                   {"EVK_V2_COUNT": "0"}, {"EVK_V2_COUNT": "0", "EVK_V2_REC": "4"}, {"EVK_V2_TILES_WG": "512"},
+                                   {"EVK_V2_TILES_WG": "512", "EVK_V2_COUNT": "0"}])
 def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
     """The voxel fast path under its run-time switches: the partition geometry a multi-rank job gets (8 K-event
     sub-chunks, room for a collective's workgroups), plain work-item order, the round-1 three-pass path, power-of-two and
     odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation, 4-byte compact records (the
-    default above 16 M events) and 8-byte records."""
+    default above 16 M events) and 8-byte records, with and without the unit-polarity counting mode, 512- and 768-thread tile
+    workgroups.  (The library reads these switches on every call.)"""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     for (n, H, W, B, seed) in ((700_001, 480, 640, 5, 3), (90_000, 100, 130, 3, 4)):
@@ -188,6 +191,35 @@ def test_compact_records_with_three_entries_per_lane_on_structured_scenes(E, sce
     b = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
     assert torch.equal(a, b)
     close(a.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("count", ["1", "0"])
+@pytest.mark.parametrize("rec", ["8", "4"])
+def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monkeypatch, count, rec):
+    """The tile kernel's counting mode (unit polarities: an integer count per bin + ONE float64 sum, grid[b] = S0[b] - G[b] +
+    G[b - 1]) against the oracle, with everything that leaves its straight-line path: a time range narrower than the stream
+    (events up to a bin width outside [ts[0], ts[-1]] still reach the edge bins, those further out nothing), events exactly on
+    the range's ends and on bin boundaries, zero polarities, a hot pixel (cut tiles); accumulate and overwrite mode.  Then a
+    polarity of 0.5 anywhere in the stream must switch the call to the float64 path (same oracle, same bar)."""
+    from event_utils_amd.representations.voxel_grid import _voxel_f32_device
+    monkeypatch.setenv("EVK_V2_COUNT", count)
+    monkeypatch.setenv("EVK_V2_REC", rec)
+    n, H, W, B = 900_000, 480, 640, 5
+    x, y, t, p = _events(12, n, H, W)
+    p[::11] = 0.0
+    x[: n // 4] = 300; y[: n // 4] = 200
+    t_lo, t_hi = np.float32(0.03), np.float32(0.07)          # the stream spans [0, 0.1]: a bin is 0.01 wide
+    t[1000:1100] = t_lo; t[2000:2100] = t_hi; t[3000:3100] = t_lo + (t_hi - t_lo) * np.float32(0.5)
+    t = np.sort(t)
+    for pp in (p, np.where(np.arange(n) == n // 2, np.float32(0.5), p).astype(np.float32)):
+        ref = R.events_to_voxel_torch(x, y, t, pp, B, sensor_size=(H, W), accum="f64", t_range=(t_lo, t_hi))
+        cols = [torch.from_numpy(a).cuda() for a in (x, y, t, pp)]
+        for _ in range(2):
+            v = _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), impl="tiled", check=False)
+            close(v.cpu().numpy(), ref)
+        base = torch.full((B, H, W), 1.5, device="cuda")
+        _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), out=base, impl="tiled", check=False)
+        close(base.cpu().numpy() - 1.5, ref, 1e-4)
 
 
 def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):
