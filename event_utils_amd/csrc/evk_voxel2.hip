@@ -579,19 +579,27 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // UNIT-POLARITY COUNTING (round 3).  When every polarity of the call is +1, -1 or +0 (what the reference's loaders
     // produce; the partition kernel reports it in index[7]) an event's two contributions p (1 - f) and p f to bins b0 and
     // b0 + 1 (f = t_norm - b0) are not added as two float64 LDS atomics: the event adds p to an INTEGER count S0[b0] and
-    // p f to ONE float64 cell G[b0], and the flush forms  grid[b] = S0[b] - G[b] + G[b - 1].  An int32 LDS atomic costs a
-    // fraction of a float64 one (and the second weight is never computed): tile kernel 29.5 -> 24.5 us at 10 M events.  The
-    // sums differ from the reference's only in that p (1 - f) is not rounded to float32 per event (< 6e-8 per event, random
-    // sign; the bar is 1e-5 of the grid's maximum).  Events outside [ts[0], ts[-1]] touch an edge bin only: bin 0 through
-    // G[-1] (the planes are G[-1 .. B-1]), bin B - 1 through -G[B - 1]; a NaN t_norm goes to every G.  Costs LDS: (B + 1)
-    // float64 + B int32 planes -- the host enables it (EVK_VOXEL2_COUNT in `flags`) where two workgroups still fit a CU.
+    // p f, as a multiple of 2^-31, to ONE int64 cell G[b0], and the flush forms  grid[b] = S0[b] - G[b] + G[b - 1].  An
+    // int32 LDS atomic costs a fraction of a float64 one, the int64 one two thirds -- and much less when a wave's events
+    // share cells, as on edges --, and the second weight is never computed: tile kernel 29.5 -> 24 us at 10 M uniform events,
+    // 41 -> 30 us on the moving-edge scene.  Integer adds commute: such a call's grid is BIT-REPRODUCIBLE from run to run.
+    // f is a float32 in [0, 1): exact in 2^-31 steps unless below 2^-7 (truncated by < 5e-10).  The sums differ from the
+    // reference's in that p (1 - f) is not rounded to float32 per event (< 6e-8 per event, random sign; the bar is 1e-5 of
+    // the grid's maximum).  Events outside [ts[0], ts[-1]] touch an edge bin only: bin 0 through G[-1] (the planes are
+    // G[-1 .. B-1]), bin B - 1 through -G[B - 1]; a NaN t_norm (dt == 0) poisons its cell in every bin: one bit per cell.
+    // Costs LDS: (B + 1) int64 + B int32 planes -- the host enables it (EVK_VOXEL2_COUNT in `flags`) where two workgroups
+    // still fit a CU.
+    constexpr double G_ONE = 2147483648.0;   // 2^31
+    __shared__ uint32_t poison[(1 << V2_LB) / 32];
     constexpr bool COUNTING = !SPLIT && !FIXED;
     const bool unit = COUNTING && (flags & EVK_VOXEL2_COUNT) && index[7] == 0u;
     int *const s0 = reinterpret_cast<int *>(acc + (B + 1) * ppix);   // unit mode: acc = G[-1 .. B-1], then S0[0 .. B-1]
     V2_U(0);
+    unsigned long long *const gq = reinterpret_cast<unsigned long long *>(acc);   // unit mode: G as int64
     if (unit) {
         for (int i = threadIdx.x; i < (B + 1) * ppix; i += WG) acc[i] = 0.0;
         for (int i = threadIdx.x; i < B * ppix; i += WG) s0[i] = 0;
+        if (threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
     } else {
         for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
     }
@@ -640,15 +648,19 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // record down the general path by POISONING the value the range test reads: the hot path is the two compares it was.)
     // unit mode, t_norm outside [0, B - 1] or NaN: see above
     auto unit_general = [&](int local, float tn, float p) {
-        acc_t *gp = acc + local;   // plane k holds G[k - 1]
+        unsigned long long *gp = gq + local;   // plane k holds G[k - 1]
         if (tn != tn) {
-            for (int k = 0; k <= B; ++k) add(gp + k * ppix, tn * p);
+            __hip_atomic_fetch_or(poison + (local >> 5), 1u << (local & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (tn < 0.0f) {
             const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - 0.0f));
-            if (val != 0.0f) add(gp, val);
+            if (val != 0.0f)
+                __hip_atomic_fetch_add(gp, (unsigned long long)__double2ll_rn((double)val * G_ONE), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - bm1));
-            if (val != 0.0f) add(gp + B * ppix, -val);
+            if (val != 0.0f)
+                __hip_atomic_fetch_add(gp + B * ppix, (unsigned long long)__double2ll_rn(-(double)val * G_ONE), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     auto one = [&](auto unit_tag, uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
@@ -687,8 +699,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
                 const int b0 = (int)tn;
                 const int off = __mul24(b0, ppix) + local;
-                add(acc + ppix + off, p * (tn - (float)b0));                                      // G[b0] += p f
-                __hip_atomic_fetch_add(s0 + off, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // S0[b0] += p
+                // G[b0] += p f (in 2^-31 steps: |p f| < 1 fits an int32), S0[b0] += p
+                const int fx = (int)((p * (tn - (float)b0)) * 2147483648.0f);
+                __hip_atomic_fetch_add(gq + ppix + off, (unsigned long long)(long long)fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s0 + off, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 unit_general(local, tn, p);
             }
@@ -1012,7 +1026,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         int b, row, col;
         split_cell(c, b, row, col);
         const int l = row * tpitch + col;
-        if (unit) return (float)(((double)s0[b * ppix + l] - acc[(b + 1) * ppix + l]) + acc[b * ppix + l]);
+        if (unit) {   // exact integer combination, one rounding to float32
+            if ((poison[l >> 5] >> (l & 31)) & 1u) return __uint_as_float(0x7FC00000u);
+            const long long v = ((long long)s0[b * ppix + l] << 31) - (long long)gq[(b + 1) * ppix + l] + (long long)gq[b * ppix + l];
+            return (float)((double)v * (1.0 / G_ONE));
+        }
         const acc_t a = acc[b * ppix + l];
         if constexpr (FIXED) return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V2_FIXED_ONE));
         return (float)a;

@@ -220,6 +220,17 @@ def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monke
         base = torch.full((B, H, W), 1.5, device="cuda")
         _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), out=base, impl="tiled", check=False)
         close(base.cpu().numpy() - 1.5, ref, 1e-4)
+        if count == "1" and pp is p:      # integer sums: the same bits on every run
+            a = _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), impl="tiled", check=False)
+            assert torch.equal(a, v)
+    # dt == 0 (Q9): every t_norm is NaN (0 / 0) -- the reference's NaN weights reach every bin of every pixel that holds an event
+    tz = np.full(n, 0.05, dtype=np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = R.events_to_voxel_torch(x, y, tz, p, B, sensor_size=(H, W), accum="f64")
+    v = _voxel_f32_device(*[torch.from_numpy(a).cuda() for a in (x, y, tz, p)], B, (H, W), 0.05, 0.05, impl="tiled", check=False)
+    v = v.cpu().numpy()
+    assert np.array_equal(np.isnan(v), np.isnan(ref)) and np.isnan(ref).any()
+    assert np.all(v[~np.isnan(ref)] == 0.0)
 
 
 def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):
