@@ -1139,14 +1139,15 @@ static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 // piece to arrive sums the partial tiles).  Two numbers, because cutting costs (a staging store, a ticket, the combine --
 // measured on the moving-edge scene, where most tiles hold 1.5-3 x the mean: cutting everything above 1.5 x made the kernel
 // 30 % slower, 41 -> 53 us) but a blob that holds half of the events in twenty tiles must become many small pieces (cut at
-// 4 x into pieces of < 4 x: 111 us; into pieces of ~1 x: see DESIGN.md).  Uniform events are never cut.
+// 4 x into pieces of < 4 x: 111 us; into pieces of ~1 x: see DESIGN.md).  Uniform events are never cut.  (3 / 1.5 until
+// the tile kernel counted unit polarities and ran 768 threads; with both a piece is cheaper: 2.5 / 1.25, blob 48.5 -> 43.5 us.)
 // EVK_V2_SPLIT="at,part" overrides (measurements).
 struct V2Split {
     double at, part;
 };
 static const V2Split &v2_split() {
     static const V2Split f = [] {
-        V2Split v{3.0, 1.5};
+        V2Split v{2.5, 1.25};
         const char *s = getenv("EVK_V2_SPLIT");
         double a = 0, p = 0;
         if (s && sscanf(s, "%lf,%lf", &a, &p) == 2 && a >= 1.0 && p >= 0.25 && p <= a) v = V2Split{a, p};

@@ -173,10 +173,10 @@ def test_compact_records_with_three_entries_per_lane_on_structured_scenes(E, sce
     n, H, W, B = 13_000_000, 480, 640, 5
     x, y, t, p = _events(41, n, H, W)
     rng = np.random.default_rng(8)
-    hot = rng.random(n) < (0.45 if scene == "band" else 0.6)
+    hot = rng.random(n) < (0.35 if scene == "band" else 0.6)
     if scene == "band":
-        # 45 % of the events in a fifth of the rows: 2.75 x the mean per tile -- below the cut at 3 x, so a tile keeps its whole
-        # column of ~1590 entries, ~44 records = 6 chunks each: ~1190 chunks per wave against a list of 448
+        # 35 % of the events in a fifth of the rows: 2.4 x the mean per tile -- below the cut at 2.5 x, so a tile keeps its whole
+        # column of ~1590 entries, ~38 records = 5 chunks each: ~990 chunks per wave against a list of 448
         y[hot] = rng.integers(200, 296, hot.sum()).astype(np.float32)
     else:
         x[hot] = (W // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
