@@ -458,6 +458,13 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t *part_start = index + V2_PART, *counters = index + V2_COUNTER(ntiles), *item_tile = index + V2_ITEM(ntiles);
     uint32_t tt[PER_MAX];
     uint32_t np = 0;
+    // (this block is the tail of the whole kernel: the three loads its last lines need are issued here, ahead of the scan)
+    uint32_t now5 = 0, prev6 = 0, cnt_oob = 0;
+    if (tid == 0) {
+        now5 = __hip_atomic_load(gidx + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev6 = gidx[6];
+        if (host_report && oob) cnt_oob = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
         const int i = i0 + k;
@@ -484,14 +491,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     if (tid == 0) {
         part_start[ntiles] = total_parts;
         __hip_atomic_store(gidx + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        {   // did THIS call see a polarity other than +1, -1, +0?  (the tile kernel counts unit polarities with integers)
-            const uint32_t now = __hip_atomic_load(gidx + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gidx[7] = now != gidx[6] ? 1u : 0u;
-            gidx[6] = now;
-        }
+        // did THIS call see a polarity other than +1, -1, +0?  (the tile kernel counts unit polarities with integers)
+        gidx[7] = now5 != prev6 ? 1u : 0u;
+        gidx[6] = now5;
         if (host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
                             // in pinned memory, so that a deferred error check costs no copy and no event on the stream
-            const uint32_t cnt = oob ? __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t cnt = cnt_oob;
             // {seq, count} as ONE 8-byte system-scope store: the pair cannot be seen torn, and no release (a write-back of the
             // L2 at the very end of the kernel's critical path) is needed to order two stores
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_report),
