@@ -25,8 +25,10 @@ int evk_post_variance_publish(int mode, const float *iwe, const float *diwe, int
 // host polls that flag: no copy command, no stream synchronisation (their completion signal + wake-up cost ~15 us per
 // evaluation, a fifth of a 10 M-event evaluation).  Every 16 K polls the stream is queried so that a failed launch
 // cannot hang the caller.  EVK_CMAX_POLL=0 (or a post-pass that cannot publish) takes the copy + synchronise route.
-// (Letting the post-pass kernel finalise as well -- last workgroup by ticket, one launch less -- measured SLOWER: 69.9 vs
-// 66.6 us per 10 M-event evaluation; every workgroup then pays an agent-scope release before its ticket.)
+// (Letting the post-pass kernel finalise as well -- last workgroup of a plane by ticket, one launch less -- is SLOWER, with
+// or without fences: round 2, an agent-scope release per workgroup: 69.9 vs 66.6 us per 10 M-event evaluation; round 3, the
+// partial sums handed over with agent-scope stores and loads and a relaxed ticket, no fence: 70.1 vs 65.6 us -- every
+// one of the 300 short workgroups waits for its ticket to come back, and the last one then adds the partials alone.)
 struct HostSlot {
     double *vals = nullptr;    // 12 doubles
     uint32_t *flags = nullptr; // 3 sequence numbers, one per plane

@@ -41,60 +41,66 @@ __device__ __forceinline__ void block_sum(double (&acc)[K], double *partial_out)
 
 // WIDE: additionally out[4..7] = the raw sums tot[1..4] (generic objectives); stride of `out` per plane stays 4 or 8.
 // host_slot / host_flag (optional, pinned host memory): the block also stores its 4 results at host_slot[4 * plane ..] and
-// then `seq` at host_flag[plane] (system-scope release), so that a host thread polling the flag has the results without
+// then `seq` at host_flag[plane] (system-scope stores, the store counter drained in between), so that a host thread polling the flag has the results without
 // a copy command or a stream synchronisation (evk_cmax.hip).
 struct HostPublish {
     double *slot;
     uint32_t *flag;
     uint32_t seq;
 };
+// The results of one image plane from its total sums (thread 0 of the finalising workgroup), and their delivery to the host.
+// The four doubles and then the sequence number go out as system-scope stores with the store counter drained in between: the
+// host cannot see the flag before the values, and no release fence -- a write-back of the XCD's L2, on the path the host is
+// waiting on -- is needed to order them.
+template <int MODE, bool WIDE>
+__device__ __forceinline__ void finalise_plane(const double *tot, int64_t n, double *out, const HostPublish &pub, int plane) {
+    const double inv = 1.0 / (double)n;
+    const double mean = tot[0] * inv;
+    if constexpr (MODE == 0) {
+        out[0] = mean;
+        out[1] = tot[1] * inv - mean * mean;
+        out[2] = tot[0];
+        out[3] = tot[1];
+    } else {
+        // mean(2*(a-mean)*d_i) = 2/n * (sum(a*d_i) - mean*sum(d_i))
+        out[0] = 2.0 * inv * (tot[3] - mean * tot[1]);
+        out[1] = 2.0 * inv * (tot[4] - mean * tot[2]);
+        out[2] = mean;
+        out[3] = tot[0];
+        if constexpr (MODE == 3) {  // value + gradient: [g0, g1, mean v, var v] of the blurred image v
+            const double mv = tot[5] * inv;
+            out[2] = mv;
+            out[3] = tot[6] * inv - mv * mv;
+        }
+    }
+    if constexpr (WIDE && MODE == 0) {  // stats: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
+        out[4] = tot[2], out[5] = tot[3], out[6] = tot[4], out[7] = 0.0;
+    }
+    if constexpr (WIDE && MODE == 1) {  // gradient sums: [.., .., mean, sum g, sum d0, sum d1, sum g d0, sum g d1]
+        out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
+    }
+    if (pub.slot) {
+        for (int k = 0; k < 4; ++k)
+            __hip_atomic_store(pub.slot + 4 * plane + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub.flag + plane, pub.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <int MODE, bool WIDE = false>
 __global__ void __launch_bounds__(EVK_BLOCK) k_reduce_final(const double *__restrict__ partials, int nblocks,
                                                             int64_t n, double *__restrict__ out,
                                                             HostPublish pub = HostPublish{nullptr, nullptr, 0u}) {
     double acc[EVK_REDUCE_K] = {};
     partials += (int64_t)blockIdx.x * nblocks * EVK_REDUCE_K;  // one block per image plane (batched evaluation)
-    out += (WIDE ? 8 : 4) * blockIdx.x;
     for (int b = threadIdx.x; b < nblocks; b += EVK_BLOCK)
 #pragma unroll
         for (int k = 0; k < EVK_REDUCE_K; ++k) acc[k] += partials[(int64_t)b * EVK_REDUCE_K + k];
     __shared__ double tot[EVK_REDUCE_K];
     block_sum<EVK_REDUCE_K>(acc, tot);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double inv = 1.0 / (double)n;
-        const double mean = tot[0] * inv;
-        if constexpr (MODE == 0) {
-            out[0] = mean;
-            out[1] = tot[1] * inv - mean * mean;
-            out[2] = tot[0];
-            out[3] = tot[1];
-        } else {
-            // mean(2*(a-mean)*d_i) = 2/n * (sum(a*d_i) - mean*sum(d_i))
-            out[0] = 2.0 * inv * (tot[3] - mean * tot[1]);
-            out[1] = 2.0 * inv * (tot[4] - mean * tot[2]);
-            out[2] = mean;
-            out[3] = tot[0];
-            if constexpr (MODE == 3) {  // value + gradient: [g0, g1, mean v, var v] of the blurred image v
-                const double mv = tot[5] * inv;
-                out[2] = mv;
-                out[3] = tot[6] * inv - mv * mv;
-            }
-        }
-        if constexpr (WIDE && MODE == 0) {  // stats: [mean, var, sum v, sum v^2, sum exp v, sum exp(-p v), count, -]
-            out[4] = tot[2], out[5] = tot[3], out[6] = tot[4], out[7] = 0.0;
-        }
-        if constexpr (WIDE && MODE == 1) {  // gradient sums: [.., .., mean, sum g, sum d0, sum d1, sum g d0, sum g d1]
-            out[4] = tot[1], out[5] = tot[2], out[6] = tot[3], out[7] = tot[4];
-        }
-        if (pub.slot) {
-            for (int k = 0; k < 4; ++k)
-                __hip_atomic_store(pub.slot + 4 * blockIdx.x + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(pub.flag + blockIdx.x, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (threadIdx.x == 0) finalise_plane<MODE, WIDE>(tot, n, out + (WIDE ? 8 : 4) * blockIdx.x, pub, (int)blockIdx.x);
 }
-
 
 #define EVK_POST_T 32
 #define EVK_POST_MIX 1u       // scipy's 3-D gaussian_filter on (2, H, W): also filter across the channel axis (Q4)
