@@ -2,21 +2,24 @@
 //
 // The three-pass counting sort of evk_tiled.hip (histogram -> scan -> scatter) reads every event twice and writes a
 // 16-byte record: 581 MB of traffic for 166 MB of algorithmic bytes at 10 M events (profiles/r01_pmc_traffic.json).
-// Here every partition workgroup sorts SUB-CHUNKS of <= 16 K consecutive events by tile entirely in LDS and writes each
-// sorted sub-chunk back as ONE contiguous, fully coalesced run of 8-byte records, plus one 4-byte (start, count) entry
-// per (tile, sub-chunk) in a tile-major table.  No global histogram, no scan kernels, no look-back: the events are
-// read once (16 B) and written once (8 B).  The tile kernel then walks its table row and pulls its ~100-200 byte
-// segments out of the runs (G lanes x 16 B per segment), accumulating in LDS exactly like k_voxel_tiled.
+// Here every partition workgroup sorts SUB-CHUNKS of <= 12 K consecutive events by tile entirely in LDS and writes each
+// sorted sub-chunk back as ONE contiguous, fully coalesced run of 8-byte (or, above 16 M events, 4-byte) records, plus
+// one 4-byte (start, count) entry per (sub-chunk, tile).  No global histogram, no scan kernels, no look-back: the events
+// are read once (16 B) and written once (8 or 4 B).  The tile kernel (k_voxel_tiles2, below) then pulls its ~100-200 byte
+// segments out of the runs, 64-byte chunks handed to groups of 4 lanes, and accumulates in LDS: float64 sums, or -- for
+// calls whose polarities are all +1 / -1 / +0, where the LDS allows -- an integer count and one int64 fixed-point sum per
+// event (the counting mode).  Tiles have any size (evk_part.h: TileGridG); tiled.voxel2_shape picks one whose tile COUNT is
+// a multiple of the 256 CUs.
 //
-// 8-byte record: lo = float32 t (raw bits); hi = [31:11] the top 21 bits of the float32 polarity, [10] "wide" flag,
-// [9:0] pixel inside the tile.  A polarity whose low 11 mantissa bits are zero (+-1, 0, small integers, halves, ...:
-// every polarity the reference's loaders produce) is carried exactly; any other value sets the wide flag and is stored
-// in a side array at the record's index (rare path, 4 extra bytes for that event only), so the result is exact for
-// arbitrary float32 weights.
+// 8-byte record: lo = float32 t_norm (raw bits); hi = [31:11] the top 21 bits of the float32 polarity, [10] "wide" flag,
+// [9:0] accumulator cell inside the tile.  A polarity whose low 11 mantissa bits are zero (+-1, 0, small integers,
+// halves, ...: every polarity the reference's loaders produce) is carried exactly; any other value sets the wide flag and
+// is stored in a side array at the record's index (rare path, 4 extra bytes for that event only), so the result is exact
+// for arbitrary float32 weights.  4-byte record: see k_part_sorted.
 //
 // Hot tiles (clustered data): every partition block adds its per-tile counts to global totals; the LAST block to
-// finish (ticket) builds the work-item plan (a tile with more than max(32768, 4n/T) events is split over several
-// workgroups, by sub-chunk range), exactly the plan k_tile_scan_totals builds for the three-pass path.
+// finish (a relaxed ticket: everything it reads from the others is an agent-scope atomic, no fence) builds the work-item
+// plan -- a tile with more than 2.5 x the mean is cut into pieces of 1.25 x the mean, by sub-chunk range.
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -26,9 +29,6 @@
 
 namespace evk {
 
-#ifndef V2_PIPE
-#define V2_PIPE 1
-#endif
 #define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info),
                              // [4] contributions the deterministic mode refused, [5] events whose polarity is not +1, -1 or
                              // +0 (cumulative), [6] its value after the previous call, [7] 1 if THIS call had any
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 
 // Voxel tiles from the sorted runs: one workgroup per work item (tile, or part of a hot tile = a range of sub-chunks).
 // A tile's records sit in ~100-200 byte segments, one per sub-chunk.  Every thread fetches the table entry of one
-// sub-chunk; each wave then cuts its 64 segments into 64-byte CHUNKS (8 records, 16-byte aligned), lists the chunks
+// sub-chunk; each wave then cuts its 64 segments into 64-byte CHUNKS (8 records, from the segment's first one), lists the chunks
 // in LDS (wave scan of the chunk counts) and hands them out to groups of 4 lanes, 16 bytes per lane: all lanes stay busy
 // whatever the segment lengths are, and U chunk loads per lane are in flight at a time.  Segments longer than 56
 // records (clustered scenes) are streamed by the whole wave instead.
@@ -1256,9 +1256,9 @@ static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, c
                                                                     host_report, seq);
 }
 
-// Tile kernel: 512 threads, 2 chunk loads per lane in flight (256 / 1024 threads, 4 / 8 loads: 48-69 us against 34,
-// DESIGN.md section 3; EVK_EXPERIMENTS builds keep them, EVK_V2_WG / EVK_V2_U).  `lds_dyn` >= the accumulators: asking for
-// more LDS than they need is how the launch fixes the number of workgroups a CU holds (below).
+// Tile kernel: 768 or 512 threads (chosen in voxel2() below), 2 chunk loads per lane in flight (-DV2_U8 / -DV2_U4 for
+// measurements: 1, 3 and 4 are level or slower).  `lds_dyn` = the accumulators of the mode the launch
+// may run in (the chunk lists are static).
 template <int WG, int U, bool SPLIT, bool FIXED, int REC>
 static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *rec, const void *pw, const uint32_t *bases,
                          const uint32_t *table, uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox,
