@@ -1349,7 +1349,9 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // tiles).  Uniform events do not care (29.5 us either way, 512 tiles in one generation); the pieces of a hot tile are
         // done sooner: blob scene 57 -> 49 us, i.e. 1.25 x the uniform call end to end.  4-byte records (HBM-resident calls, three
         // table entries per lane, 128 registers): 512 (768: 151-158 against 132-142 us at 50 M events).
-        const bool may_wide = recb == 8 && v2_tiles_wg() != 512;
+        // (a call that shares its CUs with a collective's workgroups keeps the 512-thread workgroups: two of them with the
+        // counting mode's accumulators leave ~19 KB of every CU's LDS free, two 768-thread ones 3 KB)
+        const bool may_wide = recb == 8 && v2_tiles_wg() != 512 && !share;
         int wg = 512;
         bool count = false;
         if (may_wide && may_count && two_fit(lds_count, 768, recb)) wg = 768, count = true;
