@@ -966,9 +966,17 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             }
             const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
             const uint32_t nch = (cnt + 7u) >> 3;
-            const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
-            const uint32_t mych = is_long ? 0u : nch;
-            const uint32_t incl = wave_scan(mych);
+            // A segment is LONG (streamed by the whole wave, one after the other) only when the wave's chunks do not all fit its
+            // list: the pieces of a hot tile are few entries of ~25 chunks each, and through the list they get the pipelined
+            // rounds and full groups of lanes instead of a dependent round trip per segment.
+            uint32_t mych = nch;
+            uint32_t incl = wave_scan(mych);
+            bool is_long = false;
+            if (__shfl(incl, 63, 64) > (uint32_t)V2_CHUNK_CAP(WG)) {   // (wave-uniform)
+                is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
+                mych = is_long ? 0u : nch;
+                incl = wave_scan(mych);
+            }
             const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
             V2_U(2);
             __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
