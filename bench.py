@@ -112,10 +112,14 @@ def main():
         t_first, t_last = float(t[0]), float(t[-1])
 
     impl = args.impl or tiled.default_impl()
-    # N > 1: the all-reduce of step i (RCCL, its own stream) overlaps the kernels of step i+1 (double-buffered grids);
-    # every grid is fully reduced before the clock stops.  EVK_BENCH_SYNC_ALLREDUCE=1 serialises them instead.
-    overlap = use_dist and os.environ.get("EVK_BENCH_SYNC_ALLREDUCE", "0") != "1"
-    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2 if overlap else 1)]
+    # N > 1: the all-reduce of step i (RCCL, its own stream) overlaps the kernels of step i+1 (double-buffered grids), or the
+    # two run one after the other on one stream; every grid is fully reduced before the clock stops.  Overlapping pays when
+    # the exchange takes about as long as the kernels (xGMI) and costs when it does not (its two cross-stream dependencies
+    # per step are ~10 us of queue latency each), so -- unless EVK_BENCH_SYNC_ALLREDUCE=1 / 0 forces one -- both are timed
+    # in the warm-up and the faster one (max over ranks, the same decision on every rank) is what the K steps run.
+    forced = os.environ.get("EVK_BENCH_SYNC_ALLREDUCE")
+    overlap = use_dist and forced != "1"
+    outs = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(2 if use_dist else 1)]
     works = [None] * len(outs)
     out = outs[0]
 
@@ -176,6 +180,23 @@ def main():
             el = float(tt.item())
         return el
 
+    exchange_choice = None
+    if use_dist and forced not in ("0", "1"):
+        # (overlapped: the kernels leave LDS on every CU for the collective's workgroups, EVK_SHARE_CU=1 -- the library's default
+        # in a multi-rank job; serial: nothing runs beside them, so they take the single-GPU geometry)
+        share_before = os.environ.get("EVK_SHARE_CU")
+        trial = {}
+        for mode in (True, False):
+            overlap = mode
+            if share_before is None:
+                os.environ["EVK_SHARE_CU"] = "1" if mode else "0"
+            trial[mode] = timed(step, max(args.steps, 20), args.warmup)     # identical on every rank (max over ranks)
+        overlap = trial[True] <= trial[False]
+        if share_before is None:
+            os.environ["EVK_SHARE_CU"] = "1" if overlap else "0"
+        exchange_choice = {"overlapped_ms": round(trial[True] / max(args.steps, 20) * 1e3, 4),
+                           "serial_ms": round(trial[False] / max(args.steps, 20) * 1e3, 4),
+                           "chosen": "overlapped" if overlap else "serial", "EVK_SHARE_CU": os.environ.get("EVK_SHARE_CU")}
     elapsed = timed(step, args.steps, args.warmup)
     E.check_errors()                     # deferred out-of-range reports of the timed calls (none expected)
     ms_per_step = elapsed / args.steps * 1e3
@@ -216,7 +237,9 @@ def main():
     }
     if use_dist:
         result["rccl_ranks"] = dist.get_world_size()
-        result.update(check_sharded(dist, dev, out if not overlap else outs[(args.steps - 1) % 2], pd, n, world))
+        result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], pd, n, world))
+        if exchange_choice:
+            result["exchange"] = exchange_choice
         # ---- what the step is made of, so that a 1 -> N curve can be read without re-running: the kernels alone, the grid
         #      collective alone (same buffer shape, both forms), the two back to back, and the N = 1 entry point on this rank
         from event_utils_amd import distributed as DD
@@ -240,11 +263,12 @@ def main():
             DD.reduce_scatter_all_gather_sum_(outs[0])
         ms = lambda fn: round(timed(fn, args.steps, args.warmup) / args.steps * 1e3, 4)   # noqa: E731
         result["breakdown"] = {
-            "overlap_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only), "allreduce_ms": ms(allreduce_only),
+            "headline_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only), "allreduce_ms": ms(allreduce_only),
             "reduce_scatter_all_gather_ms": ms(rsag_only), "serial_ms": ms(serial), "serial_rsag_ms": ms(serial_rsag),
             "n1_equivalent_ms": ms(step_public), "grid_bytes": int(zgrid.numel() * 4),
-            "note": "max over ranks, barrier + synchronize on both sides like ms_per_step.  overlap_ms = the headline step "
-                    "(all-reduce of step i overlapped with the kernels of step i+1); compute_ms = this rank's kernels with "
+            "note": "max over ranks, barrier + synchronize on both sides like ms_per_step.  headline_ms = the timed step "
+                    "(`exchange`: all-reduce of step i overlapped with the kernels of step i+1, or serial -- the faster of "
+                    "the two in the warm-up); compute_ms = this rank's kernels with "
                     "no collective (internal entry, resident grid); allreduce_ms / reduce_scatter_all_gather_ms = the grid "
                     "exchange alone; serial_* = kernels then exchange, not overlapped; n1_equivalent_ms = the public "
                     "events_to_voxel_torch call BENCH's N = 1 `value` times, here on every rank at once without a "
