@@ -52,6 +52,9 @@ namespace evk {
 #ifndef V2_TILES_WAVES
 #define V2_TILES_WAVES(REC) ((REC) == 4 ? 4 : 6)
 #endif
+#ifndef V2_STORE_SC1
+#define V2_STORE_SC1 1   // (A/B) write-through stores for the runs of 8-byte records
+#endif
 #ifndef V2_ENT
 #define V2_ENT(REC) ((REC) == 4 ? 3 : 1)
 #endif
@@ -245,12 +248,26 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             uint4 *dst = REC == 8 ? reinterpret_cast<uint4 *>(rec + lo_prev)
                                   : reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev);
             const int n16 = REC == 8 ? (int)((kept_prev + 1) >> 1) : (int)((kept_prev + 3) >> 2);
-            // streaming stores: the run is read once, by the tile kernel, from the Infinity Cache or HBM -- kept out of this
-            // XCD's L2 the partition runs 3 % (10 M events) / 5 % (50 M) faster and the tile kernel within noise (tools/ab.sh)
-            for (int i = tid; i < n16; i += THREADS) {
-                const uint4 v = src[i];
-                __builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
-                __builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+            if constexpr (REC == 8 && V2_STORE_SC1) {
+                // 8-byte records = cache-resident calls: WRITE-THROUGH (sc1) stores, through a buffer descriptor of this run.
+                // Streaming ("nt") stores keep their lines in the XCD's L2, and what a kernel leaves dirty there is written
+                // back at the kernel boundary behind it (MI355X_MICROARCH.md: + B / 6 TB/s for B bytes left dirty): the
+                // boundary to the tile kernel was ~5 us instead of ~2 -- the whole call 0.0711 -> 0.068 ms at 10 M events.
+                typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)dst, 0, (int)__builtin_amdgcn_readfirstlane(n16 * 16), 0x00020000);
+                for (int i = tid; i < n16; i += THREADS) {
+                    const uint4 v = src[i];
+                    __builtin_amdgcn_raw_buffer_store_b128(u4v{v.x, v.y, v.z, v.w}, rs, i * 16, 0, /* sc1 */ 16);
+                }
+            } else {
+                // 4-byte records = HBM-resident calls: streaming stores (write-through ones cost the partition 5 % there:
+                // 219 against 209 us at 50 M events, and the boundary is 1 % of that call)
+                for (int i = tid; i < n16; i += THREADS) {
+                    const uint4 v = src[i];
+                    __builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
+                    __builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+                }
             }
         }
     };
