@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // still fit a CU.
     constexpr double G_ONE = 2147483648.0;   // 2^31
     __shared__ uint32_t poison[(1 << V2_LB) / 32];
-    constexpr bool COUNTING = !SPLIT && !FIXED;
+    constexpr bool COUNTING = !SPLIT;   // (also in the EVK_VOXEL_DETERMINISTIC instantiation: the counting mode IS deterministic)
     const bool unit = COUNTING && (flags & EVK_VOXEL2_COUNT) && index[7] == 0u;
     int *const s0 = reinterpret_cast<int *>(acc + (B + 1) * ppix);   // unit mode: acc = G[-1 .. B-1], then S0[0 .. B-1]
     V2_U(0);
@@ -1354,7 +1354,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         auto two_fit = [](size_t acc_bytes, int wg, int rec) {
             return 2 * (acc_bytes + (size_t)(rec == 4 ? 12 : 8) * (wg / 64) * V2_CHUNK_CAP(wg) + 256) <= (size_t)160 * 1024;
         };
-        const bool may_count = !sp && !fx && v2_count_enabled() && n < ((int64_t)1 << 31);   // (int32 counts)
+        const bool may_count = !sp && v2_count_enabled() && n < ((int64_t)1 << 31);   // (int32 counts)
 #ifndef V2_U4
 #define V2_U4 2   // chunk loads per lane in flight, 4-byte records
 #endif
