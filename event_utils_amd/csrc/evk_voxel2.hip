@@ -135,6 +135,9 @@ __device__ unsigned long long v2_tile_cycles[16];
 #define V2_UEND() do {} while (0)
 #endif
 
+// floats of staging per work item (the partial tile of a cut tile's piece): a multiple of 32 = whole 128-byte lines
+__host__ __device__ static inline int64_t v2_staging_stride(int64_t cells) { return (cells + 31) & ~(int64_t)31; }
+
 struct Part2 {
     int S;          // events per sub-chunk (% 4 == 0, <= THREADS * EPT)
     int per_block;  // consecutive sub-chunks per partition block
@@ -1073,7 +1076,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     }
     // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
     const int cells = NB * tpix;
-    float *mine = staging + (int64_t)item * cells;
+    const int64_t stride = v2_staging_stride(cells);   // whole 128-byte lines per item: no line is shared by two items
+    float *mine = staging + (int64_t)item * stride;
     // The partial tile goes to the staging buffer with AGENT-SCOPE stores and is read back with agent-scope loads: such
     // accesses are performed at the level all XCDs share, complete (vmcnt) only when they are, and never hit a stale line of
     // this XCD's L2 -- so the hand-over to the last part needs no release / acquire FENCE, which on this chip is a write-back
@@ -1092,11 +1096,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     }
     __syncthreads();
     if (!is_last) return;
-    const float *parts = staging + (int64_t)first_item * cells;
+    const float *parts = staging + (int64_t)first_item * stride;
     flush([&](int c) {
         float sum = 0.0f;
         for (uint32_t p = 0; p < nparts; ++p)
-            sum += __hip_atomic_load(parts + (int64_t)p * cells + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += __hip_atomic_load(parts + (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return sum;
     });
 }
@@ -1229,7 +1233,7 @@ static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw, int th, boo
     L.rec = L.bases + al256((int64_t)q.nsc * 4);
     L.pw = L.rec + al256(slots * 8);        // (sized for either record format: 8 + 4 or 4 + 8 bytes per slot)
     L.staging = L.pw + al256(slots * 8);
-    L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * ((int64_t)planes * tw * th) * 4);
+    L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * v2_staging_stride((int64_t)planes * tw * th) * 4);
     return L;
 }
 
