@@ -233,6 +233,27 @@ def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monke
     assert np.all(v[~np.isnan(ref)] == 0.0)
 
 
+def test_cut_tile_hand_over_is_stable_over_many_launches(E):
+    """The pieces of a cut tile hand their partial tiles to the last-arriving piece inside one launch (agent-scope stores and
+    loads, a relaxed ticket, no fence), across XCDs, with the L2s warm from the previous launches.  A blob that cuts ~25 tiles
+    into ~200 pieces, 30 launches back to back on the same buffers: unit polarities accumulate integers, so every launch must
+    give the SAME bits (a stale word anywhere would show), and the oracle's grid."""
+    n, H, W, B = 6_000_000, 480, 640, 5
+    x, y, t, p = _events(23, n, H, W)
+    rng = np.random.default_rng(4)
+    hot = rng.random(n) < 0.5
+    x[hot] = (W // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
+    y[hot] = (H // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    first = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    filler = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for i in range(30):
+        if i % 3 == 0:
+            filler.random_(0, 255)      # other traffic through the caches between the launches
+        assert torch.equal(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)), first), i
+    close(first.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+
+
 def test_neg_pos_grids_in_deterministic_mode(E, monkeypatch):
     """Split-polarity tile kernel with fixed-point cells: both grids bit-reproducible and equal to the float64 accumulation
     (unit weights: every partial sum is exactly representable either way)."""
