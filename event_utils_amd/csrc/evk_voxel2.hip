@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t now5 = 0, prev6 = 0, cnt_oob = 0;
     if (tid == 0) {
         now5 = __hip_atomic_load(gidx + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prev6 = gidx[6];
+        prev6 = __hip_atomic_load(gidx + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (host_report && oob) cnt_oob = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
@@ -512,8 +512,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         part_start[ntiles] = total_parts;
         __hip_atomic_store(gidx + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // did THIS call see a polarity other than +1, -1, +0?  (the tile kernel counts unit polarities with integers)
-        gidx[7] = now5 != prev6 ? 1u : 0u;
-        gidx[6] = now5;
+        // (agent-scope accesses like everything else in this line of the index: its other words take the workgroups' atomics)
+        __hip_atomic_store(gidx + 7, now5 != prev6 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gidx + 6, now5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
                             // in pinned memory, so that a deferred error check costs no copy and no event on the stream
             const uint32_t cnt = cnt_oob;
