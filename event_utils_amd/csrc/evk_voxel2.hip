@@ -987,43 +987,53 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             }
             const uint32_t start = ent & 0xFFFFu, cnt = ent >> 16;
             const uint32_t nch = (cnt + 7u) >> 3;
-            // A segment is LONG (streamed by the whole wave, one after the other) only when the wave's chunks do not all fit its
-            // list: the pieces of a hot tile are few entries of ~25 chunks each, and through the list they get the pipelined
-            // rounds and full groups of lanes instead of a dependent round trip per segment.
-            uint32_t mych = nch;
-            uint32_t incl = wave_scan(mych);
-            bool is_long = false;
-            if (__shfl(incl, 63, 64) > (uint32_t)V2_CHUNK_CAP(WG)) {   // (wave-uniform)
-                is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
-                mych = is_long ? 0u : nch;
-                incl = wave_scan(mych);
-            }
-            const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
+            // A wave lists ALL chunks of its segments, in as many passes over groups of its lanes as its list (V2_CHUNK_CAP
+            // entries) needs: the pieces of a hot tile are few entries of ~25 chunks each, and through the list they get the
+            // pipelined rounds and full groups of lanes.  A segment is LONG -- streamed by the whole wave, one dependent round
+            // trip after the other -- only when even a quarter of the lanes overflows the list (> 7 chunks then).
+            const uint32_t incl_full = wave_scan(nch);
+            const uint32_t total_full = __shfl(incl_full, 63, 64);
+            uint32_t npass = (total_full + (uint32_t)V2_CHUNK_CAP(WG) - 1u) / (uint32_t)V2_CHUNK_CAP(WG);   // (wave-uniform)
+            npass = npass < 1u ? 1u : (npass > 4u ? 4u : npass);
             V2_U(2);
             __syncthreads();  // (a) accumulators are zero before the first adds; (b) the previous batch's list is consumed
             V2_U(3);
-            {
-                const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + start, e0 = p0 + cnt;
-                for (uint32_t k = 0; k < mych; ++k) {
-                    cseg[wave][excl + k] = make_uint2(p0 + 8u * k, e0);
-                    if constexpr (REC == 4) cbase[wave][excl + k] = bb;
+            for (uint32_t pass = 0; pass < npass; ++pass) {
+                const bool mine = npass == 1u || ((uint32_t)lane * npass) / 64u == pass;
+                uint32_t mych = mine ? nch : 0u, incl = incl_full;
+                bool is_long = false;
+                if (npass > 1u) {
+                    incl = wave_scan(mych);
+                    if (__shfl(incl, 63, 64) > (uint32_t)V2_CHUNK_CAP(WG)) {
+                        is_long = mine && nch > (uint32_t)V2_MAX_CHUNKS(WG);
+                        mych = (mine && !is_long) ? nch : 0u;
+                        incl = wave_scan(mych);
+                    }
                 }
-            }
-            V2_U(4);
-            // The two workgroup barriers per 512 entries are kept on purpose: with wave-private entry ranges and no
-            // barrier the kernel ran at 50 us instead of 39 -- all tiles walking the runs in step keeps each run L2-hot
-            // while its 600 segments are pulled
-            __syncthreads();
-            V2_U(5);
-            rounds(unit_tag, total);
-            V2_U(6);
-            uint64_t m = __ballot(is_long);
-            while (m) {
-                const int s = __builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
-                const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
-                stream_segment(unit_tag, rb + (e2 & 0xFFFFu), rb + (e2 & 0xFFFFu) + (e2 >> 16), b2b);
+                const uint32_t total = __shfl(incl, 63, 64), excl = incl - mych;
+                {
+                    const uint32_t rb = (uint32_t)(base + slot) * (uint32_t)q.S, p0 = rb + start, e0 = p0 + cnt;
+                    for (uint32_t k = 0; k < mych; ++k) {
+                        cseg[wave][excl + k] = make_uint2(p0 + 8u * k, e0);
+                        if constexpr (REC == 4) cbase[wave][excl + k] = bb;
+                    }
+                }
+                V2_U(4);
+                // The two workgroup barriers per batch are kept on purpose (the second one in the first pass, which every
+                // wave runs): with wave-private entry ranges and no barrier the kernel ran at 50 us instead of 39 -- all
+                // tiles walking the runs in step keeps each run L2-hot while its 600 segments are pulled
+                if (pass == 0u) __syncthreads();
+                V2_U(5);
+                rounds(unit_tag, total);
+                V2_U(6);
+                uint64_t m = __ballot(is_long);
+                while (m) {
+                    const int s = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t e2 = __shfl(ent, s, 64), b2b = __shfl(bb, s, 64);
+                    const uint32_t rb = (uint32_t)(base + s * NW + wave) * (uint32_t)q.S;  // lane s's sub-chunk
+                    stream_segment(unit_tag, rb + (e2 & 0xFFFFu), rb + (e2 & 0xFFFFu) + (e2 >> 16), b2b);
+                }
             }
         }
     }
@@ -1175,14 +1185,16 @@ static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 // measured on the moving-edge scene, where most tiles hold 1.5-3 x the mean: cutting everything above 1.5 x made the kernel
 // 30 % slower, 41 -> 53 us) but a blob that holds half of the events in twenty tiles must become many small pieces (cut at
 // 4 x into pieces of < 4 x: 111 us; into pieces of ~1 x: see DESIGN.md).  Uniform events are never cut.  (3 / 1.5 until
-// the tile kernel counted unit polarities and ran 768 threads; with both a piece is cheaper: 2.5 / 1.25, blob 48.5 -> 43.5 us.)
+// the tile kernel counted unit polarities and ran 768 threads; with both a piece is cheaper: 2.5 / 1.25, blob 48.5 -> 43.5 us;
+// 2.5 / 1.6 once a wave lists all the chunks of a piece's long segments, in passes: 39.6 us -- and no cliff any more for
+// bigger pieces: 2 x: 45, 2.5 x: 46, 3 x: 50, 4 x: 55 us; smaller ones pay their fixed costs: 1.25 x: 41.7 us.)
 // EVK_V2_SPLIT="at,part" overrides (measurements).
 struct V2Split {
     double at, part;
 };
 static const V2Split &v2_split() {
     static const V2Split f = [] {
-        V2Split v{2.5, 1.25};
+        V2Split v{2.5, 1.6};
         const char *s = getenv("EVK_V2_SPLIT");
         double a = 0, p = 0;
         if (s && sscanf(s, "%lf,%lf", &a, &p) == 2 && a >= 1.0 && p >= 0.25 && p <= a) v = V2Split{a, p};
