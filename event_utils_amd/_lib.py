@@ -15,6 +15,7 @@ EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE, EVK_POST_NONE = 1, 2, 4, 8
 EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
 EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
 EVK_VOXEL_DETERMINISTIC = 256
+EVK_IMAGE2_NO_FIXED = 512
 
 P = c_void_p  # every device / host pointer crosses as void*
 
@@ -68,6 +69,11 @@ SIGNATURES = {
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
                               c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_normalise_time_f32": [P, c_int64, c_float, c_float, c_int, P, P],
+    "evk_image2_nearest_i32": [P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
+    "evk_image2_nearest_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
+                               c_uint32, P],
+    "evk_image2_bilinear_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
+                                c_uint32, P],
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],
@@ -94,6 +100,7 @@ _SPECIAL = {
     "evk_voxel2_index_len": ([c_int, c_int64], c_int64),
     "evk_voxel2_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
     "evk_voxel2_num_tiles": ([c_int, c_int, c_int, c_int], c_int),
+    "evk_image2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
 }
 
 

@@ -1,0 +1,579 @@
+// Event images on the one-pass partition + LDS-tile design (round 4): events_to_image (image.py:5-44, nearest, numpy
+// path), events_to_image_torch (image.py:46-100, nearest and bilinear) and with it interpolate_to_image (image.py:102-115).
+//
+// The global-atomic kernels of evk_scatter.hip cap these functions at ~21 G atomics/s -- 1 (nearest) or 4 (bilinear) per
+// event -- i.e. 1-3.5 % of the 12 B/event HBM roofline.  Here the events take the voxel grid's route: k_part_sorted
+// (evk_part2.h) sorts sub-chunks of 8 K consecutive events by output tile in LDS and writes each one back as a contiguous
+// run of records, plus a (sub-chunk, tile) table; a tile kernel then pulls every tile's ~16-record segments out of the runs
+// and accumulates in LDS.  12 B/event are read (x, y, weight), 4 (nearest) or 12 (bilinear) written and read once more.
+//
+// Nearest: record = [31:11] top 21 bits of the weight | [10] wide | [9:0] cell (evk_part2.h, V2_FMT_IMGN).  The tile
+// kernel adds integers (int32 LDS atomics) whenever it can -- the integer image of the numpy path, which stays BIT-EXACT
+// with np.bincount, and float32 calls all of whose weights are +1, -1 or +0 (the partition kernel counts the others) -- and
+// float64 otherwise; every pixel of a tile is then written once (plain stores, no global atomics).
+// Bilinear: record = {x - tile x0, y - tile y0} + the weight (V2_FMT_IMGB); the tile's accumulator is a window one pixel
+// wider and higher than the tile (px + 1, py + 1 of its last column / row); the four products are evaluated in float32
+// in the reference's order (image.py:111-114) and added as int64 fixed point (2^-30 steps, unit weights) or float64; the
+// window's interior is added to the image with plain read-modify-writes, its one-pixel ring -- shared with the
+// neighbouring tiles' windows -- with global float atomics (2 (tw + th) of them per tile).
+//
+// A tile's segments are handed out one per LANE: with 4- and 8-byte records a segment of ~16 records is one or two cache
+// lines, which the lane fetches with 16-byte loads (four in flight) and accumulates itself.  Segments longer than
+// IMG_LONG records (clustered scenes, the pieces of a hot tile) are streamed by the whole wave.  Hot tiles are cut by the
+// partition kernel's plan exactly as for the voxel grid (pieces = ranges of sub-chunks, partial tiles summed by the last
+// piece to arrive, in piece order).
+#include "evk_part2.h"
+#include "evk_splat.h"
+
+namespace evk {
+
+// ---- column sources (evk_part.h) -----------------------------------------------------------------------------------
+// x, y, w float32: events_to_image_torch.  Nearest (key_of): image.py:87-95 -- events with x >= clipx or y >= clipy go to
+// pixel (0, 0) WITH their weight (quirk Q8), coordinates are truncated toward zero, negative indices wrap once, NaN and
+// anything still outside is counted (IndexError).  Bilinear (key_rel): image.py:79-86.
+struct SrcImgF32 {
+    static constexpr int G = 4, XYW = 8, TPW = 4;
+    const float *x, *y, *w;
+    float clipx, clipy;
+    float *img;   // (h, wd): the rare path of the bilinear format adds to it directly
+    int h, wd;
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(w + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
+    }
+    __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
+        const float xf = __uint_as_float(r[e]), yf = __uint_as_float(r[4 + e]);
+        const bool keep = !(xf >= clipx) & !(yf >= clipy);   // the mask multiplies the INDICES only (image.py:93-95)
+        return nearest_key_cell_int(keep ? (int)xf : 0, keep ? (int)yf : 0, (xf == xf) & (yf == yf), g, cell);
+    }
+    // Bilinear: tile of (floor(x), floor(y)) and the coordinates relative to that tile's origin.  -3 (xr, yr = x, y):
+    // an event the LDS windows cannot take -- masked (it lands on pixel (0, 0) with weight w * 0), a pixel or its right /
+    // lower neighbour outside the image (negative: wraps; beyond: IndexError), NaN -- goes to rare() below.
+    __device__ __forceinline__ int key_rel(const uint32_t *r, int e, const TileGridG &g, float &xr, float &yr) const {
+        const float xf = __uint_as_float(r[e]), yf = __uint_as_float(r[4 + e]);
+        const float fx = floorf(xf), fy = floorf(yf);
+        const bool ok = !(xf >= clipx) & !(yf >= clipy) & (fx >= 0.0f) & (fx <= (float)(g.dom_w - 2)) & (fy >= 0.0f) &
+                        (fy <= (float)(g.dom_h - 2));
+        const int px = ok ? (int)fx : 0, py = ok ? (int)fy : 0;
+        const int tx = tile_of(px, g.ix), ty = tile_of(py, g.iy);
+        xr = ok ? xf - (float)__mul24(tx, g.tw) : xf;   // exact: a multiple of ulp(x) below x
+        yr = ok ? yf - (float)__mul24(ty, g.th) : yf;
+        return ok ? __mul24(ty, g.tiles_x) + tx : -3;
+    }
+    __device__ __forceinline__ uint32_t w_bits(const uint32_t *r, int e) const { return r[e]; }
+    __device__ __forceinline__ uint32_t payload(const uint32_t *r, int e, bool &wide, bool &unit) const {
+        const uint32_t pbits = r[e];
+        wide = ((pbits & ~V2_P_MASK) != 0u) | ((pbits & 0x7F800000u) == 0x7F800000u);   // (not finite: always wide)
+        unit = ((pbits & 0x7FFFFFFFu) == 0x3F800000u) | (pbits == 0u);
+        return pbits;
+    }
+    // the direct kernel's per-event code (evk_scatter.hip, k_image_bilinear_f32); false = IndexError
+    __device__ __forceinline__ bool rare(float xf, float yf, float wv) const {
+        const float mask = (!(xf >= clipx) && !(yf >= clipy)) ? 1.0f : 0.0f;
+        // a masked event adds w * 0 * (...) to the pixels (0..1, 0..1): nothing, unless a factor is not finite
+        if (mask == 0.0f && fabsf(wv) <= 3.0e38f && fabsf(xf) <= 3.0e38f && fabsf(yf) <= 3.0e38f) return wd >= 2 && h >= 2;
+        const float fx = floorf(xf), fy = floorf(yf);
+        Splat s;
+        s.dx = xf - fx;
+        s.dy = yf - fy;
+        s.px = (long long)(fx * mask);
+        s.py = (long long)(fy * mask);
+        return splat_iwe(img, h, wd, s, wv * mask);
+    }
+};
+
+// x, y, w int32 on the (H+1, W+1) canvas: events_to_image, numpy path (np.ravel_multi_index + np.bincount, image.py:28-38).
+// No wrap: a negative coordinate is a ValueError there.  w == NULL: every weight is 1 (the meanval count image).
+struct SrcImgI32 {
+    static constexpr int G = 4, XYW = 8, TPW = 4;
+    const int32_t *x, *y, *w;
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        uint4 a = make_uint4(1u, 1u, 1u, 1u);
+        if (w) a = reinterpret_cast<const uint4 *>(w + ev0)[gl];
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
+    }
+    __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
+        return nearest_key_cell_int<false>((int)r[e], (int)r[4 + e], true, g, cell);
+    }
+    __device__ __forceinline__ uint32_t w_bits(const uint32_t *r, int e) const { return r[e]; }
+    __device__ __forceinline__ uint32_t payload(const uint32_t *r, int e, bool &wide, bool &unit) const {
+        const int wv = (int)r[e];
+        wide = ((wv << (V2_LB + 1)) >> (V2_LB + 1)) != wv;   // does not fit the record's 21 signed bits
+        unit = (uint32_t)(wv + 1) <= 2u;
+        return (uint32_t)wv << (V2_LB + 1);
+    }
+};
+
+#define IMG_FIX_ONE 1073741824.0f   // 2^30: fixed-point unit of the bilinear window (unit weights: |product| <= 1)
+
+// 16 / 8 bytes at any dword boundary (global loads need no more alignment than that)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) Quad4 {
+    u32x4 v;
+};
+struct __attribute__((packed, aligned(4))) Pair2 {
+    u32x2 v;
+};
+__device__ __forceinline__ uint4 load_u4(const void *p) {
+    const u32x4 v = static_cast<const Quad4 *>(p)->v;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 load_u2(const void *p) {
+    const u32x2 v = static_cast<const Pair2 *>(p)->v;
+    return make_uint2(v.x, v.y);
+}
+
+// The plan of a tile workgroup (as k_voxel_tiles2): work item -> tile, piece of a cut tile, its range of sub-chunks.
+struct ImgItem {
+    int tile;
+    uint32_t item, first_item, nparts, part_id;
+    int sc_lo, sc_hi;
+};
+__device__ __forceinline__ bool img_item(const uint32_t *index, int ntiles, const Part2 &q, int flags, ImgItem &it) {
+    const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
+    const uint32_t nitems = part_start[ntiles];
+    if (blockIdx.x >= nitems) return false;
+    uint32_t item = blockIdx.x;
+    // XCD-aware order (workgroup b runs on XCD b % 8): XCD k takes a contiguous range of the tile-ordered items, whose
+    // segments are neighbours in every run -- but only when no tile was cut (evk_voxel2.hip)
+    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER) && nitems == (uint32_t)ntiles) {
+        const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, q8 = nitems >> 3, r8 = nitems & 7u;
+        item = k * q8 + (k < r8 ? k : r8) + j;
+    }
+    it.item = item, it.tile = (int)item, it.first_item = item, it.nparts = 1u;
+    if (nitems != (uint32_t)ntiles) {
+        it.tile = (int)item_tile[item];
+        it.first_item = part_start[it.tile], it.nparts = part_start[it.tile + 1] - it.first_item;
+    }
+    it.part_id = item - it.first_item;
+    it.sc_lo = (int)(((int64_t)q.nsc * it.part_id) / it.nparts);
+    it.sc_hi = (int)(((int64_t)q.nsc * (it.part_id + 1)) / it.nparts);
+    return true;
+}
+
+// The last piece of a cut tile to arrive (relaxed agent-scope ticket; the partial tiles were stored with agent-scope
+// stores and every wave has drained them: no fence, evk_voxel2.hip)
+__device__ __forceinline__ bool img_last_part(uint32_t *index, int ntiles, const ImgItem &it) {
+    __shared__ int is_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t *counter = index + V2_COUNTER(ntiles) + it.tile;
+        const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == it.nparts - 1);
+        if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+// The records of a tile sit in ~16-record segments, one per sub-chunk (evk_part2.h).  As in k_voxel_tiles2 every thread
+// fetches the table entry of one sub-chunk -- in equal batches interleaved over the waves (slot = lane * NW + wave), so that
+// a short range (a piece of a hot tile) still gives every wave its share --, each wave cuts its 64 segments into CHUNKS of
+// 8 records starting at the segment's first record, lists them in LDS ({first record, end of the segment}) and hands them to
+// groups of 4 lanes, 2 records per lane: every lane has work whatever the segment lengths are (one segment per LANE, the
+// first version of these kernels, left 40 % of the lanes idle and made the bilinear kernel VALU-bound at 72 us per 10 M
+// events).  A wave lists all chunks of its segments, in as many passes over its lanes as its list needs; only a segment
+// that alone overflows the list (> 3584 records) is streamed by the whole wave.  load(pos) -> L fetches the records pos,
+// pos + 1 (unconditionally: `pos` is always inside the record buffer); use(L, pos, end) accumulates them.  The loads of
+// the next round are in flight while a round is accumulated.
+#define IMG_CAP 448   // chunk descriptors per wave
+template <int WG, int U, typename L, typename LoadF, typename UseF>
+__device__ __forceinline__ void img_records(const uint32_t *table, const Part2 &q, const ImgItem &it, uint2 (*cseg)[IMG_CAP],
+                                            LoadF load, UseF use) {
+    constexpr int NW = WG / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane * NW + wave, sub = lane & 3, grp = lane >> 2;
+    const uint32_t *col = table + it.tile;
+    auto wave_scan = [&](uint32_t v) {   // inclusive
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        return incl;
+    };
+    auto rounds = [&](const uint32_t total) {
+        auto meta = [&](uint32_t j0, uint2(&cs)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = j0 + 16u * u + grp;
+                cs[u] = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
+            }
+        };
+        auto fire = [&](const uint2(&cs)[U], L(&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = cs[u].x + 2u * sub;
+                v[u] = load(pos < cs[u].y ? pos : 2u * sub);
+            }
+        };
+        auto eat = [&](const uint2(&cs)[U], const L(&v)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t pos = cs[u].x + 2u * sub;
+                if (pos < cs[u].y) use(v[u], pos, cs[u].y);
+            }
+        };
+        constexpr uint32_t step = 16u * U;
+        uint2 ca[U], cb[U];
+        L va[U], vb[U];
+        meta(0u, ca);
+        fire(ca, va);
+        for (uint32_t j0 = 0; j0 < total; j0 += 2u * step) {
+            meta(j0 + step, cb);
+            fire(cb, vb);          // round j0 + step in flight
+            eat(ca, va);           // round j0
+            meta(j0 + 2u * step, ca);
+            fire(ca, va);          // round j0 + 2 step in flight
+            eat(cb, vb);           // round j0 + step
+        }
+    };
+    auto entry = [&](int my) -> uint32_t { return my < it.sc_hi ? col[(int64_t)my * q.nt_pad] : 0u; };
+    uint32_t ent_next = entry(it.sc_lo + slot);
+    for (int base = it.sc_lo; base < it.sc_hi; base += WG) {
+        const uint32_t ent = ent_next;
+        ent_next = entry(base + WG + slot);   // in flight while this batch is processed
+        const uint32_t cnt = ent >> 16, p0 = (uint32_t)(base + slot) * (uint32_t)q.S + (ent & 0xFFFFu), e0 = p0 + cnt;
+        const uint32_t nch = (cnt + 7u) >> 3;
+        const bool is_long = nch > (uint32_t)IMG_CAP;
+        const uint32_t mych = is_long ? 0u : nch;
+        const uint32_t incl = wave_scan(mych), total = __shfl(incl, 63, 64);
+        // (all tiles walking the runs in step keeps each run L2-hot while its segments are pulled: evk_voxel2.hip; the
+        // barrier also separates this batch's list from the previous batch's rounds)
+        __syncthreads();
+        uint32_t done = 0;
+        while (done < total) {   // (wave-uniform) lanes whose chunks fit the list, in scan order
+            const bool take = mych != 0u && incl - mych >= done && incl <= done + (uint32_t)IMG_CAP;
+            const uint64_t tm = __ballot(take);
+            const uint32_t n_this = __shfl(incl, 63 - __builtin_clzll(tm), 64) - done;
+            if (take)
+                for (uint32_t k = 0; k < mych; ++k) cseg[wave][incl - mych - done + k] = make_uint2(p0 + 8u * k, e0);
+            rounds(n_this);
+            done += n_this;
+        }
+        uint64_t m = __ballot(is_long);
+        while (m) {   // a segment that alone overflows the list: the whole wave, 2 records per lane, four loads in flight
+            const int s = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t b2 = __shfl(p0, s, 64), e2 = __shfl(e0, s, 64);
+            for (uint32_t p2 = b2 + 2u * lane; p2 < e2; p2 += 512u) {
+                L v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = load(p2 + 128u * u < e2 ? p2 + 128u * u : p2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p2 + 128u * u < e2) use(v[u], p2 + 128u * u, e2);
+            }
+        }
+    }
+}
+
+// ---- nearest: one accumulator per pixel ---------------------------------------------------------------------------
+// INT: int32 weights, int32 canvas (bit-exact).  Else float32 weights and image: integer counts while every weight of the
+// call is +1, -1 or +0 (index[7], set by the partition kernel), float64 cells otherwise.  A call with weights that do not
+// fit their record (index[1]) reads them from the side runs.
+struct RecN {
+    uint2 r, w;   // two one-word records; their exact weights (only loaded when the call has wide ones)
+};
+template <int WG, bool INT>
+__global__ void __launch_bounds__(WG) k_image_tiles_n(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ side,
+                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                      TileGridG g, Part2 q, int flags, void *__restrict__ out_,
+                                                      void *__restrict__ staging_) {
+    __shared__ int cnt32[EVK_GRIDG_MAX_CELLS];
+    __shared__ acc_t acc64[INT ? 1 : EVK_GRIDG_MAX_CELLS];
+    __shared__ uint2 cseg[WG / 64][IMG_CAP];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    ImgItem it;
+    if (!img_item(index, ntiles, q, flags, it)) return;
+    const bool unit = INT || index[7] == 0u;
+    const bool has_wide = index[1] != 0u;
+    const int tw = g.tw, th = g.th, tpix = tw * th, ppix = g.pitch * th;
+    for (int i = threadIdx.x; i < ppix; i += WG) {
+        cnt32[i] = 0;
+        if constexpr (!INT) acc64[i] = 0.0;
+    }
+    // (the first batch's barrier in img_records orders the zeroing before the first adds)
+    auto one = [&](uint32_t word, uint32_t exact) {
+        const int local = (int)(word & V2_LOCAL_MASK);
+        const uint32_t bits = (word & V2_WIDE) ? exact : (word & V2_P_MASK);
+        if constexpr (INT) {
+            const int wv = (word & V2_WIDE) ? (int)bits : (int)bits >> (V2_LB + 1);
+            __hip_atomic_fetch_add(cnt32 + local, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (unit) {
+            __hip_atomic_fetch_add(cnt32 + local, (int)__uint_as_float(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            lds_add(acc64 + local, __uint_as_float(bits));
+        }
+    };
+    img_records<WG, 2, RecN>(
+        table, q, it, cseg,
+        [&](uint32_t pos) -> RecN {
+            RecN v;
+            v.r = load_u2(rec + pos);
+            v.w = has_wide ? load_u2(side + pos) : make_uint2(0u, 0u);
+            return v;
+        },
+        [&](const RecN &v, uint32_t pos, uint32_t end) {
+            one(v.r.x, v.w.x);
+            if (pos + 1 < end) one(v.r.y, v.w.y);
+        });
+    __syncthreads();
+    typedef typename std::conditional<INT, int, float>::type Out;
+    Out *const out = static_cast<Out *>(out_);
+    const int overwrite = flags & EVK_VOXEL_OVERWRITE;
+    const int tx0 = (it.tile % g.tiles_x) * tw, ty0 = (it.tile / g.tiles_x) * th;
+    auto lds_cell = [&](int c) -> Out {   // dense cell c of the tile -> padded LDS layout
+        const int row = (int)div_magic((uint32_t)c, g.mx), col = c - row * tw, l = row * g.pitch + col;
+        if constexpr (INT) return cnt32[l];
+        else return unit ? (float)cnt32[l] : (float)acc64[l];
+    };
+    auto flush = [&](auto value_of) {
+        for (int c = threadIdx.x; c < tpix; c += WG) {
+            const int row = (int)div_magic((uint32_t)c, g.mx), col = c - row * tw;
+            const int X = tx0 + col, Y = ty0 + row;
+            if (X < g.dom_w && Y < g.dom_h) {
+                Out *o = out + (int64_t)Y * g.dom_w + X;
+                const Out v = value_of(c);
+                *o = overwrite ? v : *o + v;
+            }
+        }
+    };
+    if (it.nparts == 1) {
+        flush(lds_cell);
+        return;
+    }
+    // a piece of a cut tile: partial tile to the staging area (agent-scope stores), the last piece to arrive sums them
+    const int64_t stride = v2_staging_stride(tpix);
+    Out *const staging = static_cast<Out *>(staging_);
+    Out *mine = staging + (int64_t)it.item * stride;
+    for (int c = threadIdx.x; c < tpix; c += WG) __hip_atomic_store(mine + c, lds_cell(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!img_last_part(index, ntiles, it)) return;
+    const Out *parts = staging + (int64_t)it.first_item * stride;
+    flush([&](int c) {
+        Out sum = 0;
+        for (uint32_t p = 0; p < it.nparts; ++p)
+            sum += __hip_atomic_load(parts + (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return sum;
+    });
+}
+
+// ---- bilinear: a window one pixel wider and higher than the tile --------------------------------------------------
+#define IMG_WIN_MAX 2048   // cells of the window: (tw + 2) * (th + 1) with (tw | 1) * th <= 1024
+struct RecB {
+    uint4 r;   // {x - x0, y - y0} of two records
+    uint2 w;   // their weights
+};
+template <int WG>
+__global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ rec, const uint32_t *__restrict__ side,
+                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                      TileGridG g, Part2 q, int flags, float *__restrict__ img,
+                                                      float *__restrict__ staging) {
+    __shared__ acc_t win[IMG_WIN_MAX];   // float64, or int64 multiples of 2^-30 (unit weights)
+    __shared__ uint2 cseg[WG / 64][IMG_CAP];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    ImgItem it;
+    if (!img_item(index, ntiles, q, flags, it)) return;
+    const bool unit = !(flags & EVK_IMAGE2_NO_FIXED) && index[7] == 0u;
+    const int tw = g.tw, th = g.th;
+    const int ww = tw + 1, wh = th + 1, wpitch = ww | 1, wcells = wpitch * wh;   // odd pitch (evk_part.h)
+    for (int i = threadIdx.x; i < wcells; i += WG) win[i] = 0.0;
+    unsigned long long *const winq = reinterpret_cast<unsigned long long *>(win);
+    auto one = [&](auto unit_tag, uint32_t xb, uint32_t yb, uint32_t wb) {
+        constexpr bool UNIT = decltype(unit_tag)::value;
+        const float xr = __uint_as_float(xb), yr = __uint_as_float(yb);
+        const float fx = floorf(xr), fy = floorf(yr);
+        const float dx = xr - fx, dy = yr - fy;                  // = x - floor(x), y - floor(y) (image.py:81-82), exactly
+        const float ax = 1.0f - dx, ay = 1.0f - dy;
+        const int c0 = __mul24((int)fy, wpitch) + (int)fx;
+        if constexpr (UNIT) {
+            // image.py:111-114, the products in the order written there, on the weight times 2^30: a power of two commutes
+            // with every rounding (|product| <= 1: no overflow, and nothing below 2^-126 matters at 2^-30 resolution)
+            const float wv = __uint_as_float(wb) * IMG_FIX_ONE;
+            const float wa = wv * ax, wd = wv * dx;
+            auto addq = [&](int c, float v) {
+                __hip_atomic_fetch_add(winq + c, (unsigned long long)(long long)__float2int_rn(v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            addq(c0, wa * ay), addq(c0 + 1, wd * ay), addq(c0 + wpitch, wa * dy), addq(c0 + wpitch + 1, wd * dy);
+        } else {
+            const float wv = __uint_as_float(wb);
+            const float wa = wv * ax, wd = wv * dx;
+            lds_add(win + c0, wa * ay), lds_add(win + c0 + 1, wd * ay), lds_add(win + c0 + wpitch, wa * dy),
+                lds_add(win + c0 + wpitch + 1, wd * dy);
+        }
+    };
+    auto run = [&](auto unit_tag) {
+        img_records<WG, 2, RecB>(
+            table, q, it, cseg,
+            [&](uint32_t pos) -> RecB {
+                RecB v;
+                v.r = load_u4(rec + pos), v.w = load_u2(side + pos);
+                return v;
+            },
+            [&](const RecB &v, uint32_t pos, uint32_t end) {
+                one(unit_tag, v.r.x, v.r.y, v.w.x);
+                if (pos + 1 < end) one(unit_tag, v.r.z, v.r.w, v.w.y);
+            });
+    };
+    if (unit) run(std::true_type{});
+    else run(std::false_type{});
+    __syncthreads();
+    const int tx0 = (it.tile % g.tiles_x) * tw, ty0 = (it.tile / g.tiles_x) * th;
+    const int dcells = ww * wh;   // dense cells of the window
+    const uint32_t mw = magic_div((uint32_t)ww);
+    auto lds_cell = [&](int c) -> float {
+        const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww, l = row * wpitch + col;
+        if (unit) return (float)((double)(long long)winq[l] * (1.0 / (double)IMG_FIX_ONE));
+        return (float)win[l];
+    };
+    // Interior pixels belong to this window alone: plain read-modify-write.  The ring (first / last row and column) is also
+    // covered by the neighbouring tiles' windows: global float atomics.
+    auto flush = [&](auto value_of) {
+        for (int c = threadIdx.x; c < dcells; c += WG) {
+            const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww;
+            const int X = tx0 + col, Y = ty0 + row;
+            if (X < g.dom_w && Y < g.dom_h) {
+                float *o = img + (int64_t)Y * g.dom_w + X;
+                const float v = value_of(c);
+                if (row == 0 || row == th || col == 0 || col == tw) {
+                    if (v != 0.0f || v != v) atomic_add(o, v);
+                } else {
+                    *o += v;
+                }
+            }
+        }
+    };
+    if (it.nparts == 1) {
+        flush(lds_cell);
+        return;
+    }
+    const int64_t stride = v2_staging_stride(dcells);
+    float *mine = staging + (int64_t)it.item * stride;
+    for (int c = threadIdx.x; c < dcells; c += WG) __hip_atomic_store(mine + c, lds_cell(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!img_last_part(index, ntiles, it)) return;
+    const float *parts = staging + (int64_t)it.first_item * stride;
+    flush([&](int c) {
+        float sum = 0.0f;
+        for (uint32_t p = 0; p < it.nparts; ++p)
+            sum += __hip_atomic_load(parts + (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return sum;
+    });
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// One geometry for the images: 1024 threads x 8 events, sub-chunks of 8 K events (68 KB of LDS with 4-byte records,
+// 100 KB with the 12 bytes of the bilinear format).
+#define IMG_WG 512
+static inline int img_window_cells(int tw, int th) { return (tw + 1) * (th + 1); }
+
+struct ImgCall {
+    TileGridG g;
+    Part2 q;
+    V2Layout L;
+    int ntiles;
+};
+static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile_h, int flags, const void *out, uint32_t *index,
+                     void *scratch, int64_t scratch_bytes, uint32_t *host_report) {
+    const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL2_PARTITION_ONLY | EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER |
+                      EVK_IMAGE2_NO_FIXED;
+    if (make_grid_g(ic.g, h, wd, tile_w, tile_h) != EVK_OK || !out || !index || !scratch || n <= 0 ||
+        n > (int64_t)4000000000LL || (flags & ~known))
+        return EVK_EINVAL;
+    if (host_report && ((uintptr_t)host_report & 7u)) return EVK_EALIGN;
+    ic.ntiles = ic.g.tiles_x * ic.g.tiles_y;
+    if (ic.ntiles > evk_voxel2_max_tiles() || (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX) return EVK_EINVAL;
+    ic.L = v2_layout(ic.ntiles, n, 2, tile_w, tile_h, true);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
+    if (scratch_bytes < ic.L.total) return EVK_ESCRATCH;
+    if (!aligned16(scratch)) return EVK_EALIGN;
+    ic.q = v2_geometry(n, ic.ntiles, true);
+    return EVK_OK;
+}
+
+template <int FMT, typename C>
+static void img_partition(const C &c, int64_t n, const ImgCall &ic, uint32_t *index, void *scratch, uint32_t *oob,
+                          uint32_t *host_report, uint32_t seq, hipStream_t s) {
+    char *sb = (char *)scratch;
+    launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
+                              (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" int64_t evk_image2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h) {
+    if (ntiles <= 0 || n < 0 || tile_w <= 0 || tile_h <= 0) return 0;
+    return v2_layout(ntiles, n, 2, tile_w, tile_h, true).total;
+}
+
+extern "C" int evk_image2_nearest_i32(const int32_t *x, const int32_t *y, const int32_t *w, int64_t n, int canvas_h,
+                                      int canvas_w, int tile_w, int tile_h, int flags, int32_t *canvas, uint32_t *index,
+                                      void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                                      uint32_t seq, void *stream) {
+    if (n > 0 && (!x || !y)) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y) && aligned16(w))) return EVK_EALIGN;
+    ImgCall ic;
+    const int rc = img_setup(ic, n, canvas_h, canvas_w, tile_w, tile_h, flags, canvas, index, scratch, scratch_bytes, host_report);
+    if (rc != EVK_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY)) img_partition<V2_FMT_IMGN>(SrcImgI32{x, y, w}, n, ic, index, scratch, oob, host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY))
+        k_image_tiles_n<IMG_WG, true><<<v2_max_items(n, ic.ntiles), IMG_WG, 0, s>>>(
+            (const uint32_t *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, canvas, sb + ic.L.staging);
+    return launch_status();
+}
+
+extern "C" int evk_image2_nearest_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                                      float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index,
+                                      void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                                      uint32_t seq, void *stream) {
+    if (n > 0 && (!x || !y || !w)) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y) && aligned16(w))) return EVK_EALIGN;
+    ImgCall ic;
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
+    if (rc != EVK_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY))
+        img_partition<V2_FMT_IMGN>(SrcImgF32{x, y, w, clipx, clipy, img, h, wd}, n, ic, index, scratch, oob, host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY))
+        k_image_tiles_n<IMG_WG, false><<<v2_max_items(n, ic.ntiles), IMG_WG, 0, s>>>(
+            (const uint32_t *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, img, sb + ic.L.staging);
+    return launch_status();
+}
+
+extern "C" int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                                       float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index,
+                                       void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                                       uint32_t seq, void *stream) {
+    if (n > 0 && (!x || !y || !w)) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y) && aligned16(w))) return EVK_EALIGN;
+    if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;   // the ring of a window is ADDED to the image: always accumulates
+    ImgCall ic;
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
+    if (rc != EVK_OK) return rc;
+    if (h < 2 || wd < 2) return EVK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY))
+        img_partition<V2_FMT_IMGB>(SrcImgF32{x, y, w, clipx, clipy, img, h, wd}, n, ic, index, scratch, oob, host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY))
+        k_image_tiles_b<IMG_WG><<<v2_max_items(n, ic.ntiles), IMG_WG, 0, s>>>(
+            (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, img, (float *)(sb + ic.L.staging));
+    return launch_status();
+}

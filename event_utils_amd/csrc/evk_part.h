@@ -50,9 +50,12 @@ static inline int make_grid_g(TileGridG &g, int dom_h, int dom_w, int tw, int th
 // Nearest-pixel key (EVK_KEY_NEAREST of tile_key): the tile of an event, and the accumulator cell inside the tile.
 // Branch-free: sixteen of these per thread with early returns became thirty-two divergent branches and the register
 // allocator spilled across them.  24-bit multiplies (full rate): every operand is below 2^16.
+template <bool WRAP = true>   // WRAP: negative indices wrap once, as index_put_ does (false: np.ravel_multi_index rejects them)
 __device__ __forceinline__ int nearest_key_cell_int(int xi, int yi, bool finite, const TileGridG &g, uint32_t &cell) {
-    xi += xi < 0 ? g.dom_w : 0;     // negative indices wrap once, as index_put_ does
-    yi += yi < 0 ? g.dom_h : 0;
+    if constexpr (WRAP) {
+        xi += xi < 0 ? g.dom_w : 0;
+        yi += yi < 0 ? g.dom_h : 0;
+    }
     const bool ok = finite & ((uint32_t)xi < (uint32_t)g.dom_w) & ((uint32_t)yi < (uint32_t)g.dom_h);
     const int ux = ok ? xi : 0, uy = ok ? yi : 0;
     const int tx = tile_of(ux, g.ix), ty = tile_of(uy, g.iy);

@@ -1,7 +1,7 @@
 // Direct (global-atomic) event scatter kernels: one streaming pass over the SoA event columns, every contribution
 // is one hardware global atomic add.  These are the always-correct baseline path; the LDS-tiled kernels in
 // evk_tiled.hip replace them on the hot configurations.
-#include "evk_common.h"
+#include "evk_splat.h"
 
 namespace evk {
 
@@ -27,12 +27,6 @@ __device__ __forceinline__ Vec4<T> load_col(const T *p, int64_t base, int cnt, b
 #pragma unroll
     for (int k = 0; k < 4; ++k) r.v[k] = (k < cnt) ? p[base + k] : T(0);
     return r;
-}
-
-// torch index semantics: negative indices wrap once, anything else out of [0, dim) is an error.
-__device__ __forceinline__ bool wrap_index(long long &i, int dim) {
-    if (i < 0) i += dim;
-    return i >= 0 && i < dim;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -87,23 +81,6 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_image_nearest_f32(const float *__
 // ---------------------------------------------------------------------------------------------------------
 // bilinear splat (image.py:79-86, 102-115, 117-136)
 // ---------------------------------------------------------------------------------------------------------
-
-struct Splat {
-    long long px, py;
-    float dx, dy;
-};
-
-// Four IWE atomics, products evaluated in the reference's order (image.py:111-114).
-__device__ __forceinline__ bool splat_iwe(float *img, int h, int wd, const Splat &s, float w) {
-    long long x0 = s.px, x1 = s.px + 1, y0 = s.py, y1 = s.py + 1;
-    if (!(wrap_index(x0, wd) && wrap_index(x1, wd) && wrap_index(y0, h) && wrap_index(y1, h))) return false;
-    const float ax = 1.0f - s.dx, ay = 1.0f - s.dy;
-    atomic_add(img + y0 * wd + x0, w * ax * ay);
-    atomic_add(img + y0 * wd + x1, w * s.dx * ay);
-    atomic_add(img + y1 * wd + x0, w * ax * s.dy);
-    atomic_add(img + y1 * wd + x1, w * s.dx * s.dy);
-    return true;
-}
 
 // interpolate_to_image / interpolate_to_derivative_img on caller-computed pixels and fractions (image.py:102-136).
 __global__ void __launch_bounds__(EVK_BLOCK) k_splat_indexed_f32(const int64_t *__restrict__ px,

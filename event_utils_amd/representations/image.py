@@ -48,25 +48,35 @@ def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padd
         if not (np.issubdtype(xs.dtype, np.integer) and np.issubdtype(ys.dtype, np.integer)):
             raise TypeError("only int indices permitted")      # np.ravel_multi_index, image.py:31
         dev = D.require_gpu()
+        from .. import tiled
         n = xs.shape[0]
         xd, yd = D.to_device(xs, torch.int32), D.to_device(ys, torch.int32)
         oob = D.OobCounter(dev)
+        impl = tiled.default_impl()
         int_w = np.issubdtype(ps.dtype, np.integer) or ps.dtype == np.bool_
+
+        def count_image(wcol):
+            """int32 event image of the int32 weight column (None: the count image): the one-pass partition + LDS tiles
+            (evk_image2.hip) above the crossover, else one global int32 atomic per event -- bit-identical either way."""
+            if tiled.can_tile_image((xd, yd, wcol), impl):
+                c = torch.empty(img_size, dtype=torch.int32, device=dev)
+                if tiled.image2("i32", xd, yd, wcol, n, img_size[0], img_size[1], 0.0, 0.0, c, oob, fresh=True):
+                    return c
+            c = torch.zeros(img_size, dtype=torch.int32, device=dev)
+            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wcol), n, img_size[0], img_size[1], D.ptr(c),
+                      oob.ptr, D.stream())
+            return c
+
         if int_w and (n == 0 or float(np.abs(ps.astype(np.int64)).max()) * n < 2 ** 31):
-            canvas = torch.zeros(img_size, dtype=torch.int32, device=dev)
             wd_ = D.to_device(ps, torch.int32)      # keep every device temporary alive until the launch
-            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
-                      img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
+            canvas = count_image(wd_)
         else:
             canvas = torch.zeros(img_size, dtype=torch.float64, device=dev)
             wd_ = D.to_device(ps, torch.float64)
             _lib.call("evk_image_nearest_f64", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
                       img_size[0], img_size[1], D.ptr(canvas), oob.ptr, D.stream())
         if meanval:
-            cnt = torch.zeros(img_size, dtype=torch.int32, device=dev)
-            _lib.call("evk_image_nearest_i32", D.ptr(xd), D.ptr(yd), None, n, img_size[0], img_size[1], D.ptr(cnt),
-                      None, D.stream())
-            event_count_image = cnt.cpu().numpy().astype(np.float64)
+            event_count_image = count_image(None).cpu().numpy().astype(np.float64)
         oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas %s" % (img_size,))
         img = canvas.cpu().numpy().astype(np.float64)
     if meanval:
@@ -94,20 +104,34 @@ def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_
         raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
                            "destination and Double for the source.")
     n = xs.shape[0]
-    img = torch.full(tuple(img_size), float(default), dtype=torch.float32, device=dev)
+    from .. import tiled
     oob = D.OobCounter(dev)
     xd, yd = D.to_device(xs, torch.float32), D.to_device(ys, torch.float32)   # ints < 2^24 are exact in f32
     pd = D.to_device(ps.squeeze() if ps.dim() > 1 else ps, torch.float32)
-    if interpolation == 'bilinear' and not _is_int_tensor(xs):
-        _lib.call("evk_image_bilinear_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, img_size[0], img_size[1], clipx, clipy,
-                  D.ptr(img), oob.ptr, D.stream())
-    else:
-        if ps.dtype != torch.float32:
-            raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
-                               "destination and %s for the source." % str(ps.dtype))
-        _lib.call("evk_image_nearest_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, img_size[0], img_size[1], clipx, clipy,
-                  D.ptr(img), oob.ptr, D.stream())
-    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),))
+    bilinear = interpolation == 'bilinear' and not _is_int_tensor(xs)
+    if not bilinear and ps.dtype != torch.float32:
+        raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
+                           "destination and %s for the source." % str(ps.dtype))
+    # Above the crossover: one-pass partition + LDS tiles (evk_image2.hip); below it, or for columns it cannot take
+    # (unaligned views), one global atomic per contribution (evk_scatter.hip).  Same semantics either way.
+    img = None
+    if tiled.can_tile_image((xd, yd, pd), tiled.default_impl()) and xd.shape == pd.shape:
+        fresh = (not bilinear) and float(default) == 0.0
+        if fresh:           # every pixel is written: no memset
+            img = torch.empty(tuple(img_size), dtype=torch.float32, device=dev)
+        else:
+            img = torch.full(tuple(img_size), float(default), dtype=torch.float32, device=dev)
+        if not tiled.image2("bilinear" if bilinear else "f32", xd, yd, pd, n, img_size[0], img_size[1], clipx, clipy, img,
+                            oob, fresh=fresh):
+            img = None
+    if img is None:
+        img = torch.full(tuple(img_size), float(default), dtype=torch.float32, device=dev)
+        _lib.call("evk_image_bilinear_f32" if bilinear else "evk_image_nearest_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n,
+                  img_size[0], img_size[1], clipx, clipy, D.ptr(img), oob.ptr, D.stream())
+    # events and image that stay on the device never wait for the host (the reference's own CUDA path reports an
+    # out-of-range index_put_ asynchronously too; EVK_ERRORS=strict synchronises every call)
+    resident = xs.is_cuda and torch.device(device).type == "cuda"
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),), deferrable=resident)
     return img.to(device)
 
 

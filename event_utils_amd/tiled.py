@@ -268,6 +268,58 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
                              "accumulated in fixed point" % bad)
 
 
+# 'auto' threshold of the event images (evk_image2.hip): below it the two launches of the one-pass path cost more than
+# one global atomic (nearest) or four (bilinear) per event at ~21 G/s
+TILED_MIN_EVENTS_IMAGE = 250_000
+
+
+def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
+    """evk_image2_nearest_i32 / _nearest_f32 / _bilinear_f32 (kind = 'i32' | 'f32' | 'bilinear'): the event image of the
+    device columns accumulated into `out` (H, W) -- or, nearest kinds with fresh=True, written over it (no memset needed).
+    Returns False when the one-pass path has no tiling for this image (the caller then uses the direct kernel)."""
+    L = _lib.lib()
+    shape = voxel2_shape(H, W, 1)
+    if shape is None or (kind == "bilinear" and (H < 2 or W < 2)):
+        return False
+    tw, th = shape
+    if (tw + 2) * (th + 1) > 2048:
+        return False
+    dev = out.device
+    ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
+    key = ("image2", ntiles, n, tw, th)
+    sizes = _staging_bytes.get(key)
+    if sizes is None:
+        sizes = _staging_bytes[key] = (int(L.evk_voxel2_index_len(ntiles, n)),
+                                       int(L.evk_image2_scratch_bytes(ntiles, n, tw, th)))
+        if sizes[0] <= 0:
+            return False
+    index = _zbuf("image2_index", sizes[0], dev)          # (its own: the header words [0], [1] mean something else here)
+    scratch = _buf("voxel2_scratch", sizes[1], dev)
+    flags = stage | (_lib.EVK_VOXEL_OVERWRITE if (fresh and kind != "bilinear") else 0)
+    if os.environ.get("EVK_IMAGE2_FIXED", "1") == "0":
+        flags |= _lib.EVK_IMAGE2_NO_FIXED
+    report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
+    tail = (tw, th, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None,
+            report, seq, D.stream())
+    if kind == "i32":
+        _lib.call("evk_image2_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, *tail)
+    else:
+        _lib.call("evk_image2_%s_f32" % ("bilinear" if kind == "bilinear" else "nearest"), D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
+                  H, W, clipx, clipy, *tail)
+    return True
+
+
+def can_tile_image(cols, impl):
+    """Preconditions of the one-pass image path: contiguous, 16-byte aligned 4-byte columns and, under 'auto', enough
+    events to amortise its two launches."""
+    n = cols[0].shape[0]
+    if impl not in ("tiled", "auto") or n == 0 or n > 4_000_000_000:
+        return False
+    if not all(c is None or (c.element_size() == 4 and c.is_contiguous() and c.data_ptr() % 16 == 0) for c in cols):
+        return False
+    return impl == "tiled" or n >= TILED_MIN_EVENTS_IMAGE
+
+
 def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
     """events_to_neg_pos_voxel_torch core: (2, B, H, W) float32 = [positive events, non-positive events] from ONE
     bucketing pass and ONE tile-kernel pass, or None when the tiled path does not apply (the caller then voxelises the

@@ -357,6 +357,35 @@ int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, con
                           float t_last, int B, int flags, float *vox, uint32_t *index, void *scratch,
                           int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
 
+/* ---- event images on the one-pass partition (evk_image2.hip) -------------------------------
+ * The three event-image entry points above (evk_image_nearest_i32 / _f32, evk_image_bilinear_f32: one global atomic per
+ * contribution, ~21 G atomics/s) on the voxel grid's partition + LDS-tile design: the same results -- the integer image
+ * bit for bit, the float32 images up to the order of the additions -- from two launches that read 12 B/event and move a
+ * 4-byte (nearest) or 12-byte (bilinear) record once.  Semantics, clip thresholds, the treatment of negative /
+ * out-of-range / non-finite coordinates and the meaning of *oob are those of the corresponding direct entry point
+ * (the partition kernel hands the events an LDS tile cannot take to the direct kernel's own code).
+ *   tile_w, tile_h   as evk_voxel2_f32 (evk_voxel2_num_tiles(h, wd, tile_w, tile_h) > 0)
+ *   index            evk_voxel2_index_len(ntiles, n) uint32, zeroed once by the caller, persistent (as evk_voxel2_f32;
+ *                    the two paths may share one index on a stream)
+ *   scratch          evk_image2_scratch_bytes(ntiles, n, tile_w, tile_h) bytes, 16-byte aligned
+ *   host_report/seq  as evk_voxel2_f32
+ *   flags            EVK_VOXEL_OVERWRITE (nearest only): every pixel of the image is WRITTEN, the caller needs no memset;
+ *                    without it the result is added to the image (the reference's `default` image, image.py:77).  The
+ *                    bilinear call always adds.  EVK_VOXEL2_PARTITION_ONLY / _TILES_ONLY / _NO_XCD_ORDER as evk_voxel2_f32.
+ *                    EVK_IMAGE2_NO_FIXED: bilinear windows in float64 even when every weight is +1, -1 or +0 (A/B).
+ * Columns 16-byte aligned (EVK_EALIGN otherwise).  evk_image2_nearest_i32: w == NULL counts the events (weight 1). */
+#define EVK_IMAGE2_NO_FIXED 512
+int64_t evk_image2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h);
+int evk_image2_nearest_i32(const int32_t *x, const int32_t *y, const int32_t *w, int64_t n, int canvas_h, int canvas_w,
+                           int tile_w, int tile_h, int flags, int32_t *canvas, uint32_t *index, void *scratch,
+                           int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+int evk_image2_nearest_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                           float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
+                           int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
+                            float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
+                            int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
  * one workgroup per (work item, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted
  * by the slice's displacement), stores it to `staging`; a gather kernel adds the windows covering each canvas pixel to

@@ -1,0 +1,194 @@
+"""GPU (-m gpu): the event images on the one-pass partition + LDS-tile design (evk_image2.hip) against the oracle --
+events_to_image (integer image, bit-exact) and events_to_image_torch (nearest / bilinear, 1e-5 of the image's maximum) at
+the full 10 M-event size of BASELINE.json configs[1]'s sensor, on structured scenes whose hot tiles are cut, and on the
+inputs only the partition kernel's rare path can take (negative pixels that wrap, out-of-range ones that raise, weights
+that need all 32 bits).  The golden vectors f1 / f4 and the 16 random option-space variants run with this path forced in
+test_gpu_parity.py / test_gpu_stress.py (impl = "tiled")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import event_utils_amd as E
+    from event_utils_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return E
+
+
+@pytest.fixture(autouse=True)
+def _tiled(monkeypatch):
+    monkeypatch.setenv("EVK_IMPL", "tiled")
+
+
+def close(a, ref, tol=1e-5):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    assert a.shape == ref.shape
+    assert np.max(np.abs(a - ref)) <= tol * max(np.max(np.abs(ref)), 1e-30), np.max(np.abs(a - ref))
+
+
+def test_integer_image_10m_events_bit_exact(E):
+    """10 M events on the 640x480 sensor: +-1 polarities, the count image, and integer weights that do not fit the record's
+    21 bits (side array) -- all equal to np.bincount bit for bit."""
+    rng = np.random.default_rng(11)
+    n, H, W = 10_000_000, 480, 640
+    xs, ys = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n)      # the (H+1, W+1) canvas: x == W, y == H are legal
+    ps = rng.integers(0, 2, n) * 2 - 1
+    assert np.array_equal(E.events_to_image(xs, ys, ps, sensor_size=(H, W)), R.events_to_image(xs, ys, ps, sensor_size=(H, W)))
+    cnt = E.events_to_image(xs, ys, np.ones_like(ps), sensor_size=(H, W), meanval=False)
+    assert np.array_equal(cnt, R.events_to_image(xs, ys, np.ones_like(ps), sensor_size=(H, W)))
+    m = 1_000_000
+    big = rng.integers(-2_000, 2_000, m)
+    big[::7] = rng.integers(-(2 ** 20) - 5, 2 ** 20 + 5, big[::7].shape[0])       # around the 21-bit limit, both sides
+    assert np.array_equal(E.events_to_image(xs[:m], ys[:m], big, sensor_size=(H, W)),
+                          R.events_to_image(xs[:m], ys[:m], big, sensor_size=(H, W)))
+    a = E.events_to_image(xs[:m], ys[:m], ps[:m], sensor_size=(H, W), meanval=True, default=3)
+    assert np.array_equal(a, R.events_to_image(xs[:m], ys[:m], ps[:m], sensor_size=(H, W), meanval=True, default=3))
+
+
+@pytest.mark.parametrize("weights", ["unit", "float"])
+def test_float_images_10m_events_against_the_oracle(E, weights):
+    rng = np.random.default_rng(12)
+    n, H, W = 10_000_000, 480, 640
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32) if weights == "unit" else rng.normal(size=n).astype(np.float32)
+    xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
+    for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True),
+               dict(interpolation='bilinear', padding=False, clip_out_of_range=True)):
+        ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+        got = E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw)
+        assert got.is_cuda and got.dtype == torch.float32
+        # (float weights: sums of ~30 N(0, 1) terms per pixel; the bar is relative to the image's maximum)
+        close(got.cpu().numpy(), ref)
+    # unit weights are counted in integers: bit-reproducible from run to run, nearest and bilinear
+    if weights == "unit":
+        for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True)):
+            a = E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw)
+            b = E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw)
+            if kw["interpolation"] is None:
+                assert torch.equal(a, b)
+            else:       # (the window rings meet in float32 global atomics: equal up to their order)
+                close(a.cpu().numpy(), b.cpu().numpy(), 1e-6)
+
+
+@pytest.mark.parametrize("scene", ["blob", "one_pixel", "edges"])
+def test_structured_scenes_cut_hot_tiles(E, scene):
+    """Half of the events in a 40x30 patch / on ONE pixel / on two moving edges: hot tiles are cut into pieces whose partial
+    tiles the last piece sums; segments are long (streamed by whole waves)."""
+    rng = np.random.default_rng(13)
+    n, H, W = 3_000_000, 480, 640
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    if scene == "blob":
+        hot = rng.random(n) < 0.5
+        x[hot] = rng.uniform(300, 340, hot.sum()).astype(np.float32); y[hot] = rng.uniform(200, 230, hot.sum()).astype(np.float32)
+    elif scene == "one_pixel":
+        hot = rng.random(n) < 0.5
+        x[hot] = 123.25; y[hot] = 77.5
+    else:
+        t = np.linspace(0, 1, n)
+        hot = rng.random(n) < 0.8
+        x[hot] = (100 + 400 * t[hot] + rng.normal(0, 0.7, hot.sum())).astype(np.float32)
+        x = np.clip(x, 0, W - 1.001).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
+    for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True)):
+        ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+        close(E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw).cpu().numpy(), ref)
+        w = rng.normal(size=n).astype(np.float32)            # float64 accumulators
+        ref = R.events_to_image_torch(x, y, w, sensor_size=(H, W), accum="f64", **kw)
+        mag = R.events_to_image_torch(x, y, np.abs(w), sensor_size=(H, W), accum="f64", **kw)
+        got = E.events_to_image_torch(xd, yd, torch.from_numpy(w).cuda(), sensor_size=(H, W), **kw).cpu().numpy()
+        assert np.max(np.abs(got.astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag)
+    xi, yi = x.astype(np.int64), y.astype(np.int64)
+    pi = p.astype(np.int64) * 3
+    assert np.array_equal(E.events_to_image(xi, yi, pi, sensor_size=(H, W)), R.events_to_image(xi, yi, pi, sensor_size=(H, W)))
+
+
+def test_rare_events_take_the_direct_kernels_route(E):
+    """Bilinear: pixels at -1 wrap to the last column / row (index_put_), masked events land on (0, 0) with weight 0,
+    events whose right / lower neighbour is outside raise; nearest: clipped events pile up at (0, 0) WITH their weight (Q8),
+    negative indices wrap.  A few thousand of them among 400 k ordinary events."""
+    rng = np.random.default_rng(14)
+    n, H, W = 400_000, 120, 160
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    p = rng.normal(size=n).astype(np.float32)
+    x[:3000] = rng.uniform(-1, 0, 3000).astype(np.float32)          # px = -1 -> wraps to W (padded image: W + 1 columns)
+    y[3000:5000] = rng.uniform(-1, 0, 2000).astype(np.float32)
+    x[5000:9000] = rng.uniform(W, W + 5, 4000).astype(np.float32)   # beyond clipx: masked
+    y[9000:9500] = np.float32(H + 0.5)
+    for padding in (True, False):
+        kw = dict(interpolation='bilinear', padding=padding)
+        ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+        got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W), **kw)
+        close(got.numpy(), ref)
+    for padding in (True, False):
+        kw = dict(interpolation=None, padding=padding)
+        ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+        mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), accum="f64", **kw)
+        got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W), **kw)
+        assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag)
+    # without clipping the out-of-range events raise, as index_put_ does -- on both kernel families, with the same count
+    xs, ys, ps = (torch.from_numpy(a) for a in (x, y, p))
+    msgs = []
+    for kw in (dict(interpolation='bilinear', padding=False), dict(interpolation=None, padding=False)):
+        with pytest.raises(IndexError) as ei:
+            E.events_to_image_torch(xs, ys, ps, sensor_size=(H, W), clip_out_of_range=False, **kw)
+        msgs.append(str(ei.value))
+    import os
+    os.environ["EVK_IMPL"] = "direct"
+    try:
+        for i, kw in enumerate((dict(interpolation='bilinear', padding=False), dict(interpolation=None, padding=False))):
+            with pytest.raises(IndexError) as ei:
+                E.events_to_image_torch(xs, ys, ps, sensor_size=(H, W), clip_out_of_range=False, **kw)
+            assert str(ei.value) == msgs[i]
+    finally:
+        os.environ["EVK_IMPL"] = "tiled"
+    # a NaN weight poisons exactly the pixels the reference poisons
+    q = p.copy(); q[20_000] = np.nan
+    ref = R.events_to_image_torch(x, y, q, sensor_size=(H, W), accum="f64", interpolation='bilinear', padding=True)
+    got = E.events_to_image_torch(xs, ys, torch.from_numpy(q), sensor_size=(H, W), interpolation='bilinear', padding=True).numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(ref).sum() == 4
+
+
+def test_device_resident_image_calls_defer_their_error(E, monkeypatch):
+    """Events and image on the device: the call only enqueues; an IndexError surfaces at the next call on the stream or at
+    check_errors() (EVK_ERRORS=strict raises before returning)."""
+    from event_utils_amd import _device as D
+    n, H, W = 300_000, 100, 100
+    rng = np.random.default_rng(15)
+    x = torch.from_numpy(rng.uniform(0, W - 1, n).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.uniform(0, H - 1, n).astype(np.float32)).cuda()
+    p = torch.ones(n, device="cuda")
+    bad = x.clone(); bad[5] = 5000.0
+    monkeypatch.setenv("EVK_ERRORS", "deferred")
+    E.events_to_image_torch(bad, y, p, sensor_size=(H, W), clip_out_of_range=False, padding=False)   # enqueues
+    with pytest.raises(IndexError):
+        D.check_errors()
+    good = E.events_to_image_torch(x, y, p, sensor_size=(H, W), padding=False)
+    D.check_errors()
+    assert abs(good.double().sum().item() - n) < 1e-3
+    monkeypatch.setenv("EVK_ERRORS", "strict")
+    with pytest.raises(IndexError):
+        E.events_to_image_torch(bad, y, p, sensor_size=(H, W), clip_out_of_range=False, padding=False)
+
+
+def test_odd_sizes_and_tiny_images(E):
+    """Images smaller than a tile, one-pixel-wide images (bilinear falls back to the direct kernel), event counts that are
+    not multiples of four."""
+    rng = np.random.default_rng(16)
+    for (H, W, n) in ((5, 7, 1001), (1, 50, 777), (33, 2, 4099), (9, 1000, 65_537), (300, 17, 123_457)):
+        x = rng.uniform(0, max(W - 1, 0.5), n).astype(np.float32); y = rng.uniform(0, max(H - 1, 0.5), n).astype(np.float32)
+        p = rng.normal(size=n).astype(np.float32)
+        for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True)):
+            ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+            mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), accum="f64", **kw)
+            got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W), **kw)
+            assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag)
+        xi, yi, pi = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n), rng.integers(-9, 10, n)
+        assert np.array_equal(E.events_to_image(xi, yi, pi, sensor_size=(H, W)), R.events_to_image(xi, yi, pi, sensor_size=(H, W)))

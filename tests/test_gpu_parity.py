@@ -35,7 +35,9 @@ def E():
 
 
 # ------------------------------------------------------------------------------------------------ F1 / C1
-def test_f1_image_nearest_int_bit_exact(E, golden):
+@pytest.mark.parametrize("impl", ["auto", "tiled"])
+def test_f1_image_nearest_int_bit_exact(E, golden, impl, monkeypatch):
+    monkeypatch.setenv("EVK_IMPL", impl)   # "tiled": the one-pass partition + LDS tiles (evk_image2.hip) at any size
     g = golden("f1_image_nearest_int")
     xs, ys, ps = g["xs"].astype(np.int64), g["ys"].astype(np.int64), g["ps"].astype(np.int64)
     ss = tuple(g["sensor_size"])
@@ -184,7 +186,9 @@ def test_c2_voxel_vga_mass_and_oracle(E):
 
 
 # ------------------------------------------------------------------------------------------------ F4 image torch
-def test_f4_image_torch(E, golden):
+@pytest.mark.parametrize("impl", ["auto", "tiled"])
+def test_f4_image_torch(E, golden, impl, monkeypatch):
+    monkeypatch.setenv("EVK_IMPL", impl)
     g = golden("f4_image_torch")
     xs, ys, ps = (torch.from_numpy(g[k]) for k in ("xs", "ys", "ps"))
     ss = tuple(g["sensor_size"])

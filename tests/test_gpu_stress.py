@@ -177,13 +177,15 @@ def test_full_size_voxel_per_gpu_share_of_configs4(monkeypatch):
     _close(vt, _voxel_f32_device(*cols, B, (H, W), t0, t1))
 
 
+@pytest.mark.parametrize("impl", ["auto", "tiled"])
 @pytest.mark.parametrize("seed", range(16))
-def test_random_event_image_variants_equal_the_oracle(seed):
+def test_random_event_image_variants_equal_the_oracle(seed, impl, monkeypatch):
     """events_to_image_torch over its whole option space -- nearest / bilinear, padding, clip_out_of_range, default,
     integer or real coordinates, coordinates beyond the sensor (clipped ones pile up at (0, 0) with their weight, Q8) --
     and events_to_image (numpy path, meanval / bilinear) against the oracle on random inputs."""
     import event_utils_amd as E
     from oracle import reference_np as R
+    monkeypatch.setenv("EVK_IMPL", impl)   # "tiled": one-pass partition + LDS tiles at any size (evk_image2.hip)
     rng = np.random.default_rng(4000 + seed)
     H, W = int(rng.integers(4, 90)), int(rng.integers(4, 120))
     n = int(rng.choice([1, 33, 5000, 60_000]))
