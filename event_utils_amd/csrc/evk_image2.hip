@@ -492,7 +492,9 @@ static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile
         return EVK_EINVAL;
     if (host_report && ((uintptr_t)host_report & 7u)) return EVK_EALIGN;
     ic.ntiles = ic.g.tiles_x * ic.g.tiles_y;
-    if (ic.ntiles > evk_voxel2_max_tiles() || (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX) return EVK_EINVAL;
+    if (ic.ntiles > evk_voxel2_max_tiles() || !evk_voxel2_num_tiles(h, wd, tile_w, tile_h) ||
+        (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX)
+        return EVK_EINVAL;
     ic.L = v2_layout(ic.ntiles, n, 2, tile_w, tile_h, true);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
     if (scratch_bytes < ic.L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;

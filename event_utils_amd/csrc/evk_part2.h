@@ -43,6 +43,9 @@ namespace evk {
 #ifndef V2_XY_PREFETCH
 #define V2_XY_PREFETCH 1   // load x, y of sub-chunk j + 1 before the placement of j (else at the top of j + 1)
 #endif
+#ifndef V2_PLACE_BATCH
+#define V2_PLACE_BATCH 1   // (A/B) the placement's returning LDS atomics all issued before the first record is built
+#endif
 #ifndef V2_ABLATE_A
 #define V2_ABLATE_A 99
 #endif
@@ -415,12 +418,27 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         }
         // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot of the sorted buffer, where
         //      its record is built
+        // (V2_PLACE_BATCH, round 4: the EPT returning atomics are issued back to back and the records built behind them -- one
+        // LDS round trip per pass instead of EPT dependent ones; the compiler cannot do it itself, cursors and sorted buffer
+        // may alias for all it knows)
+        uint32_t pos_[EPT];
+        if constexpr (V2_PLACE_BATCH) {
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                pos_[s2] = 0;
+                if (kl[s2] != 0xFFFFFFFFu) pos_[s2] = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+            }
+        }
+        auto slot_of = [&](int s2) -> uint32_t {
+            if constexpr (V2_PLACE_BATCH) return pos_[s2];
+            else return atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+        };
         if constexpr (REC == 8) {
             uint32_t wide_mask = 0;
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {
                 if (kl[s2] != 0xFFFFFFFFu) {
-                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    const uint32_t pos = slot_of(s2);
                     const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
                     // (a polarity that is not finite is always "wide": the tile kernel treats it in its rare branch)
                     const bool wide = ((pbits & ~V2_P_MASK) != 0u) | ((pbits & 0x7F800000u) == 0x7F800000u);
@@ -439,7 +457,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {
                 if (kl[s2] != 0xFFFFFFFFu) {
-                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    const uint32_t pos = slot_of(s2);
                     bool wide, unit;
                     const uint32_t pay = c.payload(tpr + C::TPW * (s2 / G), s2 % G, wide, unit);
                     nwide += (unit ? 0u : 0x10000u) + (wide ? 1u : 0u);
@@ -453,7 +471,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {
                 if (kl[s2] != 0xFFFFFFFFu) {
-                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    const uint32_t pos = slot_of(s2);
                     bool wide, unit;
                     (void)c.payload(tpr + C::TPW * (s2 / G), s2 % G, wide, unit);
                     nwide += unit ? 0u : 0x10000u;
@@ -491,7 +509,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                     }
                 }
                 if (live) {
-                    const uint32_t pos = atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
+                    const uint32_t pos = slot_of(s2);
                     sorted4[pos] = word;
                 }
             }

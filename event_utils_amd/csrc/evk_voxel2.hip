@@ -634,6 +634,9 @@ extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, i
 extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
     TileGridG g;
     if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK) return 0;
+    // the partition kernel's LDS with its largest sorted buffer (12 K events x 8 bytes, or the bilinear image format's
+    // 8 K x 12): the tile counters must fit beside it
+    if (v2_part_lds(1024, 12, 8, g.tiles_x * g.tiles_y) > (size_t)V2_LDS_LIMIT) return 0;
     return g.tiles_x * g.tiles_y;
 }
 
@@ -675,7 +678,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         return EVK_EINVAL;
     if (host_report && ((uintptr_t)host_report & 7u)) return EVK_EALIGN;   // written with one 8-byte store
     const int ntiles = g.tiles_x * g.tiles_y;
-    if (ntiles > evk_voxel2_max_tiles()) return EVK_EINVAL;
+    if (ntiles > evk_voxel2_max_tiles() || !evk_voxel2_num_tiles(h, wd, tile_w, tile_h)) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
     const size_t lds_static = 12 * 8 * V2_CHUNK_CAP(512) + 64;             // the tile kernel's chunk lists (512 threads, either record size)

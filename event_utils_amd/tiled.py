@@ -610,39 +610,31 @@ def _time_ms(fn, reps):
     return float(e0.elapsed_time(e1) / reps)
 
 
-def time_voxel_kernels(xd, yd, td, pd, t_first, t_last, B, H, W, impl=None, reps=10):
-    """HIP-event timing (on the launch stream) of the stages one voxel call launches, for bench.py's roofline:
-    'bucket' = histogram + scans + scatter, 'tile' = the LDS accumulate kernel; 'direct' = the global-atomic kernel."""
+def time_voxel_kernels(sets, t_first, t_last, B, H, W, impl=None, reps=10):
+    """HIP-event timing (on the launch stream) of the kernels one voxel call launches, for bench.py's roofline.  `sets` =
+    one or more (x, y, t, p) column tuples: the timed calls rotate over them (several sets that together exceed the
+    Infinity Cache make every call read its events from HBM)."""
     import torch
     impl = impl or default_impl()
+    xd = sets[0][0]
     out = torch.zeros((B, H, W), dtype=torch.float32, device=xd.device)
-    if not (can_tile((xd, yd, td, pd), impl) and B * 8 * 64 <= 65536):
-        ms = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="direct"), reps)
+    it = [0]
+
+    def cols():
+        it[0] += 1
+        return sets[it[0] % len(sets)]
+    reps = max(reps, len(sets)) // len(sets) * len(sets)
+    shape2 = voxel2_shape(H, W, B)
+    if not (can_tile(sets[0], impl) and shape2 is not None):
+        ms = _time_ms(lambda: voxel_f32(*cols(), t_first, t_last, B, H, W, out, None, impl="direct"), reps)
         return {"impl": "direct", "dominant": "k_voxel_f32", "dominant_ms": ms, "total_ms": ms,
-                "kernels_ms": {"k_voxel_f32": round(ms, 4)}}
-    total = _time_ms(lambda: voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True),
-                     reps)
-    shape2 = voxel2_shape(H, W, B) if voxel_path() == "v2" else None
-    if shape2 is not None:
-        n = xd.shape[0]
-        run2 = lambda stage: voxel2((xd, yd, td, pd), None, n, t_first, t_last, B, H, W, *shape2, out, None, True, stage=stage)
-        kp, kt = "k_part_sorted", "k_voxel_tiles2"
-        ms = {kp: _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps),
-              kt: _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)}
-        dom = max(ms, key=ms.get)
-        return {"impl": "one-pass partition, tiles %dx%d" % shape2, "dominant": dom,
-                "dominant_ms": ms[dom], "total_ms": total, "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}
-    tw, th = voxel_tile_shape(H, W, B)
-    bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th)
-    ms = {}
-    run = lambda st: bucket_events(xd, yd, td, pd, 0, H, W, tw, th, stages=st, into=bk)
-    # the stages are not idempotent (the scan rewrites the histogram table in place): time the histogram alone, the
-    # scans as (hist + scan) - hist, then restore a consistent table with a full run and time the scatter alone
-    ms["k_tile_hist"] = _time_ms(lambda: run(1), reps)
-    ms["k_tile_scan_blocks+k_tile_scan_totals"] = max(_time_ms(lambda: run(3), reps) - ms["k_tile_hist"], 0.0)
-    run(7)
-    ms["k_tile_scatter_wc"] = _time_ms(lambda: run(4), reps)
-    ms["k_voxel_tiled"] = _time_ms(lambda: voxel_tiled(bk, t_first, t_last, B, H, W, out, True), reps)
+                "kernels_ms": {"k_voxel_f32": round(ms, 4)}, "kernels_ms_exact": {"k_voxel_f32": ms}}
+    total = _time_ms(lambda: voxel_f32(*cols(), t_first, t_last, B, H, W, out, None, impl="tiled", fresh=True), reps)
+    n = xd.shape[0]
+    run2 = lambda stage: voxel2(cols(), None, n, t_first, t_last, B, H, W, *shape2, out, None, True, stage=stage)  # noqa: E731
+    # (the tile kernel alone re-reads the records the LAST partition left: time it right behind a partition of every set)
+    ms = {"k_part_sorted": _time_ms(lambda: run2(_lib.EVK_VOXEL2_PARTITION_ONLY), reps)}
+    ms["k_voxel_tiles2"] = _time_ms(lambda: run2(_lib.EVK_VOXEL2_TILES_ONLY), reps)
     dom = max(ms, key=ms.get)
-    return {"impl": "tiled %dx%d" % (1 << tw, 1 << th), "dominant": dom, "dominant_ms": ms[dom], "total_ms": total,
-            "kernels_ms": {k: round(v, 4) for k, v in ms.items()}}
+    return {"impl": "one-pass partition, tiles %dx%d" % shape2, "dominant": dom, "dominant_ms": ms[dom], "total_ms": total,
+            "kernels_ms": {k: round(v, 4) for k, v in ms.items()}, "kernels_ms_exact": dict(ms)}

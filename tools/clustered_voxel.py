@@ -54,6 +54,6 @@ for kind in ("uniform", "edges", "blob", "pixel"):
         res.append(a.elapsed_time(b) / 10)
         ref = out.clone() if impl == "tiled" else ref
     err = (out - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
-    k = tiled.time_voxel_kernels(*cols, 0.0, 0.1, B, H, W, impl="tiled", reps=5)["kernels_ms"]
+    k = tiled.time_voxel_kernels([cols], 0.0, 0.1, B, H, W, impl="tiled", reps=5)["kernels_ms"]
     print("%-8s tiled %.3f ms (%5.1f Gev/s)   direct %.3f ms   rel.diff %.1e   %s" %
           (kind, res[0], n / res[0] / 1e6, res[1], err, {a: round(b, 3) for a, b in k.items()}))

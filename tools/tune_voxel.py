@@ -14,7 +14,7 @@ p = torch.from_numpy((rng.integers(0, 2, n) * 2 - 1).astype(np.float32)).cuda()
 for shape in ("3x3", "4x3", "4x4", "5x4", "5x5", "6x5", "6x6"):
     os.environ["EVK_VOXEL_TILE"] = shape
     try:
-        r = tiled.time_voxel_kernels(x, y, t, p, 0.0, 0.1, B, H, W, impl="tiled", reps=10)
+        r = tiled.time_voxel_kernels([(x, y, t, p)], 0.0, 0.1, B, H, W, impl="tiled", reps=10)
         print(shape, json.dumps(r))
     except Exception as e:
         print(shape, "ERR", e)

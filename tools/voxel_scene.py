@@ -27,6 +27,6 @@ for (H, W, n) in ((480, 640, 10_000_000), (720, 1280, 50_000_000)):
             y[hot] = (H // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
             t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
         cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
-        k = tiled.time_voxel_kernels(*cols, float(t[0]), float(t[-1]), 5, H, W, impl="tiled", reps=10)
+        k = tiled.time_voxel_kernels([cols], float(t[0]), float(t[-1]), 5, H, W, impl="tiled", reps=10)
         print("%dx%d n=%d %-8s total %.4f ms  %s" % (W, H, n, scene, k["total_ms"], k["kernels_ms"]), flush=True)
         del cols

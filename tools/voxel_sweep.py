@@ -86,7 +86,7 @@ def timing(n, H, W, B, reps=20, paths=("v2",), kind="uniform"):
     for path in paths:
         if len(paths) > 1:
             os.environ["EVK_VOXEL_PATH"] = path
-        k = tiled.time_voxel_kernels(*cols, float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
+        k = tiled.time_voxel_kernels([cols], float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
         alg = 16.0 * n + B * H * W * 4
         print("%s %-7s n=%d %dx%dx%d: total %.4f ms (%.1f Gev/s, whole-call frac %.3f)  %s  [%s]" % (
             path, kind, n, H, W, B, k["total_ms"], n / k["total_ms"] / 1e6, alg / (k["total_ms"] * 1e-3) / 8e12,
