@@ -766,7 +766,8 @@ static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw, int th, boo
     L.rec = L.bases + al256((int64_t)q.nsc * 4);
     L.pw = L.rec + al256(slots * 8);        // (sized for either record format: 8 + 4 or 4 + 8 bytes per slot)
     L.staging = L.pw + al256(slots * 8);
-    L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * v2_staging_stride((int64_t)planes * tw * th) * 4);
+    // (8 bytes per cell: the pieces of a cut tile hand over float32 partial tiles, or -- integer accumulators -- exact int64 ones)
+    L.total = L.staging + al256((int64_t)v2_max_items(n, ntiles) * v2_staging_stride((int64_t)planes * tw * th) * 8);
     return L;
 }
 

@@ -586,14 +586,38 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // split (hot) tile: as k_voxel_tiled -- partial tiles to staging, the last part to arrive sums them in part order
     const int cells = NB * tpix;
     const int64_t stride = v2_staging_stride(cells);   // whole 128-byte lines per item: no line is shared by two items
-    float *mine = staging + (int64_t)item * stride;
     // The partial tile goes to the staging buffer with AGENT-SCOPE stores and is read back with agent-scope loads: such
     // accesses are performed at the level all XCDs share, complete (vmcnt) only when they are, and never hit a stale line of
     // this XCD's L2 -- so the hand-over to the last part needs no release / acquire FENCE, which on this chip is a write-back
     // (and an invalidate) of the whole L2 with everything the other workgroups have flushed into it (blob scene: tile kernel
     // 48.7 -> 46.3 us).  Every wave drains its own stores before the barrier; one lane then takes the ticket.
-    for (int c = threadIdx.x; c < cells; c += WG)
-        __hip_atomic_store(mine + c, lds_cell(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    //
+    // INTEGER accumulators (the counting mode, EVK_VOXEL_DETERMINISTIC) hand over the EXACT int64 value of every cell and the
+    // last part adds integers, with ONE rounding to float32 at the end (round 4): the grid then does not depend on where the
+    // tiles were cut, i.e. it is bit-identical for any order of the events also on scenes with hot tiles.  (Round 3 staged
+    // float32 partial tiles for every mode: a permuted stream moved events between the pieces and changed their roundings.)
+    // LLONG_MIN marks a poisoned cell (NaN t_norm).
+    const bool exactq = unit || FIXED;
+    const double qscale = unit ? 1.0 / G_ONE : 1.0 / V2_FIXED_ONE;
+    auto lds_cell_q = [&](int c) -> long long {
+        int b, row, col;
+        split_cell(c, b, row, col);
+        const int l = row * tpitch + col;
+        if (unit) {
+            if ((poison[l >> 5] >> (l & 31)) & 1u) return (long long)0x8000000000000000ull;
+            return ((long long)s0[b * ppix + l] << 31) - (long long)gq[(b + 1) * ppix + l] + (long long)gq[b * ppix + l];
+        }
+        return __builtin_bit_cast(long long, acc[b * ppix + l]);
+    };
+    float *mine = staging + 2 * (int64_t)item * stride;
+    if (exactq) {
+        unsigned long long *mq = reinterpret_cast<unsigned long long *>(mine);
+        for (int c = threadIdx.x; c < cells; c += WG)
+            __hip_atomic_store(mq + c, (unsigned long long)lds_cell_q(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        for (int c = threadIdx.x; c < cells; c += WG)
+            __hip_atomic_store(mine + c, lds_cell(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int is_last;
@@ -605,11 +629,25 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     }
     __syncthreads();
     if (!is_last) return;
-    const float *parts = staging + (int64_t)first_item * stride;
+    const float *parts = staging + 2 * (int64_t)first_item * stride;
+    if (exactq) {
+        const unsigned long long *pq = reinterpret_cast<const unsigned long long *>(parts);
+        flush([&](int c) {
+            long long sum = 0;
+            bool nan = false;
+            for (uint32_t p = 0; p < nparts; ++p) {
+                const long long v = (long long)__hip_atomic_load(pq + (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nan |= v == (long long)0x8000000000000000ull;
+                sum += v;
+            }
+            return nan ? __uint_as_float(0x7FC00000u) : (float)((double)sum * qscale);
+        });
+        return;
+    }
     flush([&](int c) {
         float sum = 0.0f;
         for (uint32_t p = 0; p < nparts; ++p)
-            sum += __hip_atomic_load(parts + (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += __hip_atomic_load(parts + 2 * (int64_t)p * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return sum;
     });
 }

@@ -288,3 +288,77 @@ def test_optimize_at_configs3_size_converges_and_matches_the_direct_kernels():
                       np.asarray(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0), dtype=np.float64))
     assert abs(vals["tiled"][0] - vals["direct"][0]) <= 1e-5 * abs(vals["direct"][0])
     assert np.abs(vals["tiled"][1] - vals["direct"][1]).max() <= 1e-5 * np.abs(vals["direct"][1]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size comparisons with the oracle (round 4): BASELINE.json's sizes on the DEFAULT dispatch (the code paths that are
+# switched by size -- 4-byte voxel records above 16 M events, compact IWE records beyond the Infinity Cache, the tile
+# kernels' workgroup shapes -- run as a user gets them), against oracle/reference_np.py with float64 accumulation.
+# Bar: 1e-5 of the reference's maximum.  The oracle needs 0.5-12 s per case on one host core.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rel(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.max(np.abs(a - ref)) / max(np.max(np.abs(ref)), 1e-30)
+
+
+def test_full_size_voxel_configs1_against_the_oracle():
+    """configs[1]: 10 M events, 640x480, 5 bins."""
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    rng = np.random.default_rng(1)
+    H, W, B, n = 480, 640, 5, 10_000_000
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    got = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W)).cpu().numpy()
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    assert _rel(got, ref) <= 1e-5
+    # weights that are not +-1: the float64 two-atomic path of the tile kernel
+    pw = (p * rng.uniform(0.1, 3.0, n)).astype(np.float32)
+    got = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, pw)), B, sensor_size=(H, W)).cpu().numpy()
+    assert _rel(got, R.events_to_voxel_torch(x, y, t, pw, B, sensor_size=(H, W), accum="f64")) <= 1e-5
+
+
+def test_full_size_voxel_configs4_share_against_the_oracle():
+    """One rank's share of configs[4]: 50 M events, 1280x720, 5 bins (4-byte records, HBM-resident)."""
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    rng = np.random.default_rng(9)
+    H, W, B, n = 720, 1280, 5, 50_000_000
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    got = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W)).cpu().numpy()
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    assert _rel(got, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("cfg", [("configs[2]", 10_000_000, 480, 640, "uniform"), ("configs[3]", 50_000_000, 720, 1280, "edges")])
+def test_full_size_iwe_and_objective_against_the_oracle(cfg):
+    """configs[2] (10 M events, 640x480): IWE, dIWE, objective and gradient; configs[3] (50 M events, 1280x720, the
+    moving-edge scene of the optimize() benchmark): IWE + dIWE, objective and gradient at one flow."""
+    import bench
+    import event_utils_amd as E
+    from oracle import reference_np as R
+    from event_utils_amd.contrast_max.objectives import iwe_device
+    _, n, H, W, scene = cfg
+    if scene == "uniform":
+        rng = np.random.default_rng(2)
+        x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+        t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    else:
+        x, y, t, p = bench.structured_scene(3, n, H, W)
+    prm = np.array([30., -20.])
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    iwe, diwe = iwe_device(prm, ev, (H, W), True, True, (H, W))
+    d = [a.astype(np.float64) for a in (x, y, t, p)]
+    ri, rd = R.get_iwe(prm, *d, R.linvel_warp(), (H, W), compute_gradient=True, sensor_size=(H, W), accum="f64")
+    assert _rel(iwe.cpu().numpy(), ri) <= 1e-5
+    assert _rel(diwe.cpu().numpy(), rd) <= 1e-5
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.sensor_size = (H, W)
+    robj = R.variance_objective(); robj.sensor_size = (H, W); robj.accum = "f64"
+    f = float(obj.evaluate_function(prm, ev, None, None, None, w, (H, W), 1.0))
+    g = np.asarray(obj.evaluate_gradient(prm, ev, None, None, None, w, (H, W), 1.0), np.float64)
+    fr = float(robj.evaluate_function(prm, *d, R.linvel_warp(), (H, W), 1.0, iwe=ri))
+    gr = np.asarray(robj.evaluate_gradient(prm, *d, R.linvel_warp(), (H, W), 1.0, iwe=ri, d_iwe=rd), np.float64)
+    assert abs(f - fr) <= 1e-5 * abs(fr), (f, fr)
+    assert np.max(np.abs(g - gr)) <= 1e-5 * np.max(np.abs(gr)) + 1e-9, (g, gr)

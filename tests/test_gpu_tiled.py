@@ -126,6 +126,42 @@ def test_voxel_deterministic_mode_is_bit_reproducible_at_full_size(E, monkeypatc
                                 sensor_size=(H, W))
 
 
+@pytest.mark.parametrize("mode", ["counting", "fixed"])
+def test_integer_modes_are_order_free_also_where_hot_tiles_are_cut(E, monkeypatch, mode):
+    """Half of the events in a 100x100 px blob: its tiles are cut into pieces whose partial tiles the last piece sums.  The
+    integer modes -- the unit-polarity counting mode (default) and EVK_VOXEL_DETERMINISTIC with arbitrary weights -- hand
+    the pieces' EXACT int64 cells over and round once, so a permuted stream (which moves events between the pieces) gives the
+    same bits (round 3 staged float32 partial tiles: only run-to-run reproducible)."""
+    n, H, W, B = 4_000_000, 480, 640, 5
+    x, y, t, p = _events(31, n, H, W)
+    rng = np.random.default_rng(8)
+    hot = rng.random(n) < 0.5
+    x[hot] = (W // 3 + rng.integers(0, 100, int(hot.sum()))).astype(np.float32)
+    y[hot] = (H // 3 + rng.integers(0, 100, int(hot.sum()))).astype(np.float32)
+    if mode == "fixed":
+        p = (p * rng.uniform(0.1, 3.0, n)).astype(np.float32)
+        monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
+    # blocks of 4096 consecutive events share ONE time stamp, so that permuting inside a block keeps the stream sorted
+    blk = 4096
+    t = np.repeat(t[::blk], blk)[:n].astype(np.float32)
+    base = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, p)), B, sensor_size=(H, W)).cpu().numpy()
+    from oracle import reference_np as R
+    close(base, R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+    perm = np.concatenate([rng.permutation(blk) + i * blk for i in range(n // blk)] + [np.arange(n // blk * blk, n)])
+    assert perm.shape[0] == n
+    again = E.events_to_voxel_torch(*(torch.from_numpy(np.ascontiguousarray(a[perm])).cuda() for a in (x, y, t, p)), B,
+                                    sensor_size=(H, W)).cpu().numpy()
+    assert np.array_equal(base, again)
+    # a different event COUNT in front moves every cut: the blob's cells must not change either
+    pad = 12_345
+    xs, ys, ts, ps = (np.concatenate([a[:1].repeat(pad), a]) for a in (x, y, t, p))
+    xs[:pad], ys[:pad] = 5.0, 5.0                     # the extra events sit on pixel (5, 5)
+    more = E.events_to_voxel_torch(*(torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (xs, ys, ts, ps)), B,
+                                   sensor_size=(H, W)).cpu().numpy()
+    more[:, 5, 5] = base[:, 5, 5]
+    assert np.array_equal(base, more)
+
+
 @pytest.mark.parametrize("kind", ["wide", "zero_one", "unsorted", "mixed", "early", "nan"])
 def test_compact_records_are_exact_for_any_input(E, monkeypatch, kind):
     """4-byte records (t_norm delta | polarity code | cell): whatever does not fit -- polarities other than +-1 / 0, time
