@@ -197,21 +197,18 @@ def main():
 
     exchange_choice = None
     if use_dist and forced not in ("0", "1"):
-        # (overlapped: the kernels leave LDS on every CU for the collective's workgroups, EVK_SHARE_CU=1 -- the library's default
+        # (overlapped: the kernels leave LDS on every CU for the collective's workgroups, share_cu -- the library's default
         # in a multi-rank job; serial: nothing runs beside them, so they take the single-GPU geometry)
-        share_before = os.environ.get("EVK_SHARE_CU")
         trial = {}
         for mode in (True, False):
             overlap = mode
-            if share_before is None:
-                os.environ["EVK_SHARE_CU"] = "1" if mode else "0"
+            tiled.FORCE["share_cu"] = mode
             trial[mode] = timed(step, max(args.steps, 20), args.warmup)     # identical on every rank (max over ranks)
         overlap = trial[True] <= trial[False]
-        if share_before is None:
-            os.environ["EVK_SHARE_CU"] = "1" if overlap else "0"
+        tiled.FORCE["share_cu"] = overlap
         exchange_choice = {"overlapped_ms": round(trial[True] / max(args.steps, 20) * 1e3, 4),
                            "serial_ms": round(trial[False] / max(args.steps, 20) * 1e3, 4),
-                           "chosen": "overlapped" if overlap else "serial", "EVK_SHARE_CU": os.environ.get("EVK_SHARE_CU")}
+                           "chosen": "overlapped" if overlap else "serial", "share_cu": overlap}
     elapsed = timed(step, args.steps, args.warmup)
     E.check_errors()                     # deferred out-of-range reports of the timed calls (none expected)
     ms_per_step = elapsed / args.steps * 1e3

@@ -9,13 +9,13 @@ LIB_PATH = os.environ.get("EVK_LIB_PATH") or os.path.join(_HERE, "csrc", "libevk
 
 EVK_IWE_ABS_POLARITY = 1
 EVK_IWE_GRADIENT = 2
-EVK_IWE_PACK32 = 8
 EVK_IWE_COMPACT = 16
 EVK_POST_MIX, EVK_POST_BLUR_IWE, EVK_POST_VALUE, EVK_POST_NONE = 1, 2, 4, 8
 EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY, EVK_VOXEL_T_FROM_EVENTS = 1, 2, 4
 EVK_VOXEL2_PARTITION_ONLY, EVK_VOXEL2_TILES_ONLY = 16, 32
 EVK_VOXEL_DETERMINISTIC = 256
 EVK_IMAGE2_NO_FIXED = 512
+EVK_VOXEL2_REC4, EVK_VOXEL2_REC8, EVK_VOXEL2_NO_COUNT, EVK_VOXEL2_WG512 = 1024, 2048, 4096, 8192
 
 P = c_void_p  # every device / host pointer crosses as void*
 

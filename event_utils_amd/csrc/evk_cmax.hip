@@ -45,10 +45,6 @@ static HostSlot *host_slot() {
     }
     return &hs;
 }
-static bool poll_enabled() {
-    static const bool on = !(getenv("EVK_CMAX_POLL") && atoi(getenv("EVK_CMAX_POLL")) == 0);
-    return on;
-}
 
 static int fetch_results(const double *out, int count, double *host_out, void *stream, const HostPublish *pub = nullptr) {
     if (!host_out) return EVK_OK;
@@ -87,7 +83,7 @@ static int post_and_fetch(int mode, const float *iwe, const float *diwe, int h, 
                           uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream, int nplanes,
                           double *host_out) {
     HostPublish pub{nullptr, nullptr, 0u};
-    HostSlot *hs = (host_out && poll_enabled()) ? host_slot() : nullptr;
+    HostSlot *hs = host_out ? host_slot() : nullptr;
     if (hs) {
         if (++hs->seq == 0) hs->seq = 1;
         pub = HostPublish{hs->vals, hs->flags, hs->seq};

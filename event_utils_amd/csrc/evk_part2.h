@@ -637,39 +637,18 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
 }
 
 // ---- host-side geometry -----------------------------------------------------------------------------------------
-// Partition geometry = threads x events per thread, ONE workgroup per CU.  The library ships the two the default dispatch
-// reaches: 1024 x 8 (sub-chunks of 8 K events: 105 registers, 68 KB of LDS -- room for the workgroups of another kernel,
-// e.g. an overlapped RCCL collective) and 1024 x 12 (12 K events: longer segments for the tile kernel, taken when there
-// are more than 680 tiles and the call need not share its CUs).  Measured and rejected (compiled
-// only with -DEVK_EXPERIMENTS, tools/exp_build.sh, and selected with EVK_V2_PART): 512x32 / 1024x16 (16 K events: the
-// whole register file, 67 / 74 us), two workgroups per CU (round 2: 1024x8 / 512x16 / 768x12, spills, 75-150 us; round 3,
-// without spills: 512x16 56.0 and 768x8 56.8 against 48 us -- the kernel moves its 240 MB at 5 TB/s, a second workgroup per
-// CU only makes the sub-chunks shorter).
+// Partition geometry = threads x events per thread, ONE workgroup per CU: 1024 x 8 (sub-chunks of 8 K events: 71 registers,
+// 68 KB of LDS -- room for the workgroups of another kernel, e.g. an overlapped RCCL collective) and 1024 x 12 (12 K events:
+// longer segments for the tile kernel, taken when there are more than 680 tiles and the call need not share its CUs).
+// Measured and rejected: 512x32 / 1024x16 (16 K events: the whole register file, 67 / 74 us), two
+// workgroups per CU (512x16 56.0 and 768x8 56.8 against 48 us: a second workgroup per CU only makes the sub-chunks shorter).
 struct V2Config {
     int threads, ept;
 };
-#ifdef EVK_EXPERIMENTS
-#define V2_GEOMETRIES(X) X(1024, 8) X(1024, 12) X(1024, 16) X(512, 16)
-#else
 #define V2_GEOMETRIES(X) X(1024, 8) X(1024, 12)
-#endif
-static V2Config v2_config_env() {
-    V2Config c{0, 0};
-    const char *geo = getenv("EVK_V2_PART");
-    int t = 0, e = 0;
-    if (geo && sscanf(geo, "%dx%d", &t, &e) == 2) {
-#define X(T, E) if (t == T && e == E) c = V2Config{T, E};
-        V2_GEOMETRIES(X)
-#undef X
-    }
-    return c;
-}
 static const V2Config &v2_config(bool share = false, int ntiles = 0) {
-    static const V2Config forced = v2_config_env();
     static const V2Config small{1024, 8}, large{1024, 12};
-    if (share) return small;
-    if (forced.threads) return forced;
-    return ntiles > 680 ? large : small;
+    return (share || ntiles <= 680) ? small : large;
 }
 #define V2_MIN_SUBCHUNK 8192
 #define V2_LDS_LIMIT (160 * 1024 - 512)   // (the partition kernel also has a few bytes of static LDS)
@@ -708,37 +687,15 @@ static inline int64_t al256(int64_t b) { return (b + 255) & ~(int64_t)255; }
 // the tile kernel counted unit polarities and ran 768 threads; with both a piece is cheaper: 2.5 / 1.25, blob 48.5 -> 43.5 us;
 // 2.5 / 1.6 once a wave lists all the chunks of a piece's long segments, in passes: 39.6 us -- and no cliff any more for
 // bigger pieces: 2 x: 45, 2.5 x: 46, 3 x: 50, 4 x: 55 us; smaller ones pay their fixed costs: 1.25 x: 41.7 us.)
-// EVK_V2_SPLIT="at,part" overrides (measurements).
-struct V2Split {
-    double at, part;
-};
-static const V2Split &v2_split() {
-    static const V2Split f = [] {
-        V2Split v{2.5, 1.6};
-        const char *s = getenv("EVK_V2_SPLIT");
-        double a = 0, p = 0;
-        if (s && sscanf(s, "%lf,%lf", &a, &p) == 2 && a >= 1.0 && p >= 0.25 && p <= a) v = V2Split{a, p};
-        return v;
-    }();
-    return f;
-}
-// (the three switches below are read on EVERY call -- a getenv costs nothing next to a launch --, so that one process can
-// run the variants side by side: the tests do)
-static bool v2_count_enabled() {   // EVK_V2_COUNT=0: no unit-polarity counting in the tile kernel (A/B measurements, tests)
-    const char *s = getenv("EVK_V2_COUNT");
-    return !(s && s[0] == '0');
-}
-static int v2_tiles_wg() {   // EVK_V2_TILES_WG=512 keeps the 512-thread tile workgroups everywhere (A/B measurements)
-    const char *s = getenv("EVK_V2_TILES_WG");
-    return s ? atoi(s) : 0;
-}
+#define V2_SPLIT_AT 2.5
+#define V2_SPLIT_PART 1.6
 static int64_t v2_mean(int64_t n, int ntiles) { return n / (ntiles > 0 ? ntiles : 1); }
 static int64_t v2_cap(int64_t n, int ntiles) {   // a tile with more events than this is cut ...
-    const int64_t c = (int64_t)(v2_split().at * (double)v2_mean(n, ntiles));
+    const int64_t c = (int64_t)(V2_SPLIT_AT * (double)v2_mean(n, ntiles));
     return c > 16384 ? c : 16384;
 }
 static int64_t v2_part(int64_t n, int ntiles) {   // ... into pieces of at most this many
-    const int64_t c = (int64_t)(v2_split().part * (double)v2_mean(n, ntiles));
+    const int64_t c = (int64_t)(V2_SPLIT_PART * (double)v2_mean(n, ntiles));
     return c > 8192 ? c : 8192;
 }
 static int v2_max_items(int64_t n, int ntiles) { return ntiles + (int)(n / v2_part(n, ntiles)) + 1; }
@@ -747,11 +704,10 @@ static int v2_max_items(int64_t n, int ntiles) { return ntiles + (int)(n / v2_pa
 // Cache (more than 16 M events): there the partition is bound by HBM bytes and 20 instead of 24 B/event make it 15 % faster
 // (50 M events: 245 -> 208 us, whole call 0.397 -> 0.366 ms, same box).  Below, the streams are cache-resident and the delta /
 // code / escape arithmetic costs what the bytes save, the tile kernel's extra decode 6 % (10 M events: 0.0838 against
-// 0.0792 ms): 8-byte records.  EVK_V2_REC=4|8 forces one (measurements, tests).
-static int v2_rec_bytes(int64_t n) {
-    const char *s = getenv("EVK_V2_REC");
-    const int forced = s ? atoi(s) : 0;
-    if (forced == 4 || forced == 8) return forced;
+// 0.0792 ms): 8-byte records.  EVK_VOXEL2_REC4 / _REC8 in `flags` force one (tests, measurements).
+static int v2_rec_bytes(int64_t n, int flags) {
+    if (flags & EVK_VOXEL2_REC4) return 4;
+    if (flags & EVK_VOXEL2_REC8) return 8;
     return n * 16 > ((int64_t)256 << 20) ? 4 : 8;
 }
 struct V2Layout {

@@ -530,7 +530,6 @@ struct IweParams {
     int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
     double vxb[2], vyb[2];           // MODE 2 (batch of 3 nearby flows): flows 1 and 2 (flow 0 is vx, vy)
     double fx_scale, fx_inv;         // FIXED 1: LDS cells hold sum(value * 2^k) as int64 (2^k = fx_scale)
-    float pair_sI, pair_sE, pair_invI, pair_invE;  // FIXED 2: 2^20 / pow2ceil(bound) for the IWE / E planes, inverses
 };
 
 // Same per-event arithmetic as evk_scatter.hip's iwe_event (parity depends on it; the polarity shortcut below is exact).
@@ -566,61 +565,9 @@ __device__ __forceinline__ bool iwe_event_f32(const float4 &r, const IweParams &
 // the host so that n * max|contribution| < 2^61 cannot overflow (k >= 26, typically 30-36): quantisation <= 2^-(k+1) per
 // event, orders of magnitude below the float32 rounding of the result, and integer adds commute, so the window sums
 // are bit-reproducible from run to run.
-//
-// FIXED 2 -- PACKED PAIRS (gradient and three-flow modes).  With 8 / 12 64-bit atomics per event these modes are LDS-atomic
-// bound, 40 % of the LDS cycles being bank conflicts of randomly placed 8-byte cells
-// (profiles/r01_c4_iwe_lds_counters.json).  The bilinear splat always touches PAIRS of neighbouring cells, so two 32-bit
-// fixed-point accumulators are packed in one 64-bit word and a pair takes ONE ds_add_rtn_u64:
-//     word += (int64)lo + ((int64)hi << 32)
-// That sum is exact modulo 2^64: the low field holds sum(lo) modulo 2^32 -- read back as a signed 32-bit number it IS
-// sum(lo) while |sum(lo)| < 2^31 -- and the high field holds sum(hi) plus the carries of the low one, which
-// (word - lo) >> 32 removes exactly.  A pair can start on an even or an odd cell, so every line has two word arrays:
-// A[j] = cells (2j, 2j+1), B[j] = cells (2j+1, 2j+2); cell c = its field in A + its field in B (same LDS footprint as
-// one 64-bit cell per pixel).  Horizontal pairs serve the IWE rows (x, x+1) and the gradient's E1 plane; the E0 plane
-// pairs (y, y+1), so it is held column-major.  Atomics per event: 4 (gradient) / 6 (three flows) instead of 8 / 12.
-// Resolution and range: every contribution is scaled by 2^20 / (its bound rounded up to a power of two), i.e.
-// |contribution| < 2^20 with a quantisation of 2^-21 of the bound (float32 inputs carry 2^-24).  A field therefore
-// overflows only after the equivalent of 1024 full-weight events on ONE pixel; the atomic returns the old word, so the
-// lane that pushes a field beyond 2^30 takes the whole word out (exchange with 0) and adds it to the output image
-// with global atomics, exactly like an event outside the window.  Nothing is lost (the exchange is atomic, and fewer than
-// 2^10 concurrent adds cannot carry a field from 2^30 past 2^31); only such hot pixels lose run-to-run bit
-// reproducibility.
-#define EVK_PAIR_SHIFT 20
-#ifndef EVK_PACK_F
-#define EVK_PACK_F 0  // experiment: packed pairs for the function-only mode too
-#endif
-struct PairOverflow {  // where the two cells of a word live in the output image, for the rare drain
-    float *lo_minus, *lo_plus, *hi_minus, *hi_plus;  // value is added to *_plus and subtracted from *_minus (nullptr: skip)
-};
-__device__ __forceinline__ long long pair_lo(unsigned long long w) { return (long long)(int)(unsigned int)w; }
-__device__ __forceinline__ long long pair_hi(unsigned long long w) { return ((long long)w - pair_lo(w)) >> 32; }
-template <typename OVF>
-__device__ __forceinline__ void add_pair(unsigned long long *word, float vlo, float vhi, float scale, float inv, OVF where) {
-    const int lo = __float2int_rn(vlo * scale), hi = __float2int_rn(vhi * scale);
-    const unsigned long long packed = (unsigned long long)(unsigned int)lo |
-                                      ((unsigned long long)(unsigned int)(hi + (lo >> 31)) << 32);
-    const unsigned long long now =
-        __hip_atomic_fetch_add(word, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + packed;
-    // a 32-bit field has left [-2^30, 2^30) iff its two top bits differ (the high field is off by the low one's borrow,
-    // i.e. by at most 1: irrelevant here)
-    const unsigned int wl = (unsigned int)now, wh = (unsigned int)(now >> 32);
-    if (((wl ^ (wl << 1)) | (wh ^ (wh << 1))) & 0x80000000u) {  // rare: a hot pixel; drain the word into the image
-        const unsigned long long taken = __hip_atomic_exchange(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const PairOverflow o = where();
-        const float fl = (float)pair_lo(taken) * inv, fh = (float)pair_hi(taken) * inv;
-        if (o.lo_plus) atomic_add(o.lo_plus, fl);
-        if (o.lo_minus) atomic_add(o.lo_minus, -fl);
-        if (o.hi_plus) atomic_add(o.hi_plus, fh);
-        if (o.hi_minus) atomic_add(o.hi_minus, -fh);
-    }
-}
-// cell c of a line of `len` cells held as A[0 .. len/2) | B[0 .. len/2)
-__device__ __forceinline__ long long pair_cell(const unsigned long long *line, int len, int c) {
-    const int half = len >> 1, j = c >> 1;
-    if (c & 1) return pair_hi(line[j]) + pair_lo(line[half + j]);
-    return pair_lo(line[j]) + (j > 0 ? pair_hi(line[half + j - 1]) : 0ll);
-}
-
+// (Packed 32-bit PAIRS -- two neighbouring cells per 64-bit word, 4 / 6 atomics per event instead of 8 / 12 in the gradient /
+// three-flow modes -- were built in round 2 and measured level with these cells once the LDS pitches were odd: 0.288 against
+// 0.290 ms per gradient evaluation at 50 M events; removed in round 4)
 #ifndef IWE_ABLATE
 #define IWE_ABLATE 99  // ablation builds (timing only): 0 record loads only, 1 + per-event arithmetic without LDS atomics
 #endif
@@ -676,8 +623,6 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     }
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
-    const float sI = q.pair_sI, sE = q.pair_sE, invI = q.pair_invI, invE = q.pair_invE;
-    const int halfw = q.win_w >> 1, halfh = q.win_h >> 1;
     auto lds_acc = [&](acc_t *cell, float v) {
         if constexpr (FIXED == 1) {
             // round-to-nearest double -> int64 with one add: for |x| < 2^51 the low mantissa bits of x + 1.5*2^52 hold
@@ -700,27 +645,6 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
         const int lx = px - wx0, ly = py - wy0;
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
-            if constexpr (FIXED == 2) {
-                unsigned long long *W = reinterpret_cast<unsigned long long *>(wp);
-                const int col = (lx & 1) ? halfw + (lx >> 1) : (lx >> 1);
-                float *gc = gp + (int64_t)py * q.cw + px;  // the event's top-left pixel in the output image
-                add_pair(W + ly * lw + col, mp * ax * ay, mp * dx * ay, sI, invI,
-                         [&] { return PairOverflow{nullptr, gc, nullptr, gc + 1}; });
-                add_pair(W + (ly + 1) * lw + col, mp * ax * dy, mp * dx * dy, sI, invI,
-                         [&] { return PairOverflow{nullptr, gc + q.cw, nullptr, gc + q.cw + 1}; });
-                if constexpr (GRAD) {
-                    // E0 = (a*ay at (x, y), a*dy at (x, y+1)): a vertical pair, plane held column-major;
-                    // E1 = (a*ax at (x, y), a*dx at (x+1, y)): a horizontal pair.  In the image E0(x, y) is -d0[y][x],
-                    // +d0[y][x+1] and E1(x, y) is -d1[y][x], +d1[y+1][x] (the finite differences of the flush).
-                    unsigned long long *V = W + lcells, *H1 = V + lcells;
-                    float *d0 = diwe + (int64_t)py * q.cw + px, *d1 = d0 + plane;
-                    add_pair(V + lx * lh + ((ly & 1) ? halfh + (ly >> 1) : (ly >> 1)), a * ay, a * dy, sE, invE,
-                             [&] { return PairOverflow{d0, d0 + 1, d0 + q.cw, d0 + q.cw + 1}; });
-                    add_pair(H1 + ly * lw + col, a * ax, a * dx, sE, invE,
-                             [&] { return PairOverflow{d1, d1 + q.cw, d1 + 1, d1 + q.cw + 1}; });
-                }
-                return;
-            }
             acc_t *c = wp + ly * lw + lx;
             lds_acc(c, mp * ax * ay);
             lds_acc(c + 1, mp * dx * ay);
@@ -823,28 +747,6 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     __syncthreads();
     float *st = staging + (int64_t)blockIdx.x * PLANES * wcells;
     // cell value / difference of two cells as float (exact integer difference on the fixed-point path)
-    if constexpr (FIXED == 2) {
-        const unsigned long long *W = reinterpret_cast<const unsigned long long *>(win);
-        for (int c = threadIdx.x; c < wcells; c += EVK_BLOCK) {
-            const int lx = c % q.win_w, ly = c / q.win_w;
-            st[c] = (float)((double)pair_cell(W + ly * lw, q.win_w, lx) * (double)invI);
-            if constexpr (GRAD) {
-                const unsigned long long *V = W + lcells, *H1 = V + lcells;
-                const long long e0 = pair_cell(V + lx * lh, q.win_h, ly);
-                const long long e0l = lx > 0 ? pair_cell(V + (lx - 1) * lh, q.win_h, ly) : 0ll;
-                const long long e1 = pair_cell(H1 + ly * lw, q.win_w, lx);
-                const long long e1u = ly > 0 ? pair_cell(H1 + (ly - 1) * lw, q.win_w, lx) : 0ll;
-                st[wcells + c] = (float)((double)(e0l - e0) * (double)invE);      // d0[y][x] = E0[y][x-1] - E0[y][x]
-                st[2 * wcells + c] = (float)((double)(e1u - e1) * (double)invE);  // d1[y][x] = E1[y-1][x] - E1[y][x]
-            }
-            if constexpr (MODE == 2) {
-                st[wcells + c] = (float)((double)pair_cell(W + lcells + ly * lw, q.win_w, lx) * (double)invI);
-                st[2 * wcells + c] = (float)((double)pair_cell(W + 2 * lcells + ly * lw, q.win_w, lx) * (double)invI);
-            }
-        }
-        if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
-        return;
-    }
     auto cell = [&](const acc_t *a) -> float {
         if constexpr (FIXED == 1) return (float)((double)*reinterpret_cast<const long long *>(a) * q.fx_inv);
         else return (float)*a;
@@ -1067,16 +969,14 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     const size_t lds = (size_t)ntiles * sizeof(uint32_t);
     if (stages & EVK_STAGE_HIST)
         k_tile_hist<C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob);
-    static const bool balance = !(getenv("EVK_BUCKET_BALANCE") && atoi(getenv("EVK_BUCKET_BALANCE")) == 0);  // A/B switch
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
         k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles),
-                                              balance ? (uint32_t)bucket_item_budget(ntiles) : 0u, bucket_start,
+                                              (uint32_t)bucket_item_budget(ntiles), bucket_start,
                                               bucket_start + IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles));
     }
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
-    static const int variant = getenv("EVK_SCATTER") ? atoi(getenv("EVK_SCATTER")) : -1;  // tuning: 0 plain, 4/8/16
     // all partition blocks co-resident, one per CU.  With EVK_STAGE_SHARE_CU the rings take at most 96 KB so that a
     // workgroup of ANOTHER kernel (an overlapped RCCL collective) still fits on every CU: a scatter workgroup that
     // owns all 160 KB cannot start on a CU where such a kernel is resident, and one late workgroup costs the call
@@ -1086,8 +986,6 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     int R = 0;
     for (int r : {16, 8, 4})
         if (!R && (size_t)ntiles * (r * 16 + 10) + 8 <= lds_budget) R = r;
-    if (variant == 0) R = 0;
-    if (variant > 0 && (size_t)ntiles * (variant * 16 + 10) + 8 <= lds_budget) R = variant;
     const size_t lds_wc = (size_t)ntiles * (R * 16 + 10) + 8;  // rings + cursor + vstart + flush queue
     if (R == 16) launch_scatter_wc<16>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, lds_wc, s);
     else if (R == 8) launch_scatter_wc<8>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, lds_wc, s);
@@ -1221,20 +1119,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     q.sy_lo = (int)floor(dy_lo) - 1, q.sy_hi = (int)floor(dy_hi) - 1;
     // fixed-point LDS accumulation when the caller can bound every contribution: |p * p_scale| <= p_bound, |t - t_ref| <=
     // dt_bound.  64-bit cells: one scale for the launch from n * p_bound * max(1, dt_bound) >= any cell sum.
-    // Packed 32-bit pairs (EVK_IWE_PACK32; gradient and three-flow modes, see k_iwe_tiled): scale 2^20 / pow2ceil(bound).
     const double acc_bound = (p_bound > 0.0 && dt_bound >= 0.0) ? (double)n * p_bound * fmax(1.0, dt_bound) : 0.0;
-    bool pack32 = false;
-    q.pair_sI = q.pair_sE = q.pair_invI = q.pair_invE = 1.0f;
-    if ((flags & EVK_IWE_PACK32) && (mode != 0 || EVK_PACK_F) && acc_bound > 0.0 && acc_bound < 1e300 && win_w % 2 == 0 && win_h % 2 == 0) {
-        int eI, eE;
-        (void)frexp(p_bound * 1.0000002, &eI);                          // p_bound < 2^eI
-        (void)frexp(fmax(p_bound * dt_bound, 1e-30) * 1.0000002, &eE);
-        if (eI > -80 && eI < 80 && eE > -80 && eE < 80) {
-            pack32 = true;
-            q.pair_sI = (float)ldexp(1.0, EVK_PAIR_SHIFT - eI), q.pair_invI = (float)ldexp(1.0, eI - EVK_PAIR_SHIFT);
-            q.pair_sE = (float)ldexp(1.0, EVK_PAIR_SHIFT - eE), q.pair_invE = (float)ldexp(1.0, eE - EVK_PAIR_SHIFT);
-        }
-    }
     int k = 0;
     if (acc_bound > 0.0 && acc_bound < 1e300) {
         int e;
@@ -1268,8 +1153,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     }
 #define EVK_IWE_LAUNCH_C(M, C)                                                                                     \
     do {                                                                                                           \
-        if (pack32) k_iwe_tiled<M, 2, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
-        else if (fixed) k_iwe_tiled<M, 1, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
+        if (fixed) k_iwe_tiled<M, 1, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe); \
         else k_iwe_tiled<M, 0, C><<<nwin, EVK_BLOCK, lds, s>>>(rec, bucket_index, g, q, st, origins, iwe, diwe);   \
     } while (0)
 #define EVK_IWE_LAUNCH(M)                                                                                          \

@@ -710,7 +710,8 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
                   uint32_t *host_report, uint32_t seq, void *stream) {
     TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
-                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC;
+                      EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC |
+                      EVK_VOXEL2_REC4 | EVK_VOXEL2_REC8 | EVK_VOXEL2_NO_COUNT | EVK_VOXEL2_WG512;
     if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
         n > (int64_t)4000000000LL || (flags & ~known))
         return EVK_EINVAL;
@@ -734,7 +735,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     const V2Config &cfg = v2_config(share, ntiles);
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
-    const int recb = v2_rec_bytes(n);
+    const int recb = v2_rec_bytes(n, flags);
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
 #define X(T, E)                                                                                                              \
     if (cfg.threads == T && cfg.ept == E) {                                                                                  \
@@ -760,7 +761,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         auto two_fit = [](size_t acc_bytes, int wg, int rec) {
             return 2 * (acc_bytes + (size_t)(rec == 4 ? 12 : 8) * (wg / 64) * V2_CHUNK_CAP(wg) + 256) <= (size_t)160 * 1024;
         };
-        const bool may_count = !sp && v2_count_enabled() && n < ((int64_t)1 << 31);   // (int32 counts)
+        const bool may_count = !sp && !(flags & EVK_VOXEL2_NO_COUNT) && n < ((int64_t)1 << 31);   // (int32 counts)
 #ifndef V2_U4
 #define V2_U4 2   // chunk loads per lane in flight, 4-byte records
 #endif
@@ -782,7 +783,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // table entries per lane, 128 registers): 512 (768: 151-158 against 132-142 us at 50 M events).
         // (a call that shares its CUs with a collective's workgroups keeps the 512-thread workgroups: two of them with the
         // counting mode's accumulators leave ~19 KB of every CU's LDS free, two 768-thread ones 3 KB)
-        const bool may_wide = recb == 8 && v2_tiles_wg() != 512 && !share;
+        const bool may_wide = recb == 8 && !(flags & EVK_VOXEL2_WG512) && !share;
         int wg = 512;
         bool count = false;
         if (may_wide && may_count && two_fit(lds_count, 768, recb)) wg = 768, count = true;

@@ -12,6 +12,21 @@ def default_impl():
     return os.environ.get("EVK_IMPL", "auto")
 
 
+# Hooks for tests and measurements (NOT configuration: the defaults are what the library measured best).  Several kernel shapes
+# are chosen by size -- 4-byte voxel records above 16 M events, compact IWE records beyond the Infinity Cache, 768- or
+# 512-thread tile workgroups, the unit-polarity counting mode -- and the tests must be able to run each of them at small sizes:
+#   rec          None | 4 | 8       record size of the one-pass voxel path (EVK_VOXEL2_REC4 / _REC8)
+#   count        True | False       unit-polarity counting mode of its tile kernel (EVK_VOXEL2_NO_COUNT)
+#   tiles_wg     0 | 512            512-thread tile workgroups everywhere (EVK_VOXEL2_WG512)
+#   xcd_order    True | False       XCD-aware work-item order of the tile kernels (EVK_VOXEL2_NO_XCD_ORDER)
+#   share_cu     None | True | False   leave LDS for a collective's workgroups (None: yes in a multi-rank job)
+#   iwe_records  "auto" | "compact" | "full"   8-byte compact records of the bucketed IWE path
+#   iwe_fixed    True | False       64-bit fixed-point LDS windows of the IWE kernels (False: float64)
+#   image_fixed  True | False       fixed-point windows of the bilinear image tile kernel for unit weights
+FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu": None, "iwe_records": "auto",
+         "iwe_fixed": True, "image_fixed": True}
+
+
 # 'auto' thresholds, measured (profiles/r01_direct_tiled_crossover.txt): the single-shot voxel call pays ~40 us of fixed
 # bucketing cost, the direct kernel 2 global atomics per event at ~21 G/s -> crossover ~350 k events; the IWE path
 # re-uses its buckets over many evaluations and has 4-12 atomics per event -> crossover ~150 k events
@@ -72,13 +87,13 @@ class Buckets:
         """Rewrite the records as 8-byte compact records when that is exact (integer pixel coordinates inside the
         domain, polarities without low mantissa bits: sensor events) and drop the 16-byte ones: every later evaluation
         streams half the bytes.  One extra pass over the records and ONE host synchronisation (the verdict), paid once
-        per bucketing, i.e. once per optimisation.  EVK_IWE_RECORDS: "auto" (default) compacts when the 16-byte records
+        per bucketing, i.e. once per optimisation.  FORCE["iwe_records"]: "auto" (default) compacts when the 16-byte records
         do not fit the 256 MB Infinity Cache (> 16 M events) -- measured on MI355X (tools/iwe_kernel_time.py): 50 M
         events / 720p, function evaluation kernel 0.225 -> 0.211 ms; 10 M events / VGA (cache-resident, bound by
         arithmetic and LDS atomics, where the decode costs instructions) 0.039 -> 0.041 ms; "compact" always tries,
         "full" never does."""
         import torch
-        mode = os.environ.get("EVK_IWE_RECORDS", "auto")
+        mode = FORCE["iwe_records"]
         if self.iwe_flag or self.key_mode != 1 or self.n == 0 or (1 << (self.tw_log2 + self.th_log2)) > 1024 \
                 or mode == "full" or (mode != "compact" and self.n * 16 <= (256 << 20)):
             return self
@@ -106,10 +121,9 @@ def can_tile(cols, impl, min_events=None):
 
 def share_cu():
     """Whether the partition kernel should leave LDS for another kernel's workgroups (EVK_STAGE_SHARE_CU): yes when a
-    collective may overlap it, i.e. in a torch.distributed job of more than one rank; EVK_SHARE_CU=0/1 overrides."""
-    env = os.environ.get("EVK_SHARE_CU")
-    if env in ("0", "1"):
-        return env == "1"
+    collective may overlap it, i.e. in a torch.distributed job of more than one rank; FORCE["share_cu"] overrides."""
+    if FORCE["share_cu"] is not None:
+        return bool(FORCE["share_cu"])
     import torch.distributed as dist
     return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
@@ -141,39 +155,6 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
     return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n)
 
 
-def voxel_tile_shape(H, W, B):
-    """Tile (log2 w, log2 h) for the voxel kernel: the largest tile with >= 500 tiles (~2 workgroups per CU keep the
-    tile kernel balanced; fewer, larger tiles make the partition kernel's write-combining rings deeper and faster:
-    profiles/r01_scatter_variants_tile_sweep.txt) and B * tile * 8 B of LDS accumulators <= 40 KB (4 workgroups per
-    CU; 720p / 5 bins then takes 32x32 tiles: 0.80 ms instead of 0.97 ms for 50 M events,
-    profiles/r01_voxel_tile_shape_sweep.txt)."""
-    env = os.environ.get("EVK_VOXEL_TILE")
-    if env:
-        a, b = env.split("x")
-        return int(a), int(b)
-    for tw, th in ((5, 5), (5, 4), (4, 4), (4, 3), (3, 3)):
-        ntiles = -(-W // (1 << tw)) * -(-H // (1 << th))
-        if ntiles >= 500 and B * 8 << (tw + th) <= 40960:
-            return tw, th
-    return 3, 3
-
-
-def voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh, split_polarity=False):
-    """evk_voxel_tiled_f32 on bucketed events `bk` (staging for the parts of split hot tiles is persistent scratch).
-    split_polarity: `out` is (2, B, H, W) -- the grids of the positive and of the non-positive events, weight 1 each."""
-    planes = 2 * B if split_polarity else B
-    nbytes = int(_lib.lib().evk_voxel_tiled_staging_bytes(bk.ntiles, bk.n, planes, bk.tw_log2, bk.th_log2))
-    staging = _buf("voxel_staging", nbytes, out.device)
-    _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, H, W, bk.tw_log2, bk.th_log2,
-              t_first, t_last, B, (1 if fresh else 0) | (2 if split_polarity else 0), D.ptr(out), D.ptr(staging), nbytes,
-              D.stream())
-
-
-def voxel_path():
-    """'v2' = one-pass partition (evk_voxel2.hip, default); 'v1' = three-pass counting sort (evk_tiled.hip)."""
-    return os.environ.get("EVK_VOXEL_PATH", "v2")
-
-
 def voxel_deterministic():
     """EVK_VOXEL_DETERMINISTIC=1: the tile kernel of the one-pass path accumulates 64-bit fixed point (order-free integer
     adds) instead of float64 -- bit-identical grids from run to run.  One synchronisation per call (range check)."""
@@ -193,16 +174,15 @@ def voxel2_shape(H, W, planes):
     accumulator cell index (row * (width | 1) + column) has 10 bits; B planes of float64 cells plus the chunk lists must
     fit the LDS; at most evk_voxel2_max_tiles() tiles.  Small penalties prefer fewer tiles (longer record segments),
     all tiles resident at once (<= 3 workgroups per CU) and wide tiles (rows are contiguous in the grid)."""
-    key = (H, W, planes, voxel_path(), os.environ.get("EVK_VOXEL2_TILE"))
+    key = (H, W, planes, FORCE.get("tile"))
     if key in _shape_cache:
         return _shape_cache[key]
     L = _lib.lib()
     max_tiles = L.evk_voxel2_max_tiles()
-    env = os.environ.get("EVK_VOXEL2_TILE")
     best = None
-    if env:
-        a, b = (int(v) for v in env.split("x"))
-        if 0 < L.evk_voxel2_num_tiles(H, W, a, b) <= max_tiles:
+    if FORCE.get("tile"):            # (tests: an explicit tile size)
+        a, b = FORCE["tile"]
+        if 0 < L.evk_voxel2_num_tiles(H, W, a, b) <= max_tiles and planes * 8 * (a | 1) * b + _TILE_LIST_BYTES <= 150 * 1024:
             best = (0.0, a, b)
     else:
         for tw in range(8, 129):
@@ -211,8 +191,8 @@ def voxel2_shape(H, W, planes):
                 lds = planes * 8 * cells + _TILE_LIST_BYTES
                 if cells > 1024 or lds > 150 * 1024:
                     break
-                T = -(-W // tw) * -(-H // th)
-                if T > max_tiles:
+                T = L.evk_voxel2_num_tiles(H, W, tw, th)      # 0: the library cannot take this tiling
+                if T <= 0 or T > max_tiles:
                     continue
                 resident = min(3, (160 * 1024) // lds)
                 per_cu = -(-T // _NUM_CU)
@@ -245,8 +225,13 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     flags = (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | (_lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0) | stage
     if share_cu():
         flags |= 128         # EVK_VOXEL2_SHARE_CU
-    if os.environ.get("EVK_V2_XCD_ORDER", "1") == "0":
-        flags |= 64          # EVK_VOXEL2_NO_XCD_ORDER (A/B measurement)
+    if not FORCE["xcd_order"]:
+        flags |= 64          # EVK_VOXEL2_NO_XCD_ORDER
+    flags |= {None: 0, 4: _lib.EVK_VOXEL2_REC4, 8: _lib.EVK_VOXEL2_REC8}[FORCE["rec"]]
+    if not FORCE["count"]:
+        flags |= _lib.EVK_VOXEL2_NO_COUNT
+    if FORCE["tiles_wg"] == 512:
+        flags |= _lib.EVK_VOXEL2_WG512
     det = voxel_deterministic()
     if det:
         flags |= _lib.EVK_VOXEL_DETERMINISTIC
@@ -260,7 +245,7 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
         _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail)
     else:
         _lib.call("evk_%s_native_f32" % ver, *native.head(), *tail)
-    if det and not (stage & _lib.EVK_VOXEL2_PARTITION_ONLY) and os.environ.get("EVK_VOXEL_DET_NOCHECK") != "1":   # (timing runs)
+    if det and not (stage & _lib.EVK_VOXEL2_PARTITION_ONLY):
         bad = int(index[4].item())          # synchronises: the deterministic mode is a debugging / verification mode
         if bad:
             index[4] = 0
@@ -296,8 +281,10 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     index = _zbuf("image2_index", sizes[0], dev)          # (its own: the header words [0], [1] mean something else here)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
     flags = stage | (_lib.EVK_VOXEL_OVERWRITE if (fresh and kind != "bilinear") else 0)
-    if os.environ.get("EVK_IMAGE2_FIXED", "1") == "0":
+    if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
+    if not FORCE["xcd_order"]:
+        flags |= 64
     report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
     tail = (tw, th, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None,
             report, seq, D.stream())
@@ -322,22 +309,17 @@ def can_tile_image(cols, impl):
 
 def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
     """events_to_neg_pos_voxel_torch core: (2, B, H, W) float32 = [positive events, non-positive events] from ONE
-    bucketing pass and ONE tile-kernel pass, or None when the tiled path does not apply (the caller then voxelises the
+    partition and ONE tile-kernel pass, or None when the one-pass path does not apply (the caller then voxelises the
     two weight columns one after the other, as upstream)."""
     import torch
     impl = impl or default_impl()
-    if not (can_tile((xd, yd, td, pd), impl) and 2 * B * 8 * 64 <= 65536):
+    if not can_tile((xd, yd, td, pd), impl):
+        return None
+    shape2 = voxel2_shape(H, W, 2 * B)
+    if shape2 is None:
         return None
     out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
-    shape2 = voxel2_shape(H, W, 2 * B) if voxel_path() == "v2" else None
-    if shape2 is not None:
-        voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
-        return out
-    tw, th = voxel_tile_shape(H, W, 2 * B)
-    if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:
-        return None
-    bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob)
-    voxel_tiled(bk, t_first, t_last, B, H, W, out, True, split_polarity=True)
+    voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
     return out
 
 
@@ -351,30 +333,19 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
     else:
         tileable = can_tile((xd, yd, td, pd), impl)
-    if tileable and voxel_path() == "v2":
+    if tileable:
         shape2 = voxel2_shape(H, W, B)
         if shape2 is not None:
             voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
                    out, oob, fresh)
             return out
-    if t_first is None:          # the other kernels take ts[0] / ts[-1] as host scalars
+    if t_first is None:          # the direct kernel takes ts[0] / ts[-1] as host scalars
         if native is None:
             t_first, t_last = D.ends(td)
         else:                    # the loaders' (ts - ts_0).float(): subtraction in float64, then float32
             import numpy as np
             a, b = D.ends(native.t)
             t_first, t_last = float(np.float32(a - native.t_offset)), float(np.float32(b - native.t_offset))
-    if tileable and B * 8 * 64 <= 65536:
-        tw, th = voxel_tile_shape(H, W, B)
-        if _lib.lib().evk_bucket_num_tiles(H, W, tw, th) <= 0:     # sensors beyond 8192 tiles: enlarge the tiles
-            tw, th = next(((a, b) for a, b in ((5, 5), (6, 5), (6, 6))
-                           if _lib.lib().evk_bucket_num_tiles(H, W, a, b) > 0 and B * 8 << (a + b) <= 65536), (0, 0))
-    else:
-        tw = 0
-    if tw:
-        bk = bucket_events(xd, yd, td, pd, 0, H, W, tw, th, oob, native=native)
-        voxel_tiled(bk, t_first, t_last, B, H, W, out, fresh)
-        return out
     if native is not None:
         xd, yd, td, pd = native.widen()
     if fresh:
@@ -386,10 +357,6 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
 
 def iwe_tile_shape(dom_h, dom_w):
     """Tile (log2 w, log2 h) for the IWE kernel: the largest tile that still gives >= ~4 workgroups per CU."""
-    env = os.environ.get("EVK_IWE_TILE")
-    if env:
-        a, b = env.split("x")
-        return int(a), int(b)
     for tw, th in ((5, 5), (5, 4), (4, 4)):
         if -(-dom_w // (1 << tw)) * -(-dom_h // (1 << th)) >= 1000:
             return tw, th
@@ -441,7 +408,7 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
     if S > 64 or cand > 128:
         return None
-    key = (1, dom_h, dom_w, tw, th, os.environ.get("EVK_IWE_RECORDS", "auto"))
+    key = (1, dom_h, dom_w, tw, th, FORCE["iwe_records"])
     bk = ev._buckets.get(key)
     if bk is None:
         if native is not None:
@@ -464,19 +431,11 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
         keep = (np.ascontiguousarray(vxs, dtype=np.float64), np.ascontiguousarray(vys, dtype=np.float64))
         flow = (D.host_ptr(keep[0]), D.host_ptr(keep[1]))
     # bound of any accumulator cell: every event in one pixel, weight |p| * p_scale (* |dt| for the derivative planes);
-    # lets the kernel accumulate in 64-bit fixed point (EVK_IWE_FIXED=0 keeps float64 accumulation)
-    # EVK_IWE_FIXED: "0" float64 accumulation, "64" 64-bit fixed-point cells, "32" packed 32-bit pairs for the gradient /
-    # three-flow modes (include/evk.h), "auto" (default) = 64-bit cells
-    p_bound, dt_bound, fixed = 0.0, 0.0, os.environ.get("EVK_IWE_FIXED", "auto")
-    if fixed != "0":
+    # lets the kernel accumulate in 64-bit fixed point (FORCE["iwe_fixed"] = False keeps float64 accumulation)
+    p_bound, dt_bound = 0.0, 0.0
+    if FORCE["iwe_fixed"]:
         p_bound = ev.p_absmax() * abs(float(ev.p_scale))
         dt_bound = max(span, abs(ev.t_at(-1) - t_ref))
-        # "auto" = 64-bit cells.  (Round 2 first chose packed pairs for the analytic gradient of structured scenes -- they
-        # halve the atomics, and with EVEN LDS pitches the same-column events of an edge scene fought over 4 bank pairs:
-        # 0.393 -> 0.300 ms at 50 M events / 720p.  With odd pitches the 64-bit cells run as fast (0.288 vs 0.290 ms;
-        # 0.109 vs 0.109 ms at 10 M / VGA) and keep 2^-27 resolution and bit-reproducible sums, so nothing is chosen.)
-        if fixed == "32":
-            flags = flags | _lib.EVK_IWE_PACK32
     head = (D.ptr(bk.records), D.ptr(bk.bucket_start), bk.n, dom_h, dom_w, tw, th, S, win_w, win_h, t_first, t_ref) + \
         flow + (bounds_w, bounds_h, ch, cw, flags | bk.iwe_flag, float(ev.p_scale), p_bound, dt_bound)
     return {"head": head, "staging": staging, "staging_bytes": nbytes, "buckets": bk, "keep": keep}
@@ -525,11 +484,6 @@ def _spill_call(st, call):
         st[1] ^= 1
 
 
-def spill_enabled():
-    """EVK_CMAX_SPILL=0 restores the memset of the IWE buffer ahead of every evaluation (round 1)."""
-    return os.environ.get("EVK_CMAX_SPILL", "1") != "0"
-
-
 def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights, radius, post_flags, buf, out, scratch,
                   scratch_bytes, impl=None, host_out=None):
     """One-call objective evaluation (evk_cmax_variance_tiled_f32) into `out` (4 doubles); returns False when the
@@ -539,8 +493,8 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
     events hundreds of times and only vx, vy and the spill parity change, which takes ~10 us of Python off every
     evaluation (84 -> 74 us at 10 M events)."""
     import math
-    ckey = (t_ref, bounds_w, bounds_h, ch, cw, flags, radius, post_flags, impl or default_impl(), spill_enabled(),
-            os.environ.get("EVK_IWE_FIXED", "auto"), os.environ.get("EVK_IWE_RECORDS", "auto"), ev.p_scale)
+    ckey = (t_ref, bounds_w, bounds_h, ch, cw, flags, radius, post_flags, impl or default_impl(), FORCE["iwe_fixed"],
+            FORCE["iwe_records"], ev.p_scale)
     cache = ev.__dict__.setdefault("_cmax_calls", {})
     c = cache.get(ckey)
     if c is not None and c["buf"] is buf and c["out"] is out and c["scratch"] is scratch and c["weights"] is weights \
@@ -560,7 +514,7 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
     if plan is None:
         return False
     planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
-    sp_state = _spill_pair(buf.device, planes, ch, cw) if spill_enabled() else None
+    sp_state = _spill_pair(buf.device, planes, ch, cw)
     spill, parity = (sp_state[0], sp_state[1] ^ 1) if sp_state is not None else (None, 0)
     args = list(plan["head"]) + [D.host_ptr(weights) if weights is not None else None, radius, post_flags,
                                  D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out), D.ptr(scratch),
@@ -584,7 +538,7 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
         return False
-    st = _spill_pair(buf.device, 3, ch, cw) if spill_enabled() else None
+    st = _spill_pair(buf.device, 3, ch, cw)
     spill, parity = (st[0], st[1] ^ 1) if st is not None else (None, 0)
     _spill_call(st, lambda: _lib.call(
         "evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,

@@ -311,9 +311,10 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  * (tile, sub-chunk) table, and a tile kernel that pulls every tile's segments and accumulates in LDS (float64) --
  * the events are read once and written once (24 B/event + the grid instead of 56).  Same per-event arithmetic and
  * results as evk_voxel_f32 / evk_voxel_tiled_f32 -- with one exception: a call all of whose polarities are +1, -1 or +0
- * (and whose accumulators fit, see DESIGN.md K2') is accumulated as an integer count and one float64 sum per bin,
+ * (and whose accumulators fit, see DESIGN.md K2') is accumulated as an integer count and one int64 fixed-point sum per bin,
  * grid[b] = S0[b] - G[b] + G[b-1], i.e. without rounding p (1 - f) to float32 per event (differences < 6e-8 per event,
- * the parity bar is 1e-5 of the grid's maximum); EVK_V2_COUNT=0 in the environment keeps the two float64 atomics.
+ * the parity bar is 1e-5 of the grid's maximum), and such a grid does not depend on the order of the events;
+ * EVK_VOXEL2_NO_COUNT keeps the two float64 atomics.
  *   index    evk_voxel2_index_len(ntiles, n) uint32, ZEROED ONCE by the caller when it is allocated; the library
  *            leaves its counters at zero after every call (persistent across calls on one stream)
  *   scratch  evk_voxel2_scratch_bytes(...) bytes, 16-byte aligned, uninitialised
@@ -340,6 +341,13 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 #define EVK_VOXEL2_SHARE_CU 128    /* partition with 64 KB of LDS per CU instead of 128 KB, so that workgroups of another,
                                       concurrently running kernel (an overlapped RCCL collective) still fit on every CU */
 #define EVK_VOXEL2_NO_XCD_ORDER 64 /* A/B switch: tile kernel work items in plain order instead of one contiguous range per XCD */
+/* The library picks the record size (4 bytes above 16 M events, else 8), the unit-polarity counting mode and the tile
+ * workgroup size (768 threads where two such workgroups fit a CU) by itself; these flags force the other choice so that tests
+ * and measurements can run every shipped kernel shape at any size (results are the same within the parity bar). */
+#define EVK_VOXEL2_REC4 1024
+#define EVK_VOXEL2_REC8 2048
+#define EVK_VOXEL2_NO_COUNT 4096
+#define EVK_VOXEL2_WG512 8192
 int evk_voxel2_max_tiles(void);
 int64_t evk_voxel2_index_len(int ntiles, int64_t n);
 int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h);   /* 0 = this tiling is not supported */
@@ -396,12 +404,7 @@ int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int6
  * bounds the LDS windows accumulate in FIXED POINT -- this kernel is LDS-atomic bound, ds_add_u64 is 1.5x faster than
  * ds_add_f64 on gfx950, and integer sums are order-independent (bit-reproducible):
  *   - 64-bit cells, value * 2^k with k = min(40, 61 - ceil(log2(n * p_bound * max(1, dt_bound)))), used when k >= 26;
- *   - with EVK_IWE_PACK32 (gradient and three-flow modes), two 32-bit accumulators per 64-bit word so that a PAIR of
- *     neighbouring cells takes one atomic (4 / 6 atomics per event instead of 8 / 12): contributions scaled to < 2^20
- *     (quantisation 2^-21 of the bound); a field that passes 2^30 (a pixel hotter than ~1000 full-weight events within one
- *     workgroup) is drained into the image with global atomics, so nothing overflows.
  * Quantisation <= 2^-(k+1) per contribution for the 64-bit cells.  Without bounds: float64 accumulation. */
-#define EVK_IWE_PACK32 8u
 /* COMPACT RECORDS.  The evaluation kernels stream the bucketed records once per evaluation, and an optimisation evaluates
  * ~10^2 times, so the record stream is what the function evaluation is bound by.  Sensor events have integer pixel
  * coordinates and +-1 polarities: evk_compact_records_f32 rewrites the (x, y, t, p) float32 records of a bucketing

@@ -92,14 +92,14 @@ def test_f2_voxel_numpy(E, golden, tag, Bs):
         close(v, g["%s_voxel_B%d" % (tag, B)], 1e-12)
 
 
-@pytest.mark.parametrize("impl", ["auto", "direct", "tiled-v2", "tiled-v2-rec4", "tiled-v1"])
+@pytest.mark.parametrize("impl", ["auto", "direct", "tiled", "tiled-rec4"])
 @pytest.mark.parametrize("tag,Bs", [("small", (1, 2, 5, 9)), ("dvs", (5,))])
 def test_f3_voxel_torch(E, golden, tag, Bs, impl, monkeypatch):
     # every kernel family against the reference's own outputs: global atomics, one-pass partition (8-byte records, and the
-    # 4-byte records a call takes above 16 M events), three-pass sort
+    # 4-byte records a call takes above 16 M events)
+    from event_utils_amd import tiled
     monkeypatch.setenv("EVK_IMPL", impl.split("-")[0])
-    monkeypatch.setenv("EVK_VOXEL_PATH", impl.split("-")[1] if "-" in impl else "v2")
-    monkeypatch.setenv("EVK_V2_REC", "4" if impl.endswith("rec4") else "8")
+    monkeypatch.setitem(tiled.FORCE, "rec", 4 if impl.endswith("rec4") else 8)
     g = golden("f3_voxel_torch")
     xs, ys, ts = (torch.from_numpy(g[tag + k]) for k in ("_xs", "_ys", "_ts"))
     ps = torch.from_numpy(g[tag + "_ps"].astype(np.float32))

@@ -127,11 +127,12 @@ def test_full_size_iwe_properties(cfg, monkeypatch):
 
 def test_full_size_compact_records_and_balanced_plan(monkeypatch):
     """50 M sensor events (integer pixels) at 1280x720: beyond the Infinity Cache the bucketing compacts its records by
-    itself (EVK_IWE_RECORDS=auto) and, on the moving-edge scene, balances the plan.  Mass conservation, and IWE / dIWE
+    itself (tiled.FORCE["iwe_records"] = "auto") and, on the moving-edge scene, balances the plan.  Mass conservation, and IWE / dIWE
     equal to those from the 16-byte records (same plan, same sums: bit-identical up to the float atomics of the few events
     that leave their windows)."""
     import bench
     import event_utils_amd as E
+    from event_utils_amd import tiled
     from event_utils_amd.contrast_max.objectives import iwe_device
     n, H, W = 50_000_000, 720, 1280
     x, y, t, p = bench.structured_scene(3, n, H, W)
@@ -140,7 +141,7 @@ def test_full_size_compact_records_and_balanced_plan(monkeypatch):
     monkeypatch.setenv("EVK_IMPL", "tiled")
     out = {}
     for mode in ("auto", "full"):
-        monkeypatch.setenv("EVK_IWE_RECORDS", mode)
+        monkeypatch.setitem(tiled.FORCE, "iwe_records", mode)
         ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
         iwe, diwe = iwe_device(prm, ev, (H, W), True, True, (H, W))
         bk = list(ev._buckets.values())

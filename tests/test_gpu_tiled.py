@@ -32,6 +32,11 @@ def E(monkeypatch):
     return E
 
 
+def _tiled():
+    from event_utils_amd import tiled
+    return tiled
+
+
 def _events(seed, n, H, W, real=False, t_hi=0.1):
     rng = np.random.default_rng(seed)
     if real:
@@ -75,20 +80,23 @@ def test_voxel_tiled_vs_oracle(E, n, shape):
     close(v.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("knobs", [{"EVK_SHARE_CU": "1"}, {"EVK_V2_XCD_ORDER": "0"}, {"EVK_VOXEL_PATH": "v1"},
-                                   {"EVK_VOXEL_PATH": "v1", "EVK_SHARE_CU": "1"}, {"EVK_VOXEL2_TILE": "32x16"},
-                                   {"EVK_VOXEL2_TILE": "31x33"}, {"EVK_VOXEL_DETERMINISTIC": "1"}, {"EVK_V2_REC": "4"},
-                                   {"EVK_V2_REC": "4", "EVK_VOXEL_DETERMINISTIC": "1", "EVK_SHARE_CU": "1"}, {"EVK_V2_REC": "8"},
-                                   {"EVK_V2_COUNT": "0"}, {"EVK_V2_COUNT": "0", "EVK_V2_REC": "4"}, {"EVK_V2_TILES_WG": "512"},
-                                   {"EVK_V2_TILES_WG": "512", "EVK_V2_COUNT": "0"}])
+@pytest.mark.parametrize("knobs", [{"share_cu": True}, {"xcd_order": False}, {"tile": (32, 16)}, {"tile": (31, 33)},
+                                   {"EVK_VOXEL_DETERMINISTIC": "1"}, {"rec": 4},
+                                   {"rec": 4, "EVK_VOXEL_DETERMINISTIC": "1", "share_cu": True}, {"rec": 8},
+                                   {"count": False}, {"count": False, "rec": 4}, {"tiles_wg": 512},
+                                   {"tiles_wg": 512, "count": False}])
 def test_voxel_path_variants_agree_with_the_oracle(E, monkeypatch, knobs):
-    """The voxel fast path under its run-time switches: the partition geometry a multi-rank job gets (8 K-event
-    sub-chunks, room for a collective's workgroups), plain work-item order, the round-1 three-pass path, power-of-two and
-    odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation, 4-byte compact records (the
-    default above 16 M events) and 8-byte records, with and without the unit-polarity counting mode, 512- and 768-thread tile
-    workgroups.  (The library reads these switches on every call.)"""
+    """Every kernel shape of the voxel fast path at a small size (tiled.FORCE: the library picks them by size): the partition
+    geometry a multi-rank job gets (8 K-event sub-chunks, room for a collective's workgroups), plain work-item order,
+    power-of-two and odd tile shapes instead of the balanced choice, fixed-point (order-free) accumulation, 4-byte compact
+    records (the default above 16 M events) and 8-byte records, with and without the unit-polarity counting mode, 512- and
+    768-thread tile workgroups."""
+    from event_utils_amd import tiled
     for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+        if k.startswith("EVK_"):
+            monkeypatch.setenv(k, v)
+        else:
+            monkeypatch.setitem(tiled.FORCE, k, v)
     for (n, H, W, B, seed) in ((700_001, 480, 640, 5, 3), (90_000, 100, 130, 3, 4)):
         x, y, t, p = _events(seed, n, H, W)
         x[: n // 3] = 7; y[: n // 3] = 9                          # a hot pixel: split tiles
@@ -187,9 +195,9 @@ def test_compact_records_are_exact_for_any_input(E, monkeypatch, kind):
         p[6::1013] = np.inf
     ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
     cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
-    monkeypatch.setenv("EVK_V2_REC", "4")
+    monkeypatch.setitem(_tiled().FORCE, "rec", 4)
     v4 = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
-    monkeypatch.setenv("EVK_V2_REC", "8")
+    monkeypatch.setitem(_tiled().FORCE, "rec", 8)
     v8 = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
     with np.errstate(invalid="ignore"):
         for v in (v4, v8):
@@ -219,7 +227,7 @@ def test_compact_records_with_three_entries_per_lane_on_structured_scenes(E, sce
         y[hot] = (H // 3 + rng.integers(0, 100, hot.sum())).astype(np.float32)
     ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
     cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
-    monkeypatch.setenv("EVK_V2_REC", "4")
+    monkeypatch.setitem(_tiled().FORCE, "rec", 4)
     for _ in range(2):
         close(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy(), ref)
     monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
@@ -229,8 +237,8 @@ def test_compact_records_with_three_entries_per_lane_on_structured_scenes(E, sce
     close(a.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("count", ["1", "0"])
-@pytest.mark.parametrize("rec", ["8", "4"])
+@pytest.mark.parametrize("count", [True, False])
+@pytest.mark.parametrize("rec", [8, 4])
 def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monkeypatch, count, rec):
     """The tile kernel's counting mode (unit polarities: an integer count per bin + ONE float64 sum, grid[b] = S0[b] - G[b] +
     G[b - 1]) against the oracle, with everything that leaves its straight-line path: a time range narrower than the stream
@@ -238,8 +246,8 @@ def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monke
     the range's ends and on bin boundaries, zero polarities, a hot pixel (cut tiles); accumulate and overwrite mode.  Then a
     polarity of 0.5 anywhere in the stream must switch the call to the float64 path (same oracle, same bar)."""
     from event_utils_amd.representations.voxel_grid import _voxel_f32_device
-    monkeypatch.setenv("EVK_V2_COUNT", count)
-    monkeypatch.setenv("EVK_V2_REC", rec)
+    monkeypatch.setitem(_tiled().FORCE, "count", count)
+    monkeypatch.setitem(_tiled().FORCE, "rec", rec)
     n, H, W, B = 900_000, 480, 640, 5
     x, y, t, p = _events(12, n, H, W)
     p[::11] = 0.0
@@ -256,7 +264,7 @@ def test_unit_polarity_counting_mode_with_events_outside_the_time_range(E, monke
         base = torch.full((B, H, W), 1.5, device="cuda")
         _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), out=base, impl="tiled", check=False)
         close(base.cpu().numpy() - 1.5, ref, 1e-4)
-        if count == "1" and pp is p:      # integer sums: the same bits on every run
+        if count and pp is p:      # integer sums: the same bits on every run
             a = _voxel_f32_device(*cols, B, (H, W), float(t_lo), float(t_hi), impl="tiled", check=False)
             assert torch.equal(a, v)
     # dt == 0 (Q9): every t_norm is NaN (0 / 0) -- the reference's NaN weights reach every bin of every pixel that holds an event
@@ -451,8 +459,7 @@ def test_voxel_hot_tiles_are_split_and_combined(E, shape):
     x[hot] = (W // 2 + rng.integers(0, 3, hot.sum())).astype(np.float32)
     y[hot] = (H // 3 + rng.integers(0, 2, hot.sum())).astype(np.float32)
     cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
-    tw, th = tiled.voxel_tile_shape(H, W, B)
-    bk = tiled.bucket_events(*cols, 0, H, W, tw, th)
+    bk = tiled.bucket_events(*cols, 0, H, W, 4, 4)       # (the three-pass bucketing's own plan: 16x16 tiles)
     idx = bk.bucket_start.cpu().numpy()
     part_start = idx[bk.ntiles + 1: 2 * bk.ntiles + 2]
     assert part_start[-1] > bk.ntiles, "the hot tile should have been split"
@@ -480,12 +487,11 @@ def test_iwe_hot_tiles(E):
         close(iwe, ri); close(diwe, rd)
 
 
-@pytest.mark.parametrize("fixed", ["32", "64", "0", "auto"])
-def test_iwe_accumulator_modes_and_hot_pixel_drain(E, monkeypatch, fixed):
-    """The three LDS accumulator modes of the tiled IWE kernel (packed 32-bit pairs, 64-bit fixed point, float64) against
-    the oracle -- on uniform events and on a scene whose events all carry the same sign and pile up on a few pixels, so
-    that the packed fields pass 2^30 again and again and are drained into the image (k_iwe_tiled, add_pair)."""
-    monkeypatch.setenv("EVK_IWE_FIXED", fixed)
+@pytest.mark.parametrize("fixed", [True, False])
+def test_iwe_accumulator_modes_on_hot_pixels(E, monkeypatch, fixed):
+    """The two LDS accumulator modes of the tiled IWE kernel (64-bit fixed point, float64) against the oracle -- on uniform
+    events and on a scene whose events all carry the same sign and pile up on a few pixels (sums of ~1e5 per pixel)."""
+    monkeypatch.setitem(_tiled().FORCE, "iwe_fixed", fixed)
     H, W, n = 180, 240, 400_000
     x, y, t, p = _events(77, n, H, W, real=True)
     rng = np.random.default_rng(8)
@@ -648,7 +654,7 @@ def test_compact_records_are_bit_identical(E, sensor, hot, monkeypatch):
     p = rng.choice(np.array([-1.0, 1.0, 0.5, 0.0, -3.0], dtype=np.float32), n)
     out = {}
     for mode in ("full", "compact"):
-        monkeypatch.setenv("EVK_IWE_RECORDS", mode)
+        monkeypatch.setitem(_tiled().FORCE, "iwe_records", mode)
         ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
         obj = E.variance_objective(); obj.sensor_size = (H, W); obj.impl = "tiled"
         prm = np.array([55.0, -35.0])
@@ -675,7 +681,7 @@ def test_compact_records_are_bit_identical(E, sensor, hot, monkeypatch):
 def test_events_that_do_not_compact_keep_their_records(E, spoil, monkeypatch):
     """One event with a sub-pixel coordinate, a coordinate outside the domain or a polarity with low mantissa bits: the
     bucketing keeps the 16-byte records (the verdict of evk_compact_records_f32), results as before."""
-    monkeypatch.setenv("EVK_IWE_RECORDS", "compact")
+    monkeypatch.setitem(_tiled().FORCE, "iwe_records", "compact")
     H, W, n = 180, 240, 300_000
     rng = np.random.default_rng(33)
     x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
@@ -702,8 +708,6 @@ def test_structured_scenes_are_flagged_and_balanced(E, monkeypatch):
     import os
     import bench
     from event_utils_amd import tiled
-    if os.environ.get("EVK_BUCKET_BALANCE") == "0":
-        pytest.skip("the A/B switch of the balanced plan is off")
     H, W, n = 480, 640, 3_000_000
     for scene in ("edges", "uniform"):
         if scene == "edges":
@@ -722,3 +726,22 @@ def test_structured_scenes_are_flagged_and_balanced(E, monkeypatch):
             assert (counts / parts).max() <= 1.05 * max(counts.mean(), 4096)
         else:
             assert not bk.structured and parts.max() == 1
+
+
+def test_voxel_on_bucketed_records_entry_point(E):
+    """evk_voxel_tiled_f32 (include/evk.h): the voxel grid from tile-bucketed 16-byte records (evk_bucket_events_f32) -- the C
+    entry point for callers that bucket a stream once and voxelise it repeatedly.  The Python dispatch takes the one-pass
+    path (evk_voxel2_f32); this entry is checked here through ctypes, uniform and hot-pixel scene."""
+    from event_utils_amd import tiled, _lib, _device as D
+    L = _lib.lib()
+    for (n, H, W, B, tw, th) in ((600_001, 480, 640, 5, 5, 4), (90_000, 100, 130, 3, 4, 4)):
+        x, y, t, p = _events(51, n, H, W)
+        x[: n // 3] = 7; y[: n // 3] = 9
+        cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+        bk = tiled.bucket_events(*cols, 0, H, W, tw, th)
+        nbytes = int(L.evk_voxel_tiled_staging_bytes(bk.ntiles, n, B, tw, th))
+        staging = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
+        out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+        _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), n, H, W, tw, th, float(t[0]), float(t[-1]), B,
+                  _lib.EVK_VOXEL_OVERWRITE, D.ptr(out), D.ptr(staging), nbytes, D.stream())
+        close(out.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))

@@ -10,13 +10,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import event_utils_amd as E  # noqa: E402
+from event_utils_amd import tiled  # noqa: E402
 from event_utils_amd.events import DeviceEvents  # noqa: E402
 
 
 def evals(x, y, t, p, size, reps):
     res = {}
     for mode in ("full", "compact"):
-        os.environ["EVK_IWE_RECORDS"] = mode
+        tiled.FORCE["iwe_records"] = mode
         ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
         obj, w = E.variance_objective(), E.linvel_warp()
         obj.sensor_size = size

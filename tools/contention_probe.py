@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from event_utils_amd.representations.voxel_grid import _voxel_f32_device  # noqa: E402
+from event_utils_amd import tiled  # noqa: E402
 
 spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libspin.so"))
 spin.spin_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -26,7 +27,7 @@ for _ in range(3):
     call()
 torch.cuda.synchronize()
 for share in ("0", "1"):
-    os.environ["EVK_SHARE_CU"] = share          # EVK_VOXEL2_SHARE_CU: 64 KB instead of 128 KB of LDS per partition workgroup
+    tiled.FORCE["share_cu"] = share == "1"          # EVK_VOXEL2_SHARE_CU: 64 KB instead of 128 KB of LDS per partition workgroup
     for lds_kb in (4, 24, 48, 64):
         for k in (0, 8, 64):
             reps, ts = 10, []

@@ -15,7 +15,7 @@ from event_utils_amd.events import DeviceEvents  # noqa: E402
 def run(x, y, t, p, H, W, reps):
     ch, cw = H + 1, W + 1
     for mode in ("full", "compact"):
-        os.environ["EVK_IWE_RECORDS"] = mode
+        tiled.FORCE["iwe_records"] = mode
         ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
         buf = torch.zeros(3 * ch * cw, dtype=torch.float32, device="cuda")
         for name, flags in (("f", 0), ("grad", _lib.EVK_IWE_GRADIENT)):

@@ -4,13 +4,14 @@ traffic in between -- unit polarities accumulate integers, so every launch must 
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import event_utils_amd as E
+from event_utils_amd import tiled
 import voxel_sweep as V
 torch.cuda.set_device(0)
 H, W, B = 480, 640, 5
 filler = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
 bad = 0
 for rec in ("8", "4"):
-    os.environ["EVK_V2_REC"] = rec
+    tiled.FORCE["rec"] = int(rec)
     for kind in ("blob", "edges"):
         for n in (3_000_000, 6_000_000, 11_000_000):
             x, y, t, p = [np.ascontiguousarray(a) for a in V.scene(kind, n, H, W)]

@@ -1,6 +1,6 @@
 """One-pass voxel path (evk_voxel2.hip): correctness against the oracle on the cases that stress the record formats (escapes
 of the 4-byte records: arbitrary polarities, unsorted / sparse time stamps; hot tiles; deterministic mode), then stage
-timings (EVK_V2_REC, EVK_V2_PART, EVK_V2_SPLIT ... are read when the library first runs: one process per variant)."""
+timings (REC=4|8 in the environment of this script forces a record size through tiled.FORCE)."""
 import os
 import sys
 
@@ -84,8 +84,6 @@ def timing(n, H, W, B, reps=20, paths=("v2",), kind="uniform"):
     x, y, t, p = synth(1, n, H, W) if kind == "uniform" else scene(kind, n, H, W)
     cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
     for path in paths:
-        if len(paths) > 1:
-            os.environ["EVK_VOXEL_PATH"] = path
         k = tiled.time_voxel_kernels([cols], float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
         alg = 16.0 * n + B * H * W * 4
         print("%s %-7s n=%d %dx%dx%d: total %.4f ms (%.1f Gev/s, whole-call frac %.3f)  %s  [%s]" % (
@@ -110,7 +108,9 @@ def native_timing(n, H, W, B, reps=20):
 
 if __name__ == "__main__":
     torch.cuda.set_device(0)
-    print("variant: EVK_V2_REC=%s EVK_V2_PART=%s LIB=%s" % (os.environ.get("EVK_V2_REC", "-"), os.environ.get("EVK_V2_PART", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
+    if os.environ.get("REC") in ("4", "8"):
+        tiled.FORCE["rec"] = int(os.environ["REC"])
+    print("variant: REC=%s LIB=%s" % (os.environ.get("REC", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
     if "--check" in sys.argv:
         check()
     paths = ("v2", "v1") if "--v1" in sys.argv else ("v2",)
