@@ -384,16 +384,14 @@ class variance_objective(objective_function):
         return self.evaluate_numeric_gradient(params, xs, ys, ts, ps, warpfunc, img_size, blur_sigma, epsilon,
                                               with_value=True)
 
-    # flows of one three-flow pass may differ by at most this many pixels of displacement over the stream (the LDS
-    # windows are shared and grow by the spread)
-    BATCH_MAX_SPREAD_PX = 6.0
-
     def evaluate_function_batch(self, params_list, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                                 blur_sigma=None):
-        """f at K flows on the same resident events: consecutive flows are grouped in threes and each group whose
-        flows are close enough costs ONE pass over the events (evk_cmax_variance_batch3_tiled_f32); all passes are
-        enqueued back to back and the K results come back in a single readback.  Groups the batched kernel cannot
-        take (far-apart flows, direct-kernel regime) are evaluated one flow at a time."""
+        """f at K flows on the same resident events: consecutive flows are grouped in threes and each group costs ONE
+        pass over the events (evk_cmax_variance_batch3_tiled_f32: every flow's plane has its own LDS window origin, so the
+        flows of a group may lie anywhere -- round 4; until then only flows within 6 px of displacement shared a pass); all
+        passes are enqueued back to back and the K results come back in a single readback.  Groups the batched kernel
+        cannot take (direct-kernel regime, flows too large for the LDS windows) are evaluated one flow at a time.
+        `self.batch_passes` counts the event passes of the last call."""
         pts = [np.asarray(q, dtype=np.float64) for q in params_list]
         K = len(pts)
         vals = [None] * K
@@ -401,22 +399,22 @@ class variance_objective(objective_function):
         setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur) if K and all(len(q) == 2 for q in pts) else None
         if setup is not None:
             ev, t_ref, launch = setup
-            span = abs(ev.t_at(0) - t_ref)
             out = torch.empty(4 * 3 * ((K + 2) // 3), dtype=torch.float64, device=ev.device)
             done = []
             for c in range(0, K, 3):
                 idx = [min(c + k, K - 1) for k in range(3)]
                 trio = [pts[i] for i in idx]
-                spread = max(max(q[d] for q in trio) - min(q[d] for q in trio) for d in range(2)) * span
-                if spread <= self.BATCH_MAX_SPREAD_PX and launch(trio, out[4 * c:4 * c + 12], img_size):
+                if launch(trio, out[4 * c:4 * c + 12], img_size):
                     done.append((c, idx))
             if done:
                 res = out.cpu().numpy().reshape(-1, 4)
                 for c, idx in done:
                     for k, i in enumerate(idx):
                         vals[i] = np.float32(-res[c + k, 1])
+        self.batch_passes = len(done) if setup is not None else 0
         for i in range(K):
             if vals[i] is None:
+                self.batch_passes += 1
                 vals[i] = self.evaluate_function(pts[i], xs, ys, ts, ps, warpfunc, img_size, blur_sigma)
         return vals
 

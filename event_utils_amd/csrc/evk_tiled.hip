@@ -527,7 +527,9 @@ struct IweParams {
     int win_w, win_h;  // LDS / staging window capacity (cells)
     int abs_p, grad;
     int trio;  // MODE 2: flows 1 and 2 differ from flow 0 in vx only / in vy only (forward differences): see k_iwe_tiled
-    int sx_lo, sx_hi, sy_lo, sy_hi;  // bounds of (window origin - tile origin) over the whole stream
+    // bounds of (window origin - tile origin) over the whole stream; MODE 2: one set per flow (every flow's plane has its OWN
+    // window origin, so three flows of any distance share a pass over the events)
+    int sx_lo[3], sx_hi[3], sy_lo[3], sy_hi[3];
     double vxb[2], vyb[2];           // MODE 2 (batch of 3 nearby flows): flows 1 and 2 (flow 0 is vx, vy)
     double fx_scale, fx_inv;         // FIXED 1: LDS cells hold sum(value * 2^k) as int64 (2^k = fx_scale)
 };
@@ -601,25 +603,25 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
     for (int i = threadIdx.x; i < PLANES * lcells; i += EVK_BLOCK) win[i] = 0.0;
     // Window origin from the time span of this slice (records are time-ordered up to intra-block interleaving; an
     // event that still falls outside takes the global-atomic path below, so this is a performance hint only).
-    int wx0 = 0, wy0 = 0;
+    constexpr int NFLOW = MODE == 2 ? 3 : 1;
+    int wx0[NFLOW], wy0[NFLOW];
+#pragma unroll
+    for (int k = 0; k < NFLOW; ++k) wx0[k] = wy0[k] = 0;
     if (hi > lo) {
         const uint2 *rec8 = reinterpret_cast<const uint2 *>(rec);
         const double ta = (double)(COMPACT ? __uint_as_float(rec8[lo].x) : rec[lo].z) - q.t_ref;
         const double tb = (double)(COMPACT ? __uint_as_float(rec8[hi - 1].x) : rec[hi - 1].z) - q.t_ref;
-        double dxm = fmin(-ta * q.vx, -tb * q.vx), dym = fmin(-ta * q.vy, -tb * q.vy);
-        if constexpr (MODE == 2) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                dxm = fmin(dxm, fmin(-ta * q.vxb[k], -tb * q.vxb[k]));
-                dym = fmin(dym, fmin(-ta * q.vyb[k], -tb * q.vyb[k]));
-            }
-        }
         const int tx0 = (tile % g.tiles_x) << g.tw_log2, ty0 = (tile / g.tiles_x) << g.th_log2;
-        int sx = (int)floor(dxm) - 1, sy = (int)floor(dym) - 1;
-        sx = sx < q.sx_lo ? q.sx_lo : (sx > q.sx_hi ? q.sx_hi : sx);  // the gather kernel relies on these bounds
-        sy = sy < q.sy_lo ? q.sy_lo : (sy > q.sy_hi ? q.sy_hi : sy);
-        wx0 = tx0 + sx;
-        wy0 = ty0 + sy;
+#pragma unroll
+        for (int k = 0; k < NFLOW; ++k) {
+            const double vxk = k == 0 ? q.vx : q.vxb[k - 1], vyk = k == 0 ? q.vy : q.vyb[k - 1];
+            const double dxm = fmin(-ta * vxk, -tb * vxk), dym = fmin(-ta * vyk, -tb * vyk);
+            int sx = (int)floor(dxm) - 1, sy = (int)floor(dym) - 1;
+            sx = sx < q.sx_lo[k] ? q.sx_lo[k] : (sx > q.sx_hi[k] ? q.sx_hi[k] : sx);  // the gather kernel relies on these bounds
+            sy = sy < q.sy_lo[k] ? q.sy_lo[k] : (sy > q.sy_hi[k] ? q.sy_hi[k] : sy);
+            wx0[k] = tx0 + sx;
+            wy0[k] = ty0 + sy;
+        }
     }
     __syncthreads();
     const int64_t plane = (int64_t)q.ch * q.cw;
@@ -636,13 +638,13 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             lds_add(cell, v);
     };
     // one located event into one IWE plane (`wp` in LDS, `gp` in the image); GRAD adds the derivative planes behind it
-    auto deposit = [&](int px, int py, float dx, float dy, float mp, float jf, acc_t *wp, float *gp) {
+    auto deposit = [&](int px, int py, float dx, float dy, float mp, float jf, acc_t *wp, float *gp, int ox, int oy) {
         if (IWE_ABLATE < 2) {
             if ((float)(px + py) + dx + dy + mp + jf == 1.2345e-30f) win[0] = 1.0;
             return;
         }
         const float ax = 1.0f - dx, ay = 1.0f - dy;
-        const int lx = px - wx0, ly = py - wy0;
+        const int lx = px - ox, ly = py - oy;
         const float a = jf * mp;
         if (lx >= 0 && ly >= 0 && lx + 1 < q.win_w && ly + 1 < q.win_h) {
             acc_t *c = wp + ly * lw + lx;
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             }
         }
     };
-    auto splat = [&](const float4 &r, double vx, double vy, acc_t *wp, float *gp) {
+    auto splat = [&](const float4 &r, double vx, double vy, acc_t *wp, float *gp, int ox, int oy) {
         int px, py;
         float dx, dy, mp, jf;
         if (IWE_ABLATE < 1) {
@@ -688,7 +690,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             return;
         }
         if (!iwe_event_f32(r, q, vx, vy, px, py, dx, dy, mp, jf)) return;
-        deposit(px, py, dx, dy, mp, jf, wp, gp);
+        deposit(px, py, dx, dy, mp, jf, wp, gp, ox, oy);
     };
     // MODE 2 with the flows of a forward-difference gradient -- v, v + (a, 0), v + (0, b): the x side of flows 0 and 2 and
     // the y side of flows 0 and 1 are the same numbers, and the tests of iwe_event_f32 are per axis, so each axis is
@@ -721,16 +723,16 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
                     mp = (float)(q.abs_p ? fabs(ps) : ps);
                 }
                 const float jf = (float)(-dt);
-                if (X0.ok && Y0.ok) deposit(X0.p, Y0.p, X0.d, Y0.d, mp, jf, win, iwe);
-                if (X1.ok && Y0.ok) deposit(X1.p, Y0.p, X1.d, Y0.d, mp, jf, win + lcells, diwe);
-                if (X0.ok && Y1.ok) deposit(X0.p, Y1.p, X0.d, Y1.d, mp, jf, win + 2 * lcells, diwe + plane);
+                if (X0.ok && Y0.ok) deposit(X0.p, Y0.p, X0.d, Y0.d, mp, jf, win, iwe, wx0[0], wy0[0]);
+                if (X1.ok && Y0.ok) deposit(X1.p, Y0.p, X1.d, Y0.d, mp, jf, win + lcells, diwe, wx0[NFLOW - 2], wy0[NFLOW - 2]);
+                if (X0.ok && Y1.ok) deposit(X0.p, Y1.p, X0.d, Y1.d, mp, jf, win + 2 * lcells, diwe + plane, wx0[NFLOW - 1], wy0[NFLOW - 1]);
                 return;
             }
         }
-        splat(r, q.vx, q.vy, win, iwe);
+        splat(r, q.vx, q.vy, win, iwe, wx0[0], wy0[0]);
         if constexpr (MODE == 2) {
-            splat(r, q.vxb[0], q.vyb[0], win + lcells, diwe);
-            splat(r, q.vxb[1], q.vyb[1], win + 2 * lcells, diwe + plane);
+            splat(r, q.vxb[0], q.vyb[0], win + lcells, diwe, wx0[NFLOW - 2], wy0[NFLOW - 2]);
+            splat(r, q.vxb[1], q.vyb[1], win + 2 * lcells, diwe + plane, wx0[NFLOW - 1], wy0[NFLOW - 1]);
         }
     };
     if constexpr (COMPACT) {
@@ -772,7 +774,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
             st[2 * wcells + c] = cell(win + 2 * lcells + li);
         }
     }
-    if (threadIdx.x == 0) origins[blockIdx.x] = make_int4(wx0, wy0, hi > lo ? 1 : 0, 0);
+    // MODE 2: the three planes are three WINDOWS (ids 3 w + k) with their own origins; the staging layout is the same
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NFLOW; ++k) origins[NFLOW * blockIdx.x + k] = make_int4(wx0[k], wy0[k], hi > lo ? 1 : 0, 0);
+    }
 }
 
 // Gather: every canvas pixel sums the staged windows that cover it and ADDS the sum to the image (which already holds
@@ -785,15 +791,26 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_tiled(const float4 *__restric
 // 8.0 us at VGA
 #define EVK_GATHER_CAP 128
 #define EVK_GATHER_CAND 1024  // windows of all candidate tiles (before the overlap test)
+struct GatherBounds {
+    int sx_lo[3], sx_hi[3], sy_lo[3], sy_hi[3];
+};
+// nflow = 3 (grid.y = 3, GRAD = false): the three flows of a batched evaluation -- flow k = blockIdx.y sums the one-plane
+// windows 3 w + k (own origins, own shift bounds) into plane k of the (3, ch, cw) output.
 template <bool GRAD, int PY>
 __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restrict__ staging,
                                                           const int4 *__restrict__ origins,
                                                           const uint32_t *__restrict__ index, TileGrid g, int slices,
-                                                          int win_w, int win_h, int ch, int cw, int sx_lo, int sx_hi,
-                                                          int sy_lo, int sy_hi, float *__restrict__ iwe,
+                                                          int win_w, int win_h, int ch, int cw, GatherBounds gb, int nflow,
+                                                          float *__restrict__ iwe,
                                                           float *__restrict__ diwe, const float *__restrict__ spill,
                                                           float *__restrict__ spill_clean) {
     constexpr int PLANES = GRAD ? 3 : 1;
+    const int flow = blockIdx.y;
+    const int sx_lo = gb.sx_lo[flow], sx_hi = gb.sx_hi[flow], sy_lo = gb.sy_lo[flow], sy_hi = gb.sy_hi[flow];
+    if (flow > 0) {   // planes 1, 2 of the output and of the spill pair
+        iwe = diwe + (int64_t)(flow - 1) * ch * cw;
+        if (spill) spill += (int64_t)flow * ch * cw, spill_clean += (int64_t)flow * ch * cw;
+    }
     __shared__ int list_w[EVK_GATHER_CAP], list_x[EVK_GATHER_CAP], list_y[EVK_GATHER_CAP];   // unsorted
     __shared__ int sort_w[EVK_GATHER_CAP], sort_x[EVK_GATHER_CAP], sort_y[EVK_GATHER_CAP];   // by window id
     __shared__ int cand[EVK_GATHER_CAND];  // ids of the windows of the candidate tiles
@@ -837,7 +854,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
         const int tile = (ty_a + c / ntx) * g.tiles_x + tx_a + c % ntx;
         const int w0 = (int)part_start[tile] * slices, w1 = (int)part_start[tile + 1] * slices;
         const int at = atomicAdd(&ncand, w1 - w0);
-        for (int w = w0; w < w1 && at + (w - w0) < EVK_GATHER_CAND; ++w) cand[at + (w - w0)] = w;
+        for (int w = w0; w < w1 && at + (w - w0) < EVK_GATHER_CAND; ++w) cand[at + (w - w0)] = nflow * w + flow;
     }
     __syncthreads();
     const int m = ncand;
@@ -884,8 +901,8 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
                 const int tile = ty * g.tiles_x + tx;
                 const int w0 = (int)part_start[tile] * slices, w1 = (int)part_start[tile + 1] * slices;
                 for (int w = w0; w < w1; ++w) {
-                    const int4 o = origins[w];
-                    if (o.z) add_window(w, o.x, o.y);
+                    const int4 o = origins[nflow * w + flow];
+                    if (o.z) add_window(nflow * w + flow, o.x, o.y);
                 }
             }
     }
@@ -1080,7 +1097,7 @@ extern "C" int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index,
 
 extern "C" int64_t evk_iwe_tiled_staging_bytes(int ntiles, int64_t n, int slices, int planes, int win_w, int win_h) {
     return (int64_t)bucket_max_items_balanced(n, ntiles) * slices *
-           ((int64_t)planes * win_w * win_h * (int64_t)sizeof(float) + (int64_t)sizeof(int4));
+           ((int64_t)planes * win_w * win_h * (int64_t)sizeof(float) + (int64_t)planes * (int64_t)sizeof(int4));
 }
 
 static int launch_iwe_tiled(int mode, const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
@@ -1115,8 +1132,14 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
         if (!(fabs(Dx) < 1e6 && fabs(Dy) < 1e6)) return EVK_EINVAL;
         dx_lo = fmin(dx_lo, Dx), dx_hi = fmax(dx_hi, Dx), dy_lo = fmin(dy_lo, Dy), dy_hi = fmax(dy_hi, Dy);
     }
-    q.sx_lo = (int)floor(dx_lo) - 1, q.sx_hi = (int)floor(dx_hi) - 1;
-    q.sy_lo = (int)floor(dy_lo) - 1, q.sy_hi = (int)floor(dy_hi) - 1;
+    GatherBounds gb;
+    for (int k = 0; k < 3; ++k) {   // per flow (MODE 2), else the one flow's in every slot
+        const int kk = k < nflow ? k : 0;
+        const double Dx = -(t_first - t_ref) * vx[kk], Dy = -(t_first - t_ref) * vy[kk];
+        q.sx_lo[k] = gb.sx_lo[k] = (int)floor(fmin(0.0, Dx)) - 1, q.sx_hi[k] = gb.sx_hi[k] = (int)floor(fmax(0.0, Dx)) - 1;
+        q.sy_lo[k] = gb.sy_lo[k] = (int)floor(fmin(0.0, Dy)) - 1, q.sy_hi[k] = gb.sy_hi[k] = (int)floor(fmax(0.0, Dy)) - 1;
+    }
+    (void)dx_lo, (void)dx_hi, (void)dy_lo, (void)dy_hi;
     // fixed-point LDS accumulation when the caller can bound every contribution: |p * p_scale| <= p_bound, |t - t_ref| <=
     // dt_bound.  64-bit cells: one scale for the launch from n * p_bound * max(1, dt_bound) >= any cell sum.
     const double acc_bound = (p_bound > 0.0 && dt_bound >= 0.0) ? (double)n * p_bound * fmax(1.0, dt_bound) : 0.0;
@@ -1136,7 +1159,7 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     q.fx_inv = fixed ? ldexp(1.0, -k) : 0.0;
     const int nwin = bucket_max_items_balanced(n, ntiles) * slices;
     int4 *origins = (int4 *)staging;  // origins first (16 B each), windows after
-    float *st = (float *)((char *)staging + (int64_t)nwin * sizeof(int4));
+    float *st = (float *)((char *)staging + (int64_t)nwin * planes * sizeof(int4));   // (three origins per workgroup in MODE 2)
     hipStream_t s = (hipStream_t)stream;
     const int gpx = (canvas_w + EVK_GATHER_PX - 1) / EVK_GATHER_PX;
     const bool tall = mode == 0 && gpx * ((canvas_h + 7) / 8) > 2048;   // see k_iwe_gather (three planes: 29.3 vs 28.3 us)
@@ -1164,17 +1187,17 @@ static int launch_iwe_tiled(int mode, const float *records, const uint32_t *buck
     if (mode == 0) {
         EVK_IWE_LAUNCH(0);
         if (tall) k_iwe_gather<false, 16><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
-                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
-                                                       spill, spill_clean);
+                                                       canvas_w, gb, 1, out_iwe, out_diwe, spill, spill_clean);
         else k_iwe_gather<false, 8><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
-                                                       canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
-                                                       spill, spill_clean);
-    } else {
-        if (mode == 1) EVK_IWE_LAUNCH(1);
-        else EVK_IWE_LAUNCH(2);
+                                                       canvas_w, gb, 1, out_iwe, out_diwe, spill, spill_clean);
+    } else if (mode == 1) {
+        EVK_IWE_LAUNCH(1);
         k_iwe_gather<true, 8><<<ggrid, EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
-                                                      canvas_w, q.sx_lo, q.sx_hi, q.sy_lo, q.sy_hi, out_iwe, out_diwe,
-                                                      spill, spill_clean);
+                                                      canvas_w, gb, 1, out_iwe, out_diwe, spill, spill_clean);
+    } else {   // three flows: three one-plane gathers (grid.y = flow) over the windows 3 w + flow
+        EVK_IWE_LAUNCH(2);
+        k_iwe_gather<false, 8><<<dim3(ggrid, 3), EVK_BLOCK, 0, s>>>(st, origins, bucket_index, g, slices, win_w, win_h, canvas_h,
+                                                                 canvas_w, gb, 3, out_iwe, out_diwe, spill, spill_clean);
     }
 #undef EVK_IWE_LAUNCH
 #undef EVK_IWE_LAUNCH_C

@@ -396,13 +396,10 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     t_first = ev.t_at(0)
     planes = 3 if (flags & _lib.EVK_IWE_GRADIENT or batch is not None) else 1
     span = abs(t_first - t_ref)
-    # envelope of the displacements; the flows of a batch share their windows, which grow by the spread of the flows
-    # (+1 px: 1.0 for the unit forward differences of a numeric gradient)
+    # the largest displacement over the flows sizes the time slices and the windows (every flow of a batch has its own
+    # window origin: evk_tiled.hip, MODE 2)
     Dx = max(abs(v) for v in vxs) * span
     Dy = max(abs(v) for v in vys) * span
-    if batch is not None:
-        Dx += 1.0 + math.floor((max(vxs) - min(vxs)) * span)
-        Dy += 1.0 + math.floor((max(vys) - min(vys)) * span)
     S, win_w, win_h = _iwe_window(0.0, 1.0, Dx, Dy, 1 << tw, 1 << th, planes)
     # windows the gather kernel must test per pixel; huge flows (line-search overshoots) use the direct kernel
     cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S

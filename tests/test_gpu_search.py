@@ -88,8 +88,9 @@ def test_objective_landscape_and_draw(E, C, golden, scene):
 
 @pytest.mark.parametrize("n,shape", [(400_000, (480, 640)), (30_000, (180, 240))])
 def test_batched_evaluation_equals_single_evaluations(E, monkeypatch, n, shape):
-    """K flows through evaluate_function_batch (three nearby flows per pass on the tiled path; far-apart flows and the
-    direct-kernel regime fall back to single passes) == K separate evaluate_function calls."""
+    """K flows through evaluate_function_batch (three flows per pass on the tiled path, each with its own LDS window origin;
+    flows too large for the windows and the direct-kernel regime fall back to single passes) == K separate
+    evaluate_function calls."""
     H, W = shape
     rng = np.random.default_rng(5)
     x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
@@ -119,6 +120,37 @@ def test_batched_evaluation_equals_single_evaluations(E, monkeypatch, n, shape):
     for k in (3, 6, 10):
         r = ref.evaluate_function(np.array(flows[k]), f64(x), f64(y), f64(t), f64(p), R.linvel_warp(), (H, W), 1.0)
         assert abs(batch[k] - r) <= TOL * abs(r)
+
+
+def test_grid_search_initial_at_configs2_size_takes_nine_event_passes(E, C):
+    """configs[2]'s events (10 M, 640x480): the 25 samples of one grid-search level over the reference's default range
+    (+-150 px/s: flows up to 30 px apart) are 9 passes over the events -- every flow of a three-flow pass has its own LDS
+    window origin (round 4; with shared windows only flows within 6 px shared a pass and this level took 25) -- and equal
+    the single evaluations; three of them are checked against the oracle."""
+    rng = np.random.default_rng(2)
+    n, H, W = 10_000_000, 480, 640
+    x = rng.uniform(1, W - 1, n).astype(np.float32); y = rng.uniform(1, H - 1, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    obj, w = E.variance_objective(), E.linvel_warp()
+    obj.sensor_size = (H, W)
+    calls = []
+    real = obj.evaluate_function_batch
+
+    def counting(*a, **k):
+        r = real(*a, **k)
+        calls.append(obj.batch_passes)
+        return r
+    obj.evaluate_function_batch = counting
+    r = C.grid_search_initial(ev, None, None, None, w, obj, (H, W))
+    assert len(r["params"]) == 25 and calls == [9]
+    single = [float(obj.evaluate_function(np.array(q), ev, None, None, None, w, (H, W), 1.0)) for q in r["params"]]
+    assert np.max(np.abs(f64(r["eval"]) - f64(single))) <= 2e-6 * np.max(np.abs(f64(single)))
+    ref = R.variance_objective(); ref.sensor_size = (H, W); ref.accum = "f64"
+    d = [f64(a) for a in (x, y, t, p)]
+    for k in (0, 12, 23):
+        fr = float(ref.evaluate_function(np.array(r["params"][k]), *d, R.linvel_warp(), (H, W), 1.0))
+        assert abs(r["eval"][k] - fr) <= TOL * abs(fr)
 
 
 def test_rms_objective_matches_reference(E, golden, scene):
