@@ -310,3 +310,46 @@ def test_voxel_kernels_compile_without_register_spills(tmp_path):
     assert all(v <= 80 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n and "ELi8EEEv" in n)
     assert all(v <= 128 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n)
     assert all(v <= 128 for n, (v, _) in seen.items() if "k_part_sorted" in n)
+
+
+def test_evk_bfgs_line_search_logic_on_a_known_function():
+    """events_cmax.evk_bfgs needs no GPU: on an objective object that evaluates a tilted, badly scaled quadratic bowl plus a
+    quartic term it must reach the minimiser from (0, 0) with few (value + gradient) evaluations and three-point passes, stop
+    by itself, call the callback once per accepted point, and never evaluate anything after a failed line search."""
+    from event_utils_amd.contrast_max.events_cmax import evk_bfgs
+    A = np.array([[3.0, 0.3], [0.3, 0.05]])      # positive definite, condition number ~150
+    xm = np.array([40.0, -25.0])
+
+    class Bowl:
+        def __init__(self):
+            self.fg_calls, self.batch_calls = 0, 0
+
+        def f(self, q):
+            d = np.asarray(q, dtype=np.float64) - xm
+            return 0.5 * d.dot(A).dot(d) * 1e-3 + 1e-7 * np.sum(d ** 4) - 2.0
+
+        def evaluate_function_and_gradient(self, q, *a):
+            self.fg_calls += 1
+            d = np.asarray(q, dtype=np.float64) - xm
+            return np.float32(self.f(q)), (A.dot(d) * 1e-3 + 4e-7 * d ** 3).astype(np.float32)
+
+        def evaluate_function_and_numeric_gradient(self, q, *a):
+            self.fg_calls += 1
+            q = np.asarray(q, dtype=np.float64)
+            f0 = self.f(q)
+            return np.float32(f0), np.array([self.f(q + [1, 0]) - f0, self.f(q + [0, 1]) - f0], dtype=np.float32)
+
+        def evaluate_function_batch(self, pts, *a):
+            self.batch_calls += 1
+            assert len(pts) == 3
+            return [np.float32(self.f(q)) for q in pts]
+    for numeric in (False, True):
+        o, seen, tr = Bowl(), [], []
+        x = evk_bfgs(o, np.array([0, 0]), (), numeric_grads=numeric, callback=lambda q: seen.append(np.array(q)), trace=tr)
+        if numeric:     # forward differences with epsilon = 1 are a biased gradient: the search ends where no step along it helps
+            assert o.f(x) - o.f(xm) < 1e-3 * (o.f(np.zeros(2)) - o.f(xm)), (x, o.f(x))
+        else:           # (float32 values: the flat axis resolves ~0.1)
+            assert np.linalg.norm(x - xm) < 0.2, x
+        assert len(seen) == len(tr) - 1 and o.fg_calls == len(tr)
+        assert o.fg_calls <= 25 and o.batch_calls <= 40
+        assert all(tr[k + 1][1] <= tr[k][1] for k in range(len(tr) - 1))       # monotone: every accepted point improves f
