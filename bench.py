@@ -251,7 +251,7 @@ def main():
     }
     if use_dist:
         result["rccl_ranks"] = dist.get_world_size()
-        result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], pd, n, world))
+        result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], sets[(args.steps - 1) % COLUMN_SETS][3], n, world))
         if exchange_choice:
             result["exchange"] = exchange_choice
         # ---- what the step is made of, so that a 1 -> N curve can be read without re-running: the kernels alone, the grid
@@ -260,7 +260,7 @@ def main():
         zgrid = torch.zeros((B, H, W), dtype=torch.float32, device=dev)     # zeros stay zeros under repeated sums
 
         def compute_only(i):
-            _voxel_f32_device(xd, yd, td, pd, B, (H, W), t_first, t_last, out=outs[0], check=False, impl=impl, fresh=True)
+            _voxel_f32_device(*sets[i % COLUMN_SETS], B, (H, W), t_first, t_last, out=outs[0], check=False, impl=impl, fresh=True)
 
         def allreduce_only(i):
             dist.all_reduce(zgrid, op=dist.ReduceOp.SUM)
@@ -275,16 +275,27 @@ def main():
         def serial_rsag(i):
             compute_only(i)
             DD.reduce_scatter_all_gather_sum_(outs[0])
+
+        def banded(K):
+            # ONE call with its exchange overlapped INSIDE it: one partition, the tile kernel in K row bands, band k all-reduced
+            # (asynchronously, RCCL's stream) while band k + 1 accumulates, the reduced bands assembled at the end
+            def run(i):
+                c = sets[i % COLUMN_SETS]
+                DD.banded_exchange(tiled.voxel2_bands(c, n, t_first, t_last, B, H, W, K), outs[0])
+            return run
         ms = lambda fn: round(timed(fn, args.steps, args.warmup) / args.steps * 1e3, 4)   # noqa: E731
         result["breakdown"] = {
             "headline_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only), "allreduce_ms": ms(allreduce_only),
             "reduce_scatter_all_gather_ms": ms(rsag_only), "serial_ms": ms(serial), "serial_rsag_ms": ms(serial_rsag),
+            "banded_ms": {str(K): ms(banded(K)) for K in (2, 4)},
             "n1_equivalent_ms": ms(step_public), "grid_bytes": int(zgrid.numel() * 4),
             "note": "max over ranks, barrier + synchronize on both sides like ms_per_step.  headline_ms = the timed step "
                     "(`exchange`: all-reduce of step i overlapped with the kernels of step i+1, or serial -- the faster of "
                     "the two in the warm-up); compute_ms = this rank's kernels with "
                     "no collective (internal entry, resident grid); allreduce_ms / reduce_scatter_all_gather_ms = the grid "
-                    "exchange alone; serial_* = kernels then exchange, not overlapped; n1_equivalent_ms = the public "
+                    "exchange alone; serial_* = kernels then exchange, not overlapped; banded_ms[K] = ONE call whose tile "
+                    "kernel runs in K row bands, band k all-reduced while band k + 1 accumulates (EVK_VOXEL_COLLECTIVE=bandsK: "
+                    "the exchange overlapped inside a single call); n1_equivalent_ms = the public "
                     "events_to_voxel_torch call BENCH's N = 1 `value` times, here on every rank at once without a "
                     "collective (it allocates the grid and reads ts[0]/ts[-1] on the device: ~1 % above compute_ms)"}
     else:

@@ -69,6 +69,7 @@ SIGNATURES = {
     "evk_voxel2_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_float,
                               c_float, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_normalise_time_f32": [P, c_int64, c_float, c_float, c_int, P, P],
+    "evk_voxel2_band_f32": [c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P],
     "evk_image2_nearest_i32": [P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_image2_nearest_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
                                c_uint32, P],

@@ -41,12 +41,18 @@ namespace evk {
 // grid is bit-identical from run to run and for any order of the events.  |contribution| < 2^30 and finite, else it is
 // counted in index[4] and left out (the wrapper raises).
 #define V2_FIXED_ONE 4294967296.0
+// A ROW BAND of the grid (round 4; evk_voxel2_band_f32): only the tiles [tile_lo, tile_hi) are accumulated, and written to a
+// (planes, rows, dom_w) buffer of their own whose first row is image row y_lo -- contiguous, so that an event-sharded run can
+// all-reduce band k while band k + 1 is still being accumulated.  tile_hi == 0: the whole grid, as ever.
+struct Band {
+    int tile_lo, tile_hi, y_lo, rows;
+};
 template <int WG, int U, bool SPLIT, bool FIXED, int REC>
 __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const void *__restrict__ rec_, const void *__restrict__ side_,
                                                      const uint32_t *__restrict__ bases,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGridG g, Part2 q, int B, int flags, float *__restrict__ vox,
-                                                     float *__restrict__ staging) {
+                                                     float *__restrict__ staging, Band band) {
     constexpr int NW = WG / 64, E = V2_ENT(REC);
     // REC 8: a lane takes 16 bytes = 2 records {t_norm, polarity | cell}; REC 4: 8 bytes = 2 one-word records (k_part_sorted),
     // decoded with the base of their sub-chunk, which travels with the chunk list
@@ -68,7 +74,9 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
     V2_T0();
-    const uint32_t nitems = part_start[ntiles];
+    const uint32_t nitems_all = part_start[ntiles];
+    uint32_t item_lo = 0, nitems = nitems_all;
+    if (band.tile_hi > 0) item_lo = part_start[band.tile_lo], nitems = part_start[band.tile_hi] - item_lo;
     if (blockIdx.x >= nitems) return;
     // XCD-aware work-item order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), and the segments of NEIGHBOURING
     // tiles are neighbours in every run (and their table entries share a cache line), so XCD k takes a contiguous
@@ -77,10 +85,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     uint32_t item = blockIdx.x;
     // (not when tiles were cut: the pieces of a hot tile are neighbours in the item order, a contiguous range would hand most
     // of a blob to two or three XCDs -- blob scene 68 -> 63 us in plain order, uniform events 29 -> 34 us)
-    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER) && nitems == (uint32_t)ntiles) {
+    if (!(flags & EVK_VOXEL2_NO_XCD_ORDER) && nitems_all == (uint32_t)ntiles) {
         const uint32_t k = blockIdx.x & 7u, j = blockIdx.x >> 3, q8 = nitems >> 3, r8 = nitems & 7u;
         item = k * q8 + (k < r8 ? k : r8) + j;
     }
+    item += item_lo;
     const int tw = g.tw, th = g.th, tpix = tw * th;
     // LDS layout of the accumulators: rows of tw | 1 cells (8 bytes), i.e. an ODD pitch.  With a pitch of 32 cells = 64
     // dwords every row of one column lands on the same pair of banks, and the events of a real scene sit on edges: a
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // every workgroup of a launch whose workgroups all start together -- are not made)
     int tile = (int)item;
     uint32_t first_item = item, nparts = 1u;
-    if (nitems != (uint32_t)ntiles) {
+    if (nitems_all != (uint32_t)ntiles) {
         tile = (int)item_tile[item];
         first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     }
@@ -545,7 +554,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     V2_U(7);
     __syncthreads();
     V2_U(8);
-    const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    const int64_t plane = (int64_t)(band.tile_hi > 0 ? band.rows : g.dom_h) * g.dom_w;
     auto split_cell = [&](int c, int &b, int &row, int &col) {   // dense cell c = (plane, row, column) of the tile
         b = (int)div_magic((uint32_t)c, g.mp);
         const int l = c - b * tpix;
@@ -558,7 +567,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             split_cell(c, b, row, col);
             const int X = tx0 + col, Y = ty0 + row;
             if (X < g.dom_w && Y < g.dom_h) {
-                float *o = vox + b * plane + (int64_t)Y * g.dom_w + X;
+                float *o = vox + b * plane + (int64_t)(Y - band.y_lo) * g.dom_w + X;
                 const float v = value_of(c);
                 *o = overwrite ? v : *o + v;
             }
@@ -693,7 +702,7 @@ extern "C" int evk_voxel2_max_tiles(void) {
 template <int WG, int U, bool SPLIT, bool FIXED, int REC>
 static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *rec, const void *pw, const uint32_t *bases,
                          const uint32_t *table, uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox,
-                         float *staging) {
+                         float *staging, const Band &band) {
     static std::once_flag once[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -701,13 +710,13 @@ static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *r
         (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED, REC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP(WG) - 256);
     });
-    k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging);
+    k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);
 }
 
 template <typename C>
 static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, float t_first, float t_last, int B,
                   int flags, float *vox, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
-                  uint32_t *host_report, uint32_t seq, void *stream) {
+                  uint32_t *host_report, uint32_t seq, void *stream, const Band &band = Band{0, 0, 0, 0}) {
     TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC |
@@ -771,10 +780,10 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
 #define V2_UU(R) ((R) == 4 ? V2_U4 : V2_U8)
 #define V2_TILES(W, R)                                                                                                     \
     do {                                                                                                                   \
-        if (sp && fx) launch_tiles<W, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (sp) launch_tiles<W, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else if (fx) launch_tiles<W, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);   \
-        else launch_tiles<W, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging);          \
+        if (sp && fx) launch_tiles<W, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
+        else if (sp) launch_tiles<W, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
+        else if (fx) launch_tiles<W, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
+        else launch_tiles<W, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);          \
     } while (0)
         // Threads per tile workgroup.  8-byte records (cache-resident calls): 768 -- twelve waves per tile -- while TWO such
         // workgroups fit a CU's LDS (accumulators + 12 chunk lists <= 80 KB: VGA at 5 bins; not split polarities or 720p
@@ -837,6 +846,23 @@ extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, co
     const SrcF32 c{x, y, t, p};
     return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
                   seq, stream);
+}
+
+extern "C" int evk_voxel2_band_f32(int64_t n, int h, int wd, int tile_w, int tile_h, int B, int flags, int tile_row_lo,
+                                   int tile_row_hi, float *band, uint32_t *index, void *scratch, int64_t scratch_bytes,
+                                   void *stream) {
+    TileGridG g;
+    if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || tile_row_lo < 0 || tile_row_hi <= tile_row_lo ||
+        tile_row_hi > g.tiles_y || !band)
+        return EVK_EINVAL;
+    const int y_lo = tile_row_lo * tile_h, y_hi = tile_row_hi * tile_h < h ? tile_row_hi * tile_h : h;
+    const Band b{tile_row_lo * g.tiles_x, tile_row_hi * g.tiles_x, y_lo, y_hi - y_lo};
+    const SrcF32 none{nullptr, nullptr, nullptr, nullptr};
+    // the tile kernel alone (the records of the preceding EVK_VOXEL2_PARTITION_ONLY call are in `scratch`), over the band's
+    // tiles, always overwriting: every cell of the band buffer is written
+    return voxel2(none, n, h, wd, tile_w, tile_h, 0.0f, 0.0f, B,
+                  (flags & ~(EVK_VOXEL2_PARTITION_ONLY | EVK_VOXEL_T_FROM_EVENTS)) | EVK_VOXEL2_TILES_ONLY | EVK_VOXEL_OVERWRITE, band,
+                  index, scratch, scratch_bytes, nullptr, nullptr, 0, stream, b);
 }
 
 extern "C" int evk_voxel2_native_f32(const int16_t *x, const int16_t *y, int xy_stride, const void *t, int t_kind,

@@ -178,22 +178,67 @@ def _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob=None):
     return tiled.voxel_f32(*cols, float(t_first), float(t_last), B, H, W, out, oob, fresh=True)
 
 
+def banded_exchange(bands, out, group=None):
+    """`bands` yields (y_lo, y_hi, band) -- contiguous (B, rows, W) partial grids of this rank, each one yielded as soon as
+    its kernel is enqueued.  Every band's SUM all-reduce is issued asynchronously right then (RCCL runs it on its own stream,
+    behind the band's kernel), so it overlaps the accumulation of the bands that follow; the reduced bands are copied into
+    `out` (B, H, W) at the end.  The same bytes as one all-reduce of the grid, in len(bands) pieces."""
+    dist = _dist()
+    pending = []
+    for y0, y1, band in bands:
+        work = dist.all_reduce(band, op=dist.ReduceOp.SUM, group=group, async_op=True) \
+            if (dist.is_available() and dist.is_initialized()) else None
+        pending.append((y0, y1, band, work))
+    for y0, y1, band, work in pending:
+        if work is not None:
+            work.wait()
+        out[:, y0:y1, :].copy_(band)
+    return out
+
+
+def voxel_bands():
+    """Row bands of the intra-call overlap of the voxel exchange (EVK_VOXEL_COLLECTIVE=bandsK, K = 2..8; default: one
+    all-reduce of the whole grid after the kernels)."""
+    v = voxel_collective()
+    return int(v[5:]) if v.startswith("bands") and v[5:].isdigit() else 0
+
+
 def events_to_voxel_torch_sharded(xs, ys, ts, ps, B, sensor_size=(180, 240), group=None, local_fn=None):
     """events_to_voxel_torch over an event stream sharded across ranks: `xs, ys, ts, ps` are THIS rank's slice.
     Returns the full (B, H, W) grid on every rank.  `local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last)`
     computes one shard's partial grid (default: the HIP kernels; the CPU tests inject the oracle).  Out-of-range
-    coordinates raise IndexError on every rank, after the collectives."""
+    coordinates raise IndexError on every rank, after the collectives.
+    EVK_VOXEL_COLLECTIVE=bandsK: the exchange overlaps the call's own kernels -- the tile kernel runs in K row bands and band
+    k is all-reduced while band k + 1 accumulates (banded_exchange)."""
     n = len(xs)
     inf = float("inf")
     t0 = float(ts[0]) if n else inf
     t1 = float(ts[-1]) if n else -inf
     t_first, t_last = global_time_range(t0, t1, group)
+    K = voxel_bands()
+    H, W = int(sensor_size[0]), int(sensor_size[1])
     if local_fn is not None:
-        return all_reduce_sum_(local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last), group, form=voxel_collective())
+        part = local_fn(xs, ys, ts, ps, B, sensor_size, t_first, t_last)
+        if K >= 2:      # (CPU tests: the banding and the assembly with the oracle's partial grid cut into row bands)
+            edges = [k * H // K for k in range(K + 1)]
+            out = torch.empty_like(part)
+            return banded_exchange(((edges[k], edges[k + 1], part[:, edges[k]:edges[k + 1], :].contiguous()) for k in range(K)
+                                    if edges[k + 1] > edges[k]), out, group)
+        return all_reduce_sum_(part, group, form=voxel_collective())
     from . import _device as D
+    from . import tiled
     oob = D.OobCounter(D.require_gpu(), poll=False)
-    part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
-    out = all_reduce_sum_(part, group, form=voxel_collective())
+    bands = None
+    if K >= 2 and n:
+        dev = D.require_gpu()
+        cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
+        if tiled.can_tile(cols, tiled.default_impl()):
+            bands = tiled.voxel2_bands(cols, n, float(t_first), float(t_last), B, H, W, K, oob)
+    if bands is not None:
+        out = banded_exchange(bands, torch.empty((B, H, W), dtype=torch.float32, device=dev), group)
+    else:
+        part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
+        out = all_reduce_sum_(part, group, form="rsag" if voxel_collective() == "rsag" else None)
     _raise_everywhere(oob.state, IndexError, "index out of range for voxel grid of size %s"
                       % ((B, int(sensor_size[0]), int(sensor_size[1])),), group)
     return out

@@ -205,11 +205,10 @@ def voxel2_shape(H, W, planes):
     return shape
 
 
-def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
-    """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
-    ts[-1] are read on the device (no transfer before the launch)."""
+def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
+    """(index, scratch, scratch bytes, flags) of a call of the one-pass voxel path: the persistent per-stream buffers and the
+    flags every launch of one call must share (geometry, record size, workgroup shapes)."""
     L = _lib.lib()
-    dev = out.device
     ver = "voxel2"
     planes = 2 * B if split_polarity else B
     ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
@@ -222,7 +221,7 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
             raise _lib.EvkError("evk_%s: unsupported geometry (%d tiles, %d events)" % (ver, ntiles, n))
     index = _zbuf(ver + "_index", sizes[0], dev)
     scratch = _buf(ver + "_scratch", sizes[1], dev)
-    flags = (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | (_lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0) | stage
+    flags = _lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0
     if share_cu():
         flags |= 128         # EVK_VOXEL2_SHARE_CU
     if not FORCE["xcd_order"]:
@@ -232,9 +231,53 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
         flags |= _lib.EVK_VOXEL2_NO_COUNT
     if FORCE["tiles_wg"] == 512:
         flags |= _lib.EVK_VOXEL2_WG512
-    det = voxel_deterministic()
-    if det:
+    if voxel_deterministic():
         flags |= _lib.EVK_VOXEL_DETERMINISTIC
+    return index, scratch, sizes[1], flags
+
+
+def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
+    """The one-pass voxel path in ROW BANDS (evk_voxel2_band_f32), for event-sharded runs: ONE partition, then the tile kernel
+    of every band of tile rows launched on the current stream, each writing a contiguous (B, rows, W) buffer of its own.
+    A generator: yields (y_lo, y_hi, band) right after band k's launch, so that the caller can start band k's all-reduce
+    (another stream) while band k + 1 accumulates.  None when the one-pass path has no tiling for this grid."""
+    import torch
+    shape = voxel2_shape(H, W, B)
+    if shape is None:
+        return None
+    tw, th = shape
+    dev = cols[0].device
+    index, scratch, nbytes, flags = _voxel2_env(dev, n, B, H, W, tw, th)
+    tiles_y = -(-H // th)
+    nbands = max(1, min(int(nbands), tiles_y))
+    edges = [k * tiles_y // nbands for k in range(nbands + 1)]
+    report, seq = oob.report_args() if oob is not None else (None, 0)
+    dummy = torch.empty(1, dtype=torch.float32, device=dev)      # (the partition does not touch the grid)
+    _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, H, W, tw, th, t_first, t_last, B,
+              flags | _lib.EVK_VOXEL2_PARTITION_ONLY, D.ptr(dummy), D.ptr(index), D.ptr(scratch), nbytes,
+              oob.ptr if oob is not None else None, report, seq, D.stream())
+
+    def gen():
+        for k in range(nbands):
+            r0, r1 = edges[k], edges[k + 1]
+            if r1 <= r0:
+                continue
+            y0, y1 = r0 * th, min(r1 * th, H)
+            band = torch.empty((B, y1 - y0, W), dtype=torch.float32, device=dev)
+            _lib.call("evk_voxel2_band_f32", n, H, W, tw, th, B, flags, r0, r1, D.ptr(band), D.ptr(index), D.ptr(scratch), nbytes,
+                      D.stream())
+            yield y0, y1, band
+    return gen()
+
+
+def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
+    """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
+    ts[-1] are read on the device (no transfer before the launch)."""
+    index, scratch, nbytes, flags = _voxel2_env(out.device, n, B, H, W, tw, th, split_polarity)
+    sizes = (index.numel(), nbytes)
+    ver = "voxel2"
+    flags |= (_lib.EVK_VOXEL_OVERWRITE if fresh else 0) | stage
+    det = voxel_deterministic()
     if t_first is None:
         flags |= _lib.EVK_VOXEL_T_FROM_EVENTS
         t_first = t_last = 0.0

@@ -356,6 +356,13 @@ int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *
                    int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
                    uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                    uint32_t seq, void *stream);
+/* ROW BANDS for event-sharded runs: after an evk_voxel2_f32 call with EVK_VOXEL2_PARTITION_ONLY (same n, h,
+ * wd, tile size, B, flags, index, scratch), accumulate only the tile rows [tile_row_lo, tile_row_hi) and WRITE them to `band`,
+ * a contiguous (B, rows, wd) float32 buffer (rows = min(tile_row_hi * tile_h, h) - tile_row_lo * tile_h; 2B planes with
+ * EVK_VOXEL_SPLIT_POLARITY).  A sharded caller launches the bands one after the other and all-reduces band k (one contiguous
+ * buffer) while band k + 1 is being accumulated; event_utils_amd/distributed.py does. */
+int evk_voxel2_band_f32(int64_t n, int h, int wd, int tile_w, int tile_h, int B, int flags, int tile_row_lo, int tile_row_hi,
+                        float *band, uint32_t *index, void *scratch, int64_t scratch_bytes, void *stream);
 /* out[i] = (t[i] - t_first) / (t_last - t_first) * (B - 1) in float32: the normalised time of voxel_grid.py:134, by the very
  * function the partition kernel calls -- bit-identical to numpy's float32 arithmetic; the tests compare it bit for bit. */
 int evk_normalise_time_f32(const float *t, int64_t n, float t_first, float t_last, int B, float *out, void *stream);

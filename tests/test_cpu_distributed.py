@@ -50,8 +50,14 @@ def _worker(rank, world, port, n, out_dir):
     os.environ["EVK_VOXEL_COLLECTIVE"] = "rsag"
     assert DD.voxel_collective() == "rsag"
     vox2 = DD.events_to_voxel_torch_sharded(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi], B, (H, W), local_fn=_oracle_local)
-    os.environ.pop("EVK_VOXEL_COLLECTIVE")
     err = max(err, np.abs(vox2.numpy().astype(np.float64) - ref).max())
+    # ... and through the banded exchange (EVK_VOXEL_COLLECTIVE=bands3: three row bands, each all-reduced asynchronously
+    # while the next one is produced, assembled at the end)
+    os.environ["EVK_VOXEL_COLLECTIVE"] = "bands3"
+    assert DD.voxel_bands() == 3
+    vox3 = DD.events_to_voxel_torch_sharded(x[lo:hi], y[lo:hi], t[lo:hi], p[lo:hi], B, (H, W), local_fn=_oracle_local)
+    os.environ.pop("EVK_VOXEL_COLLECTIVE")
+    err = max(err, np.abs(vox3.numpy().astype(np.float64) - ref).max())
     odd = torch.arange(7, dtype=torch.float32) * (rank + 1)
     DD.reduce_scatter_all_gather_sum_(odd)
     assert torch.equal(odd, torch.arange(7, dtype=torch.float32) * sum(range(1, world + 1)))

@@ -73,7 +73,21 @@ def test_voxel_exchange_as_reduce_scatter_all_gather_and_errors_on_every_rank(pg
     plain = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
     monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "rsag")
     rsag = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
-    assert torch.equal(plain, rsag)
+    # (one rank here: the same sums; over more ranks the two forms add the partial grids in different orders)
+    assert torch.allclose(plain, rsag, rtol=1e-6, atol=1e-6 * float(plain.abs().max()))
+    # the banded exchange (EVK_VOXEL_COLLECTIVE=bandsK): one partition, the tile kernel in K row bands, every band
+    # all-reduced while the next one accumulates -- the same grid (same kernels, same per-tile sums: bit-identical)
+    for K in (2, 4, 64):
+        monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "bands%d" % K)
+        banded = DD.events_to_voxel_torch_sharded(*cols, B, (H, W))
+        assert torch.equal(plain, banded), K
+    hot = [c.clone() for c in cols]
+    hot[0][: n // 2] = 40.0; hot[1][: n // 2] = 60.0               # a hot pixel: cut tiles inside a band
+    monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "allreduce")
+    ref_hot = DD.events_to_voxel_torch_sharded(*hot, B, (H, W))
+    monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "bands3")
+    assert torch.equal(ref_hot, DD.events_to_voxel_torch_sharded(*hot, B, (H, W)))
+    monkeypatch.setenv("EVK_VOXEL_COLLECTIVE", "rsag")
     odd = torch.arange(1001, dtype=torch.float32, device="cuda")
     assert torch.equal(DD.reduce_scatter_all_gather_sum_(odd.clone()), odd)
     # a deferred report left behind by an earlier call on this stream is folded into the sharded call's own check
