@@ -518,7 +518,7 @@ def bench_image_10m(E, tiled, dev, impl):
            "impl": "one-pass partition (k_part_sorted, 4-byte nearest / 8+4-byte bilinear records) + k_image_tiles_n / _b; tiles %dx%d"
                    % tiled.voxel2_shape(H, W, 1)}
 
-    def block(k, public_ms=None):
+    def block(k, public_ms=None, tag=None):
         if k is None:
             return {"error": "no tiling"}
         b = {"call_ms": round(k["call_ms"], 4), "Mevents_per_s": round(n / k["call_ms"] / 1e3, 1),
@@ -527,6 +527,10 @@ def bench_image_10m(E, tiled, dev, impl):
         if public_ms is not None:
             b["public_call_ms"] = round(public_ms, 4)
             b["public_Mevents_per_s"] = round(n / public_ms / 1e3, 1)
+        if tag is not None:     # HBM bytes of one call from the committed rocprofv3 PMC passes of this same workload
+            _, src, call_traffic = pmc_traffic("k_part_sorted", tag)
+            if call_traffic:
+                b["traffic"], b["traffic_source"] = call_traffic, src
         return b
 
     def public(**kw):
@@ -535,7 +539,7 @@ def bench_image_10m(E, tiled, dev, impl):
         def fn():
             keep[0] = E.events_to_image_torch(xd, yd, kw.pop("_p", pud), sensor_size=(H, W), **kw)
         return fn
-    res["events_to_image_int32"] = block(_image_kernel_times(tiled, "i32", (xi, yi, pi), n, H, W, torch.int32, 20))
+    res["events_to_image_int32"] = block(_image_kernel_times(tiled, "i32", (xi, yi, pi), n, H, W, torch.int32, 20), tag="img_nearest")
     for name, kind, pcol, kw in (("events_to_image_torch_nearest", "f32", pud, dict(interpolation=None, padding=False)),
                                  ("events_to_image_torch_nearest_float_weights", "f32", pfd, dict(interpolation=None, padding=False)),
                                  ("events_to_image_torch_bilinear", "bilinear", pud, dict(interpolation='bilinear', padding=False)),
@@ -545,7 +549,8 @@ def bench_image_10m(E, tiled, dev, impl):
 
         def fn(pcol=pcol, kw=kw):
             keep[0] = E.events_to_image_torch(xd, yd, pcol, sensor_size=(H, W), **kw)
-        res[name] = block(_image_kernel_times(tiled, kind, (xd, yd, pcol), n, H, W, torch.float32, 20), tiled._time_ms(fn, 20))
+        res[name] = block(_image_kernel_times(tiled, kind, (xd, yd, pcol), n, H, W, torch.float32, 20), tiled._time_ms(fn, 20),
+                          tag="img_bilinear" if name == "events_to_image_torch_bilinear" else None)
     E.check_errors()
     # the global-atomic kernels these calls ran on until round 4 (EVK_IMPL=direct), for the record
     canvas = torch.zeros((H, W), dtype=torch.int32, device=dev)

@@ -10,7 +10,8 @@ import os
 import re
 import sys
 
-ALG = {"c2": 16 * 10_000_000 + 5 * 480 * 640 * 4, "c5_share": 16 * 50_000_000 + 5 * 720 * 1280 * 4}
+ALG = {"c2": 16 * 10_000_000 + 5 * 480 * 640 * 4, "c5_share": 16 * 50_000_000 + 5 * 720 * 1280 * 4,
+       "img_nearest": 12 * 10_000_000 + 480 * 640 * 4, "img_bilinear": 12 * 10_000_000 + 480 * 640 * 4}
 
 
 def collect(d, counter):
@@ -30,11 +31,13 @@ def collect(d, counter):
 def main():
     root = sys.argv[1]
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py <tag> "
-                   "(8 calls of the voxel path alone); hbm bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
+                   "(8 calls of the voxel / event-image path alone); hbm bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
                    "FETCH_SIZE reports half of a wide coalesced streaming read, MI355X_MICROARCH.md HBM section; WRITE_SIZE "
                    "as reported).  whole_call_bytes = sum over the kernels of one call; algorithmic_bytes = 16 B/event + "
-                   "the grid (SURVEY.md 8(d)).  Summarised by tools/pmc_summary.py."}
-    for tag in ("c2", "c5_share"):
+                   "the grid, 12 B/event + the image for img_* (SURVEY.md 8(d)).  Summarised by tools/pmc_summary.py."}
+    for tag in ("c2", "c5_share", "img_nearest", "img_bilinear"):
+        if not os.path.isdir(os.path.join(root, "pmc_fetch_" + tag)):
+            continue
         fetch = collect(os.path.join(root, "pmc_fetch_" + tag), "FETCH_SIZE")
         write = collect(os.path.join(root, "pmc_write_" + tag), "WRITE_SIZE")
         ks, total = {}, 0

@@ -1,6 +1,8 @@
 """The voxel call of one bench workload, alone, for the rocprofv3 PMC passes (tools/profile_round.sh):
     python tools/pmc_workload.py c2        10 M events, 640x480x5   (configs[1], the headline)
     python tools/pmc_workload.py c5_share  50 M events, 1280x720x5  (one rank's share of configs[4])
+    python tools/pmc_workload.py img_nearest | img_bilinear   10 M events, 640x480: events_to_image (int32) /
+                                           events_to_image_torch(bilinear) through the one-pass path (evk_image2.hip)
 Runs the internal entry point (resident grid, no per-call checks) 8 times so that the counters see exactly the kernels
 of the call: k_part_sorted and k_voxel_tiles2 (evk_voxel2.hip)."""
 import os
@@ -13,6 +15,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from event_utils_amd.representations.voxel_grid import _voxel_f32_device  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if tag.startswith("img_"):     # the event images of bench.py's image_10m block: 10 M events, 640x480, one-pass path
+    from event_utils_amd import tiled  # noqa: E402
+    n, H, W = 10_000_000, 480, 640
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
+    inf = float("inf")
+    if tag == "img_nearest":
+        cols, kind, img = (xd.int(), yd.int(), pd.int()), "i32", torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    else:
+        cols, kind, img = (xd, yd, pd), "bilinear", torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    for _ in range(8):
+        assert tiled.image2(kind, *cols, n, H, W, inf, inf, img, None, fresh=(kind != "bilinear"))
+    torch.cuda.synchronize()
+    print("done", tag)
+    sys.exit(0)
 n, H, W, B = (10_000_000, 480, 640, 5) if tag == "c2" else (50_000_000, 720, 1280, 5)
 rng = np.random.default_rng(1 if tag == "c2" else 40)
 x = rng.integers(0, W, n).astype(np.float32)
