@@ -195,7 +195,7 @@ def _report_at_exit():
     process: say so on stderr.  (An exception cannot propagate out of an atexit hook.)"""
     import sys
     try:
-        if not torch.cuda.is_available():
+        if not any(st.pending for st in _errors.values()):    # nothing deferred: do not touch (or initialise) the device
             return
         check_errors()
     except (IndexError, ValueError) as e:

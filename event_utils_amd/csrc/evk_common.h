@@ -13,6 +13,31 @@
 #define EVK_BLOCK 256
 #define EVK_NUM_CU 256
 
+// The in-kernel hand-overs of this library (the partition's ticket, the pieces of a cut tile, the host publish of a result)
+// carry NO release / acquire fence: everything the receiving side reads was written with agent- (or system-) scope atomics,
+// which on gfx950 are performed at the level all XCDs share and complete -- vmcnt -- only then, and every wave drains its own
+// with `s_waitcnt vmcnt(0)` before the workgroup's ticket (DESIGN.md section 3, K1': a fence there is a write-back of the
+// XCD's whole L2, 4.5 us of a 47 us kernel).  That reasoning is specific to gfx9-family memory pipelines (one counter, vmcnt,
+// covering loads, stores and atomics): refuse to compile the device code for anything else.  -DEVK_SAFE_HANDOVER puts the
+// textbook fences back (release before the ticket, acquire after it) so that the parity tests can be run with both forms.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "libevk's fence-free hand-overs assume a gfx9-family memory pipeline (built and validated for gfx950 only)"
+#endif
+#ifdef EVK_SAFE_HANDOVER
+#define EVK_HANDOVER_RELEASE() __atomic_thread_fence(__ATOMIC_RELEASE)   /* (HIP: agent scope) */
+#define EVK_HANDOVER_ACQUIRE() __atomic_thread_fence(__ATOMIC_ACQUIRE)
+#else
+#define EVK_HANDOVER_RELEASE() do {} while (0)
+#define EVK_HANDOVER_ACQUIRE() do {} while (0)
+#endif
+// every wave drains its own stores / atomics, [fence], workgroup barrier: what precedes a ticket
+#define EVK_HANDOVER_DRAIN()                              \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+        EVK_HANDOVER_RELEASE();                           \
+        __syncthreads();                                  \
+    } while (0)
+
 namespace evk {
 
 __device__ __forceinline__ void atomic_add(float *p, float v) {

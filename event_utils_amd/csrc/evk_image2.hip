@@ -164,8 +164,7 @@ __device__ __forceinline__ bool img_item(const uint32_t *index, int ntiles, cons
 // stores and every wave has drained them: no fence, evk_voxel2.hip)
 __device__ __forceinline__ bool img_last_part(uint32_t *index, int ntiles, const ImgItem &it) {
     __shared__ int is_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    EVK_HANDOVER_DRAIN();
     if (threadIdx.x == 0) {
         uint32_t *counter = index + V2_COUNTER(ntiles) + it.tile;
         const uint32_t prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -173,6 +172,7 @@ __device__ __forceinline__ bool img_last_part(uint32_t *index, int ntiles, const
         if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    if (is_last) EVK_HANDOVER_ACQUIRE();
     return is_last != 0;
 }
 
@@ -477,6 +477,11 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
 #define IMG_WG 512
 static inline int img_window_cells(int tw, int th) { return (tw + 1) * (th + 1); }
 
+// sub-chunks of 8 K events, or -- more than 680 tiles (720p and up): longer segments for the tile kernel -- 12 K, when the
+// bilinear format's 12 bytes of LDS per event and the tile counters still fit
+static inline bool img_small(int ntiles) {
+    return ntiles <= 680 || v2_part_lds(1024, 12, V2_FMT_IMGB, ntiles) > (size_t)V2_LDS_LIMIT;
+}
 struct ImgCall {
     TileGridG g;
     Part2 q;
@@ -495,10 +500,11 @@ static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile
     if (ic.ntiles > evk_voxel2_max_tiles() || !evk_voxel2_num_tiles(h, wd, tile_w, tile_h) ||
         (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX)
         return EVK_EINVAL;
-    ic.L = v2_layout(ic.ntiles, n, 2, tile_w, tile_h, true);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
+    const bool small = img_small(ic.ntiles);
+    ic.L = v2_layout(ic.ntiles, n, 2, tile_w, tile_h, small);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
     if (scratch_bytes < ic.L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
-    ic.q = v2_geometry(n, ic.ntiles, true);
+    ic.q = v2_geometry(n, ic.ntiles, small);
     return EVK_OK;
 }
 
@@ -506,8 +512,12 @@ template <int FMT, typename C>
 static void img_partition(const C &c, int64_t n, const ImgCall &ic, uint32_t *index, void *scratch, uint32_t *oob,
                           uint32_t *host_report, uint32_t seq, hipStream_t s) {
     char *sb = (char *)scratch;
-    launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
-                              (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
+    if (img_small(ic.ntiles))
+        launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
+                                  (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
+    else
+        launch_part<1024, 12, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
+                                   (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
 }
 
 }  // namespace evk
@@ -516,7 +526,7 @@ using namespace evk;
 
 extern "C" int64_t evk_image2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h) {
     if (ntiles <= 0 || n < 0 || tile_w <= 0 || tile_h <= 0) return 0;
-    return v2_layout(ntiles, n, 2, tile_w, tile_h, true).total;
+    return v2_layout(ntiles, n, 2, tile_w, tile_h, img_small(ntiles)).total;
 }
 
 extern "C" int evk_image2_nearest_i32(const int32_t *x, const int32_t *y, const int32_t *w, int64_t n, int canvas_h,

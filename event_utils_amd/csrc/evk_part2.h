@@ -557,8 +557,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             __hip_atomic_store(gidx + 1, __float_as_uint(c.t1(n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    EVK_HANDOVER_DRAIN();
     // Everything the last block reads from the others -- tile totals, dropped-event count, wide-record count -- was written
     // with AGENT-SCOPE ATOMICS and is read with agent-scope atomic loads: performed at the level all XCDs share, and complete
     // (vmcnt) only when they are.  Every wave has drained its own (the wait above), so the ticket needs NO release / acquire
@@ -573,6 +572,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     V2_T(11);  // totals, ticket
     V2_TEND();
     if (!is_last) return;
+    EVK_HANDOVER_ACQUIRE();
     // ---- plan: part_start, per-tile combine counters, item -> tile; totals / ticket back to 0.  A tile with more than `cap`
     //      events is cut into pieces of at most `part` events (ranges of sub-chunks).
     const int per = (ntiles + THREADS - 1) / THREADS;

@@ -496,8 +496,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
     float *mine = staging + (int64_t)blockIdx.x * cells;
     for (int c = threadIdx.x; c < cells; c += EVK_BLOCK)
         __hip_atomic_store(mine + c, (float)acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    EVK_HANDOVER_DRAIN();
     __shared__ int is_last;
     if (threadIdx.x == 0) {
         uint32_t *counter = index + IDX_COUNTER(ntiles) + tile;
@@ -507,6 +506,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_tiled(const float4 *__restr
     }
     __syncthreads();
     if (!is_last) return;
+    EVK_HANDOVER_ACQUIRE();
     const float *parts = staging + (int64_t)first_item * cells;
     flush([&](int c) {
         float sum = 0.0f;

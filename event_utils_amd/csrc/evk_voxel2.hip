@@ -627,8 +627,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         for (int c = threadIdx.x; c < cells; c += WG)
             __hip_atomic_store(mine + c, lds_cell(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    EVK_HANDOVER_DRAIN();
     __shared__ int is_last;
     if (threadIdx.x == 0) {
         uint32_t *counter = index + V2_COUNTER(ntiles) + tile;
@@ -638,6 +637,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     }
     __syncthreads();
     if (!is_last) return;
+    EVK_HANDOVER_ACQUIRE();
     const float *parts = staging + 2 * (int64_t)first_item * stride;
     if (exactq) {
         const unsigned long long *pq = reinterpret_cast<const unsigned long long *>(parts);

@@ -192,3 +192,20 @@ def test_odd_sizes_and_tiny_images(E):
             assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag)
         xi, yi, pi = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n), rng.integers(-9, 10, n)
         assert np.array_equal(E.events_to_image(xi, yi, pi, sensor_size=(H, W)), R.events_to_image(xi, yi, pi, sensor_size=(H, W)))
+
+
+def test_images_at_50m_events_720p(E):
+    """One rank's share of configs[4] as an image: 50 M events, 1280x720 -- 1020 tiles, sub-chunks of 12 K events (the
+    partition geometry above 680 tiles), 6104 segments per tile.  Integer image bit-exact, float32 nearest and bilinear
+    against the float64 oracle."""
+    rng = np.random.default_rng(17)
+    n, H, W = 50_000_000, 720, 1280
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    xi, yi, pi = x.astype(np.int64), y.astype(np.int64), p.astype(np.int64)
+    assert np.array_equal(E.events_to_image(xi, yi, pi, sensor_size=(H, W)), R.events_to_image(xi, yi, pi, sensor_size=(H, W)))
+    del xi, yi, pi
+    xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
+    for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True)):
+        ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
+        close(E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw).cpu().numpy(), ref)
