@@ -112,6 +112,13 @@ struct SrcImgI32 {
     }
 };
 
+#ifndef IMG_WG
+#define IMG_WG 512    // threads of a tile workgroup (768 and up: the chunk lists no longer fit the 64 KB of static LDS)
+#endif
+#ifndef IMG_U
+#define IMG_U 1       // chunk loads per lane group in flight (A/B, 10 M events: bilinear tile kernel 31.8 us with 1, 34.0 with 2,
+                      // 37 with 4; nearest 15.0 / 15.0 / 17.0)
+#endif
 #define IMG_FIX_ONE 1073741824.0f   // 2^30: fixed-point unit of the bilinear window (unit weights: |product| <= 1)
 
 // 16 / 8 bytes at any dword boundary (global loads need no more alignment than that)
@@ -316,7 +323,7 @@ __global__ void __launch_bounds__(WG) k_image_tiles_n(const uint32_t *__restrict
             lds_add(acc64 + local, __uint_as_float(bits));
         }
     };
-    img_records<WG, 2, RecN>(
+    img_records<WG, IMG_U, RecN>(
         table, q, it, cseg,
         [&](uint32_t pos) -> RecN {
             RecN v;
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
         }
     };
     auto run = [&](auto unit_tag) {
-        img_records<WG, 2, RecB>(
+        img_records<WG, IMG_U, RecB>(
             table, q, it, cseg,
             [&](uint32_t pos) -> RecB {
                 RecB v;
@@ -474,7 +481,6 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
 // ---- host side ------------------------------------------------------------------------------------------------------
 // One geometry for the images: 1024 threads x 8 events, sub-chunks of 8 K events (68 KB of LDS with 4-byte records,
 // 100 KB with the 12 bytes of the bilinear format).
-#define IMG_WG 512
 static inline int img_window_cells(int tw, int th) { return (tw + 1) * (th + 1); }
 
 // sub-chunks of 8 K events, or -- more than 680 tiles (720p and up): longer segments for the tile kernel -- 12 K, when the

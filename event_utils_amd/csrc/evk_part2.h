@@ -158,11 +158,16 @@ struct Part2 {
 //   handed to the column source's `rare()` -- the direct kernel's global atomics -- by this kernel itself.
 #define V2_FMT_IMGN 1
 #define V2_FMT_IMGB 12
+// REC = V2_FMT_VOX8W: the 8-byte voxel records, with the EXACT polarities of a sub-chunk staged in LDS (4 more bytes per
+// event) and written as a second dense run when one of them is wide -- instead of a scattered 4-byte store per wide
+// polarity (arbitrary float32 weights: partition 78 -> ~50 us at 10 M events).  The geometry with 8 K-event sub-chunks
+// only (100 KB of LDS; 12 K-event sub-chunks would need 147 KB), and not when the call shares its CUs with a collective.
+#define V2_FMT_VOX8W 9
 #define V2_DELTA_SHIFT 12
 #define V2_DELTA_LIMIT (1u << 20)
 #define V2_CODE_SHIFT 10
 // bytes of LDS per event of the sorted buffer
-__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : rec; }
+__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : (rec == V2_FMT_VOX8W ? 12 : rec); }
 template <int THREADS, int EPT, int REC, typename C>
 __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q, float t_first,
                                                             float t_last, float bm1, int t_from_events,
@@ -171,8 +176,10 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                             uint32_t cap, uint32_t part, uint32_t *oob, uint32_t *host_report,
                                                             uint32_t seq) {
-    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB, "record format");
-    constexpr bool VOX = REC == 8 || REC == 4;                // voxel formats: a time column, t_norm in the record
+    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_VOX8W, "record format");
+    constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
+    constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN;   // exact weights staged in LDS, dense side run on demand
+    constexpr bool VOX = R8 || REC == 4;                      // voxel formats: a time column, t_norm in the record
     constexpr int LB = v2_fmt_lds_bytes(REC);
     uint2 *const rec = static_cast<uint2 *>(rec_);            // REC 8 / IMGB: 8-byte records | REC 4 / IMGN: viewed as uint32 below
     float *const pw = static_cast<float *>(side_);            // REC 8: exact polarity at the record's index
@@ -284,14 +291,14 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     auto write_out = [&]() {   // the previous pass's run(s) of records
         if (V2_ABLATE_A >= 4) {
             const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
-            if constexpr (REC == 8 || REC == V2_FMT_IMGB)
+            if constexpr (R8 || REC == V2_FMT_IMGB)
                 store_run(src, reinterpret_cast<uint4 *>(rec + lo_prev), (int)((kept_prev + 1) >> 1));
             else
                 store_run(src, reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev), (int)((kept_prev + 3) >> 2));
             if constexpr (REC == V2_FMT_IMGB)   // the weights of the same records
                 store_run(reinterpret_cast<const uint4 *>(sortedp),
                           reinterpret_cast<uint4 *>(static_cast<uint32_t *>(side_) + lo_prev), (int)((kept_prev + 3) >> 2));
-            if constexpr (REC == V2_FMT_IMGN) {
+            if constexpr (STAGE_W) {
                 // the exact weights of the run, as a second run at the records' indices -- only when one of them does not fit
                 // its record (tmp[65], set by the placement; cleared by the next pass's scan, i.e. after every wave has been
                 // here): weights that need all 32 bits cost 4 more bytes per event, +-1 and small integers nothing
@@ -387,7 +394,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 if (base + THREADS < ntiles) lds_barrier();   // tmp is reused by the next round
             }
             if (REC == 4 && tid == 0) tmp[67] = 0;   // escapes of this pass
-            if (REC == V2_FMT_IMGN && tid == 0) tmp[65] = 0;   // wide weights of this pass
+            if (STAGE_W && tid == 0) tmp[65] = 0;   // wide weights of this pass
         }
         lds_barrier();  // cursors complete
         V2_T(3);
@@ -433,7 +440,22 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             if constexpr (V2_PLACE_BATCH) return pos_[s2];
             else return atomicAdd(&cur[kl[s2] >> V2_LB], 1u);
         };
-        if constexpr (REC == 8) {
+        if constexpr (REC == V2_FMT_VOX8W) {
+            bool any_wide = false;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                if (kl[s2] != 0xFFFFFFFFu) {
+                    const uint32_t pos = slot_of(s2);
+                    const uint32_t pbits = __float_as_uint(c.p_of(tpr + C::TPW * (s2 / G), s2 % G));
+                    const bool wide = ((pbits & ~V2_P_MASK) != 0u) | ((pbits & 0x7F800000u) == 0x7F800000u);
+                    nwide += ((((pbits & 0x7FFFFFFFu) == 0x3F800000u) | (pbits == 0u)) ? 0u : 0x10000u) + (wide ? 1u : 0u);
+                    sorted[pos] = make_uint2(__float_as_uint(tv[s2]), (wide ? V2_WIDE : (pbits & V2_P_MASK)) | (kl[s2] & V2_LOCAL_MASK));
+                    sortedp[pos] = pbits;
+                    any_wide |= wide;
+                }
+            }
+            if (any_wide) tmp[65] = 1u;   // (every writer stores the same value)
+        } else if constexpr (REC == 8) {
             uint32_t wide_mask = 0;
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {

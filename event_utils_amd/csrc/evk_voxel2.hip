@@ -746,6 +746,15 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     const int recb = v2_rec_bytes(n, flags);
     if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
+        // (8-byte records in the 8 K-event geometry of a call that has its CUs to itself: the exact polarities are staged in
+        // LDS and wide ones leave as a dense run -- V2_FMT_VOX8W, evk_part2.h)
+#ifndef V2_USE_VOX8W
+#define V2_USE_VOX8W 1   // (A/B)
+#endif
+        if (V2_USE_VOX8W && recb == 8 && cfg.threads == 1024 && cfg.ept == 8 && !share) {
+            launch_part<1024, 8, V2_FMT_VOX8W>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, bases, table, index, oob,
+                                               host_report, seq, s);
+        } else {
 #define X(T, E)                                                                                                              \
     if (cfg.threads == T && cfg.ept == E) {                                                                                  \
         if (recb == 4)                                                                                                       \
@@ -753,8 +762,9 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         else                                                                                                                 \
             launch_part<T, E, 8>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, bases, table, index, oob, host_report, seq, s); \
     }
-        V2_GEOMETRIES(X)
+            V2_GEOMETRIES(X)
 #undef X
+        }
     }
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int items = v2_max_items(n, ntiles);
