@@ -37,10 +37,12 @@ struct SrcImgF32 {
     float clipx, clipy;
     float *img;   // (h, wd): the rare path of the bilinear format adds to it directly
     int h, wd;
+    template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
         const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
+    template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
         const uint4 a = reinterpret_cast<const uint4 *>(w + ev0)[gl];
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
@@ -91,10 +93,12 @@ struct SrcImgF32 {
 struct SrcImgI32 {
     static constexpr int G = 4, XYW = 8, TPW = 4;
     const int32_t *x, *y, *w;
+    template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
         const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
+    template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
         uint4 a = make_uint4(1u, 1u, 1u, 1u);
         if (w) a = reinterpret_cast<const uint4 *>(w + ev0)[gl];

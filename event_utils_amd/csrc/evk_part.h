@@ -86,15 +86,30 @@ __device__ __forceinline__ float time_norm(float t, const TimeNorm &k) { return 
 // load site -- int16 -> float, (float)(t - t_offset) in float64, {0,1} -> -1/+1, as round 2 did -- makes the compiler wait
 // for the data right behind the load instruction: the loads then overlap nothing, which is why the 13 B/event path was
 // slower than the 16 B/event one.
+// NT: nontemporal loads.  The columns of a call beyond the Infinity Cache (the 4-byte-record calls, > 16 M events) are read
+// once and need not displace the records in L2 / MALL: 50 M events 0.340 -> 0.335 ms, 10 M events from HBM 0.0730 -> 0.0711
+// (tools/ab.sh, ROTATE=1); a 10 M-event stream that IS cache-resident loses what it had (0.0686 -> 0.0715): plain loads there.
+typedef uint32_t evk_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 load_col16(const float *col, int64_t ev0, uint32_t gl) {
+    if constexpr (NT) {
+        const evk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const evk_u32x4 *>(col + ev0) + gl);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return reinterpret_cast<const uint4 *>(col + ev0)[gl];
+    }
+}
 struct SrcF32 {  // four float32 SoA columns, 16 B / event
     static constexpr int G = 4, XYW = 8, TPW = 8;
     const float *x, *y, *t, *p;
+    template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        const uint4 a = load_col16<NT>(x, ev0, gl), b = load_col16<NT>(y, ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
+    template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(t + ev0)[gl], b = reinterpret_cast<const uint4 *>(p + ev0)[gl];
+        const uint4 a = load_col16<NT>(t, ev0, gl), b = load_col16<NT>(p, ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
     __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
@@ -118,6 +133,7 @@ struct SrcNative {
     const uint8_t *p;
     double t_offset;
     int xy_stride, p_kind;
+    template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
         if (xy_stride == 2) {   // x0 y0 | x1 y1 | x2 y2 | x3 y3
             const uint4 w = reinterpret_cast<const uint4 *>(x + 2 * ev0)[gl];
@@ -127,6 +143,7 @@ struct SrcNative {
             r[0] = a.x, r[1] = a.y, r[2] = b.x, r[3] = b.y;
         }
     }
+    template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
         if constexpr (T64) {    // two 16-byte loads, issued together
             const uint4 a = reinterpret_cast<const uint4 *>(static_cast<const double *>(t) + ev0)[2 * gl];

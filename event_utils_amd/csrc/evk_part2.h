@@ -240,11 +240,11 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t rare = 0;        // IMGB: events of this pass that go to the column source's rare() (bit = event of the thread)
     auto load_xy = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NG; ++k) c.load_xy(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
+        for (int k = 0; k < NG; ++k) c.template load_xy<REC == 4>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
     };
     auto load_tp = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NG; ++k) c.load_tp(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
+        for (int k = 0; k < NG; ++k) c.template load_tp<REC == 4>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
         if constexpr (REC == 4) tb = c.t1((int64_t)sc * q.S);   // base of the t_norm deltas (same address in every lane)
     };
     auto fence = [&]() {   // for the compiler: loads hoisted above a compute phase keep their 2 * EPT registers live through it

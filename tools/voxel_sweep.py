@@ -83,8 +83,14 @@ def scene(kind, n, H, W):
 def timing(n, H, W, B, reps=20, paths=("v2",), kind="uniform"):
     x, y, t, p = synth(1, n, H, W) if kind == "uniform" else scene(kind, n, H, W)
     cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
+    sets = [cols]
+    if "--rotate" in sys.argv and kind == "uniform":      # 4 distinct streams: every call reads its events from HBM
+        for k in range(1, 4):
+            xs, ys, ts_, ps = synth(1000 * k + 1, n, H, W)
+            ts_[0], ts_[-1] = t[0], t[-1]
+            sets.append([torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (xs, ys, ts_, ps)])
     for path in paths:
-        k = tiled.time_voxel_kernels([cols], float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
+        k = tiled.time_voxel_kernels(sets, float(t[0]), float(t[-1]), B, H, W, impl="tiled", reps=reps)
         alg = 16.0 * n + B * H * W * 4
         print("%s %-7s n=%d %dx%dx%d: total %.4f ms (%.1f Gev/s, whole-call frac %.3f)  %s  [%s]" % (
             path, kind, n, H, W, B, k["total_ms"], n / k["total_ms"] / 1e6, alg / (k["total_ms"] * 1e-3) / 8e12,
