@@ -39,12 +39,12 @@ struct SrcImgF32 {
     int h, wd;
     template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        const uint4 a = load_col16<NT>(reinterpret_cast<const float *>(x), ev0, gl), b = load_col16<NT>(reinterpret_cast<const float *>(y), ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
     template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(w + ev0)[gl];
+        const uint4 a = load_col16<NT>(w, ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
     }
     __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
@@ -95,13 +95,13 @@ struct SrcImgI32 {
     const int32_t *x, *y, *w;
     template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a = reinterpret_cast<const uint4 *>(x + ev0)[gl], b = reinterpret_cast<const uint4 *>(y + ev0)[gl];
+        const uint4 a = load_col16<NT>(reinterpret_cast<const float *>(x), ev0, gl), b = load_col16<NT>(reinterpret_cast<const float *>(y), ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
     }
     template <bool NT = false>
     __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
         uint4 a = make_uint4(1u, 1u, 1u, 1u);
-        if (w) a = reinterpret_cast<const uint4 *>(w + ev0)[gl];
+        if (w) a = load_col16<NT>(reinterpret_cast<const float *>(w), ev0, gl);
         r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
     }
     __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {

@@ -86,9 +86,10 @@ __device__ __forceinline__ float time_norm(float t, const TimeNorm &k) { return 
 // load site -- int16 -> float, (float)(t - t_offset) in float64, {0,1} -> -1/+1, as round 2 did -- makes the compiler wait
 // for the data right behind the load instruction: the loads then overlap nothing, which is why the 13 B/event path was
 // slower than the 16 B/event one.
-// NT: nontemporal loads.  The columns of a call beyond the Infinity Cache (the 4-byte-record calls, > 16 M events) are read
-// once and need not displace the records in L2 / MALL: 50 M events 0.340 -> 0.335 ms, 10 M events from HBM 0.0730 -> 0.0711
-// (tools/ab.sh, ROTATE=1); a 10 M-event stream that IS cache-resident loses what it had (0.0686 -> 0.0715): plain loads there.
+// NT: nontemporal loads.  A call reads its event columns ONCE; loaded with the nontemporal hint they do not displace the
+// records the partition writes (and the tile kernel reads back) in L2 / MALL: 10 M events from HBM 0.0730 -> 0.0711 ms, 50 M events
+// 0.340 -> 0.335 ms (tools/ab.sh, ROTATE=1).  Only a loop that re-reads ONE cache-sized stream call after call -- rounds 1-3's
+// bench -- is slower with it (0.0686 -> 0.0715 ms: the columns no longer survive in the Infinity Cache from call to call).
 typedef uint32_t evk_u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ uint4 load_col16(const float *col, int64_t ev0, uint32_t gl) {

@@ -43,6 +43,9 @@ namespace evk {
 #ifndef V2_XY_PREFETCH
 #define V2_XY_PREFETCH 1   // load x, y of sub-chunk j + 1 before the placement of j (else at the top of j + 1)
 #endif
+#ifndef V2_NT_COLUMNS
+#define V2_NT_COLUMNS true   // (A/B) nontemporal loads of the event columns (evk_part.h, load_col16)
+#endif
 #ifndef V2_PLACE_BATCH
 #define V2_PLACE_BATCH 1   // (A/B) the placement's returning LDS atomics all issued before the first record is built
 #endif
@@ -240,11 +243,11 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t rare = 0;        // IMGB: events of this pass that go to the column source's rare() (bit = event of the thread)
     auto load_xy = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NG; ++k) c.template load_xy<REC == 4>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
+        for (int k = 0; k < NG; ++k) c.template load_xy<V2_NT_COLUMNS>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, xyr + C::XYW * k);
     };
     auto load_tp = [&](int sc) {
 #pragma unroll
-        for (int k = 0; k < NG; ++k) c.template load_tp<REC == 4>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
+        for (int k = 0; k < NG; ++k) c.template load_tp<V2_NT_COLUMNS>(row_base(sc, k), valid_in(sc, k) > 0 ? (uint32_t)tl_ : 0u, tpr + C::TPW * k);
         if constexpr (REC == 4) tb = c.t1((int64_t)sc * q.S);   // base of the t_norm deltas (same address in every lane)
     };
     auto fence = [&]() {   // for the compiler: loads hoisted above a compute phase keep their 2 * EPT registers live through it

@@ -3,6 +3,6 @@
 for i in 1 2; do
   for name in "$@"; do
     lib=tools/exp/libevk_$name.so; [ "$name" = default ] && lib=event_utils_amd/csrc/libevk.so
-    echo "== $name"; EVK_LIB_PATH=$PWD/$lib python tools/image2_time.py 2>&1 | grep "n= 10000000" | grep "int32\|bilinear unit" | cut -c1-150
+    echo "== $name"; EVK_LIB_PATH=$PWD/$lib python tools/image2_time.py ${ROTATE:+--rotate} 2>&1 | grep "n= 10000000" | grep "int32\|bilinear unit" | cut -c1-150
   done
 done

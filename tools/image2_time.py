@@ -28,13 +28,19 @@ def run(n, H, W, scene="uniform", reps=20):
     xd, yd, pud, pfd = (torch.from_numpy(a).cuda() for a in (x, y, pu, pf))
     xi, yi, pi = xd.int(), yd.int(), pud.int()
     out = {}
+    rot = 4 if "--rotate" in sys.argv else 1      # 4 copies of the columns: every call reads its events from HBM
     for name, kind, cols, dt in (("int32 nearest", "i32", (xi, yi, pi), torch.int32),
                                  ("f32 nearest unit", "f32", (xd, yd, pud), torch.float32),
                                  ("f32 nearest float", "f32", (xd, yd, pfd), torch.float32),
                                  ("bilinear unit", "bilinear", (xd, yd, pud), torch.float32),
                                  ("bilinear float", "bilinear", (xd, yd, pfd), torch.float32)):
         img = torch.zeros((H, W), dtype=dt, device="cuda")
-        call = lambda stage=0: tiled.image2(kind, *cols, n, H, W, INF, INF, img, None, fresh=False, stage=stage)
+        copies = [cols] + [tuple(c.clone() for c in cols) for _ in range(rot - 1)]
+        it = [0]
+
+        def call(stage=0, copies=copies, it=it, kind=kind, img=img):
+            it[0] += 1
+            return tiled.image2(kind, *copies[it[0] % len(copies)], n, H, W, INF, INF, img, None, fresh=False, stage=stage)
         assert call()
         total = tiled._time_ms(call, reps)
         part = tiled._time_ms(lambda: call(_lib.EVK_VOXEL2_PARTITION_ONLY), reps)
