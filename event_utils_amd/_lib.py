@@ -101,6 +101,8 @@ _SPECIAL = {
     "evk_voxel2_index_len": ([c_int, c_int64], c_int64),
     "evk_voxel2_scratch_bytes": ([c_int, c_int64, c_int, c_int, c_int], c_int64),
     "evk_voxel2_num_tiles": ([c_int, c_int, c_int, c_int], c_int),
+    "evk_voxel2_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "evk_num_cu": ([], c_int),
     "evk_image2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
 }
 

@@ -687,6 +687,25 @@ extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
     return g.tiles_x * g.tiles_y;
 }
 
+// LDS of a tile workgroup with `planes` float64 accumulator planes: the accumulators + the chunk lists (512 threads, either
+// record size); the limit voxel2() enforces
+static size_t v2_tiles_lds(const TileGridG &g, int planes) {
+    return (size_t)planes * sizeof(acc_t) * g.pitch * g.th + 12 * 8 * V2_CHUNK_CAP(512) + 64;
+}
+#define V2_TILES_LDS_LIMIT (150 * 1024)
+
+// 1 when evk_voxel2_f32 takes this tiling with `planes` accumulator planes (B, or 2 B with EVK_VOXEL_SPLIT_POLARITY): the
+// grid is valid, the partition's and the tile kernel's LDS fit, the tile count is within evk_voxel2_max_tiles().  What a
+// caller's tile search asks instead of restating the kernels' constants.
+extern "C" int evk_voxel2_fits(int h, int wd, int tile_w, int tile_h, int planes) {
+    TileGridG g;
+    if (planes <= 0 || make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK) return 0;
+    const int ntiles = evk_voxel2_num_tiles(h, wd, tile_w, tile_h);
+    if (ntiles <= 0 || ntiles > evk_voxel2_max_tiles()) return 0;
+    return v2_tiles_lds(g, planes) <= (size_t)V2_TILES_LDS_LIMIT ? 1 : 0;
+}
+extern "C" int evk_num_cu(void) { return EVK_NUM_CU; }
+
 // largest tile count the partition kernel's LDS holds (sorted records + one uint32 per tile)
 extern "C" int evk_voxel2_max_tiles(void) {
     const int64_t budget = (int64_t)V2_LDS_LIMIT - (int64_t)1024 * 12 * 8 - 1024;   // the larger shipped geometry
@@ -729,8 +748,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     if (ntiles > evk_voxel2_max_tiles() || !evk_voxel2_num_tiles(h, wd, tile_w, tile_h)) return EVK_EINVAL;
     const int planes = (flags & EVK_VOXEL_SPLIT_POLARITY) ? 2 * B : B;
     const size_t lds_acc = (size_t)planes * sizeof(acc_t) * g.pitch * g.th;  // odd row pitch
-    const size_t lds_static = 12 * 8 * V2_CHUNK_CAP(512) + 64;             // the tile kernel's chunk lists (512 threads, either record size)
-    if (lds_acc + lds_static > 150 * 1024) return EVK_EINVAL;
+    if (v2_tiles_lds(g, planes) > (size_t)V2_TILES_LDS_LIMIT) return EVK_EINVAL;
     const bool share = flags & EVK_VOXEL2_SHARE_CU;
     const V2Layout L = v2_layout(ntiles, n, planes, tile_w, tile_h, share);
     if (scratch_bytes < L.total) return EVK_ESCRATCH;

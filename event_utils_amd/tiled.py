@@ -161,41 +161,38 @@ def voxel_deterministic():
     return os.environ.get("EVK_VOXEL_DETERMINISTIC", "0") == "1"
 
 
-_NUM_CU = 256
-_TILE_LIST_BYTES = 12 * 448 * 8 + 64     # the tile kernel's chunk lists (static LDS, 512 threads; 4-byte records: + a base per entry)
 _shape_cache = {}
 
 
 def voxel2_shape(H, W, planes):
-    """Tile size (width, height in PIXELS) for the one-pass voxel path, or None when it does not apply.
+    """Tile size (width, height in PIXELS) for the one-pass voxel / event-image path, or None when it does not apply.
     The tile kernel runs one workgroup per tile and a launch lasts as long as its busiest CU, so the tiling is chosen to
     minimise (tiles per CU, rounded up) x (pixels per tile): 640x480 -> 512 tiles of 40x15 (2 per CU, against 600 tiles
-    of 32x16 = 3 on 88 CUs and 2 on the rest: -17 % measured), 1280x720 -> 1024 tiles of 40x23.  Constraints: the
-    accumulator cell index (row * (width | 1) + column) has 10 bits; B planes of float64 cells plus the chunk lists must
-    fit the LDS; at most evk_voxel2_max_tiles() tiles.  Small penalties prefer fewer tiles (longer record segments),
-    all tiles resident at once (<= 3 workgroups per CU) and wide tiles (rows are contiguous in the grid)."""
+    of 32x16 = 3 on 88 CUs and 2 on the rest: -17 % measured), 1280x720 -> 1020 tiles of 38x24.  Which tilings the kernels
+    take -- the 10-bit cell index, the LDS of the partition and of the tile kernel, the tile count -- is the LIBRARY's
+    answer (evk_voxel2_fits); only the preferences are here: fewer tiles (longer record segments), all tiles resident at
+    once (<= 3 workgroups per CU) and wide tiles (rows are contiguous in the grid)."""
     key = (H, W, planes, FORCE.get("tile"))
     if key in _shape_cache:
         return _shape_cache[key]
     L = _lib.lib()
-    max_tiles = L.evk_voxel2_max_tiles()
+    ncu = L.evk_num_cu()
     best = None
     if FORCE.get("tile"):            # (tests: an explicit tile size)
         a, b = FORCE["tile"]
-        if 0 < L.evk_voxel2_num_tiles(H, W, a, b) <= max_tiles and planes * 8 * (a | 1) * b + _TILE_LIST_BYTES <= 150 * 1024:
+        if L.evk_voxel2_fits(H, W, a, b, planes):
             best = (0.0, a, b)
     else:
         for tw in range(8, 129):
             for th in range(4, 129):
-                cells = (tw | 1) * th
-                lds = planes * 8 * cells + _TILE_LIST_BYTES
-                if cells > 1024 or lds > 150 * 1024:
+                if (tw | 1) * th > 1024:
                     break
-                T = L.evk_voxel2_num_tiles(H, W, tw, th)      # 0: the library cannot take this tiling
-                if T <= 0 or T > max_tiles:
+                if not L.evk_voxel2_fits(H, W, tw, th, planes):
                     continue
+                T = L.evk_voxel2_num_tiles(H, W, tw, th)
+                lds = planes * 8 * (tw | 1) * th + 43 * 1024          # (accumulators + chunk lists: residency estimate only)
                 resident = min(3, (160 * 1024) // lds)
-                per_cu = -(-T // _NUM_CU)
+                per_cu = -(-T // ncu)
                 cost = per_cu * tw * th * (1.0 + T / 20000.0) * (1.0 + 0.08 * max(0, -(-per_cu // resident) - 1)) \
                     * (1.0 + 0.02 * (th > tw)) * (1.0 + 0.01 * max(0.0, tw / th - 4.0))
                 if best is None or cost < best[0]:

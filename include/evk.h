@@ -351,6 +351,11 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 int evk_voxel2_max_tiles(void);
 int64_t evk_voxel2_index_len(int ntiles, int64_t n);
 int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h);   /* 0 = this tiling is not supported */
+/* 1 when evk_voxel2_f32 takes this tiling with `planes` accumulator planes (B; 2 B with EVK_VOXEL_SPLIT_POLARITY; 1 for the
+ * event images): grid, partition LDS, tile-kernel LDS and tile count all fit.  evk_num_cu(): the CU count the tile count
+ * should be a multiple of (256 on MI355X). */
+int evk_voxel2_fits(int h, int wd, int tile_w, int tile_h, int planes);
+int evk_num_cu(void);
 int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tile_w, int tile_h);
 int evk_voxel2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
                    int tile_w, int tile_h, float t_first, float t_last, int B, int flags, float *vox,
