@@ -22,4 +22,20 @@ for rec in ("8", "4"):
                 if not torch.equal(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)), first):
                     bad += 1
             print(rec, kind, n, "mismatches so far", bad, flush=True)
+# the event images (evk_image2.hip): integer image (int32 partial tiles) and unit-weight nearest image, cut tiles on the blob scene
+tiled.FORCE["rec"] = None
+os.environ["EVK_IMPL"] = "tiled"
+for n in (3_000_000, 11_000_000):
+    x, y, t, p = [np.ascontiguousarray(a) for a in V.scene("blob", n, H, W)]
+    xi, yi, pi = x.astype(np.int64), y.astype(np.int64), p.astype(np.int64)
+    xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
+    first_i = E.events_to_image(xi, yi, pi, sensor_size=(H, W))
+    first_f = E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), interpolation=None, padding=False)
+    for i in range(100):
+        if i % 7 == 0: filler.random_(0, 255)
+        if i % 10 == 0 and not np.array_equal(E.events_to_image(xi, yi, pi, sensor_size=(H, W)), first_i):
+            bad += 1
+        if not torch.equal(E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), interpolation=None, padding=False), first_f):
+            bad += 1
+    print("image blob", n, "mismatches so far", bad, flush=True)
 print("SOAK", "FAILED" if bad else "ok")
