@@ -395,14 +395,18 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
     const int ntiles = g.tiles_x * g.tiles_y;
     ImgItem it;
     if (!img_item(index, ntiles, q, flags, it)) return;
-    const bool unit = !(flags & EVK_IMAGE2_NO_FIXED) && index[7] == 0u;
+    const bool has_side = index[7] != 0u;   // the call has weights other than +-1 / +0: their records point to the side runs
+    const bool unit = !(flags & EVK_IMAGE2_NO_FIXED) && !has_side;
     const int tw = g.tw, th = g.th;
     const int ww = tw + 1, wh = th + 1, wpitch = ww | 1, wcells = wpitch * wh;   // odd pitch (evk_part.h)
     for (int i = threadIdx.x; i < wcells; i += WG) win[i] = 0.0;
     unsigned long long *const winq = reinterpret_cast<unsigned long long *>(win);
-    auto one = [&](auto unit_tag, uint32_t xb, uint32_t yb, uint32_t wb) {
+    auto one = [&](auto unit_tag, uint32_t xb, uint32_t yb, uint32_t wside) {
         constexpr bool UNIT = decltype(unit_tag)::value;
-        const float xr = __uint_as_float(xb), yr = __uint_as_float(yb);
+        // the weight's code in the two sign bits: 0 / 1 / 2 = +1.0 / -1.0 / +0.0, 3 = the side run's value
+        const uint32_t code = (xb >> 31) | ((yb >> 31) << 1);
+        const uint32_t wb = code == 3u ? wside : (code == 2u ? 0u : (0x3F800000u | (code << 31)));
+        const float xr = __uint_as_float(xb & 0x7FFFFFFFu), yr = __uint_as_float(yb & 0x7FFFFFFFu);
         const float fx = floorf(xr), fy = floorf(yr);
         const float dx = xr - fx, dy = yr - fy;                  // = x - floor(x), y - floor(y) (image.py:81-82), exactly
         const float ax = 1.0f - dx, ay = 1.0f - dy;
@@ -429,7 +433,8 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
             table, q, it, cseg,
             [&](uint32_t pos) -> RecB {
                 RecB v;
-                v.r = load_u4(rec + pos), v.w = load_u2(side + pos);
+                v.r = load_u4(rec + pos);
+                v.w = has_side ? load_u2(side + pos) : make_uint2(0u, 0u);
                 return v;
             },
             [&](const RecB &v, uint32_t pos, uint32_t end) {

@@ -155,8 +155,10 @@ struct Part2 {
 //   a wide weight goes, exactly, to the side array at the record's index.  12 B/event read, 4 written.
 // REC = V2_FMT_IMGB (bilinear splat, image.py:79-86,102-115): the record run holds {x - tile x0, y - tile y0} as float32
 //   (8 bytes: both differences are EXACT -- multiples of ulp(x) below x -- and so are the fractions and the pixel inside the
-//   tile taken from them: floor(x - x0) = floor(x) - x0), the side run the weight's float32 bits at the record's index
-//   (4 bytes, always).  12 B/event read, 12 written; nothing is quantised and nothing escapes.  Events the splat cannot take
+//   tile taken from them: floor(x - x0) = floor(x) - x0).  Both are non-negative, so their two SIGN bits carry the weight's
+//   code -- 0 / 1 / 2 = +1.0 / -1.0 / +0.0, 3 = another value, found in the side run (the exact float32 weights of the
+//   sub-chunk at the records' indices, written only when one of them is not +-1 / +0, as for IMGN).  12 B/event read, 8
+//   written (12 with arbitrary weights); nothing is quantised.  Events the splat cannot take
 //   from an LDS window (negative or out-of-range pixels, which wrap or raise in index_put_; non-finite coordinates) are
 //   handed to the column source's `rare()` -- the direct kernel's global atomics -- by this kernel itself.
 #define V2_FMT_IMGN 1
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                                                             uint32_t seq) {
     static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_VOX8W, "record format");
     constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
-    constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN;   // exact weights staged in LDS, dense side run on demand
+    constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB;   // exact weights staged in LDS, dense side run on demand
     constexpr bool VOX = R8 || REC == 4;                      // voxel formats: a time column, t_norm in the record
     constexpr int LB = v2_fmt_lds_bytes(REC);
     uint2 *const rec = static_cast<uint2 *>(rec_);            // REC 8 / IMGB: 8-byte records | REC 4 / IMGN: viewed as uint32 below
@@ -298,9 +300,6 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 store_run(src, reinterpret_cast<uint4 *>(rec + lo_prev), (int)((kept_prev + 1) >> 1));
             else
                 store_run(src, reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev), (int)((kept_prev + 3) >> 2));
-            if constexpr (REC == V2_FMT_IMGB)   // the weights of the same records
-                store_run(reinterpret_cast<const uint4 *>(sortedp),
-                          reinterpret_cast<uint4 *>(static_cast<uint32_t *>(side_) + lo_prev), (int)((kept_prev + 3) >> 2));
             if constexpr (STAGE_W) {
                 // the exact weights of the run, as a second run at the records' indices -- only when one of them does not fit
                 // its record (tmp[65], set by the placement; cleared by the next pass's scan, i.e. after every wave has been
@@ -493,17 +492,23 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             }
             if (any_wide) tmp[65] = 1u;   // (every writer stores the same value)
         } else if constexpr (REC == V2_FMT_IMGB) {
+            bool any_b = false;
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {
                 if (kl[s2] != 0xFFFFFFFFu) {
                     const uint32_t pos = slot_of(s2);
-                    bool wide, unit;
-                    (void)c.payload(tpr + C::TPW * (s2 / G), s2 % G, wide, unit);
-                    nwide += unit ? 0u : 0x10000u;
-                    sorted[pos] = make_uint2(__float_as_uint(xr[s2]), __float_as_uint(yr[s2]));
-                    sortedp[pos] = c.w_bits(tpr + C::TPW * (s2 / G), s2 % G);
+                    const uint32_t wb = c.w_bits(tpr + C::TPW * (s2 / G), s2 % G);
+                    // +1.0 -> 0, -1.0 -> 1, +0.0 -> 2, anything else -> 3 (in the sign bits of the two coordinates, which are >= 0;
+                    // a -0.0 coordinate is stored as +0.0: the same pixel, the same fractions)
+                    const uint32_t code = (wb & 0x7FFFFFFFu) == 0x3F800000u ? wb >> 31 : 3u - (uint32_t)(wb == 0u);
+                    nwide += code == 3u ? 0x10001u : 0u;
+                    sorted[pos] = make_uint2((__float_as_uint(xr[s2]) & 0x7FFFFFFFu) | (code << 31),
+                                             (__float_as_uint(yr[s2]) & 0x7FFFFFFFu) | ((code >> 1) << 31));
+                    sortedp[pos] = wb;
+                    any_b |= code == 3u;
                 }
             }
+            if (any_b) tmp[65] = 1u;   // (every writer stores the same value)
             if (__any(rare != 0u)) {   // rare: pixels that wrap or raise in index_put_ -- the direct kernel's global atomics
 #pragma unroll
                 for (int s2 = 0; s2 < EPT; ++s2)
