@@ -24,7 +24,7 @@ int evk_post_variance_publish(int mode, const float *iwe, const float *diwe, int
 // Results to the host.  The finalise kernel stores them in a pinned slot and then a sequence number (system scope); the
 // host polls that flag: no copy command, no stream synchronisation (their completion signal + wake-up cost ~15 us per
 // evaluation, a fifth of a 10 M-event evaluation).  Every 16 K polls the stream is queried so that a failed launch
-// cannot hang the caller.  EVK_CMAX_POLL=0 (or a post-pass that cannot publish) takes the copy + synchronise route.
+// cannot hang the caller.  A post-pass that cannot publish takes the copy + synchronise route.
 // (Letting the post-pass kernel finalise as well -- last workgroup of a plane by ticket, one launch less -- is SLOWER, with
 // or without fences: round 2, an agent-scope release per workgroup: 69.9 vs 66.6 us per 10 M-event evaluation; round 3, the
 // partial sums handed over with agent-scope stores and loads and a relaxed ticket, no fence: 70.1 vs 65.6 us -- every

@@ -115,7 +115,7 @@ def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_
     # Above the crossover: one-pass partition + LDS tiles (evk_image2.hip); below it, or for columns it cannot take
     # (unaligned views), one global atomic per contribution (evk_scatter.hip).  Same semantics either way.
     img = None
-    if tiled.can_tile_image((xd, yd, pd), tiled.default_impl()) and xd.shape == pd.shape:
+    if tiled.can_tile_image((xd, yd, pd), tiled.default_impl(), bilinear) and xd.shape == pd.shape:
         fresh = (not bilinear) and float(default) == 0.0
         if fresh:           # every pixel is written: no memset
             img = torch.empty(tuple(img_size), dtype=torch.float32, device=dev)

@@ -293,9 +293,11 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
                              "accumulated in fixed point" % bad)
 
 
-# 'auto' threshold of the event images (evk_image2.hip): below it the two launches of the one-pass path cost more than
-# one global atomic (nearest) or four (bilinear) per event at ~21 G/s
-TILED_MIN_EVENTS_IMAGE = 250_000
+# 'auto' thresholds of the event images (evk_image2.hip): below them the two launches of the one-pass path (~15 / ~18 us
+# whatever the event count) cost more than one global atomic (nearest) or four (bilinear) per event at ~21 G/s -- measured,
+# profiles/r04_image_crossover.txt: nearest 17 us direct at 400 k events, bilinear 24 us at 100 k
+TILED_MIN_EVENTS_IMAGE = 320_000
+TILED_MIN_EVENTS_IMAGE_BILINEAR = 80_000
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
@@ -336,7 +338,7 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     return True
 
 
-def can_tile_image(cols, impl):
+def can_tile_image(cols, impl, bilinear=False):
     """Preconditions of the one-pass image path: contiguous, 16-byte aligned 4-byte columns and, under 'auto', enough
     events to amortise its two launches."""
     n = cols[0].shape[0]
@@ -344,7 +346,7 @@ def can_tile_image(cols, impl):
         return False
     if not all(c is None or (c.element_size() == 4 and c.is_contiguous() and c.data_ptr() % 16 == 0) for c in cols):
         return False
-    return impl == "tiled" or n >= TILED_MIN_EVENTS_IMAGE
+    return impl == "tiled" or n >= (TILED_MIN_EVENTS_IMAGE_BILINEAR if bilinear else TILED_MIN_EVENTS_IMAGE)
 
 
 def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
