@@ -57,7 +57,6 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // REC 8: a lane takes 16 bytes = 2 records {t_norm, polarity | cell}; REC 4: 8 bytes = 2 one-word records (k_part_sorted),
     // decoded with the base of their sub-chunk, which travels with the chunk list
     typedef typename std::conditional<REC == 8, uint4, uint2>::type Pair;
-    const Pair *const recp = static_cast<const Pair *>(rec_);           // indexed in PAIRS of records
     const float *const pw = static_cast<const float *>(side_);
     const uint2 *const wide2 = static_cast<const uint2 *>(side_);
     const int overwrite = flags & EVK_VOXEL_OVERWRITE;
@@ -280,7 +279,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // record, not at the 16-byte boundary below it (global loads need no more than dword alignment; with aligned chunks the
     // first one of every other segment began with a record of the neighbouring tile: one lane idle and a test per pair)
     typedef typename std::conditional<REC == 8, uint2, uint32_t>::type Rec1;
-    struct __attribute__((packed, aligned(REC))) PairU {
+    struct PairU {         // NOT packed: the compiler may assume the natural alignment it does not have (the hardware does not care)
         Pair v;
     };
     auto load_pair = [&](uint32_t pos) -> Pair { return reinterpret_cast<const PairU *>(static_cast<const Rec1 *>(rec_) + pos)->v; };
@@ -399,7 +398,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             auto mych_of = [&](int e) { return (packed >> (4 * e)) & 15u; };
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const uint32_t start = ent[e] & 0xFFFFu, cnt = ent[e] >> 16;
+                const uint32_t cnt = ent[e] >> 16;
                 const uint32_t nch = (cnt + 7u) >> 3;
                 const bool is_long = nch > (uint32_t)V2_MAX_CHUNKS(WG);
                 packed |= (is_long ? 0u : nch) << (4 * e);
