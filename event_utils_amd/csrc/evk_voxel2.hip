@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         if (threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
     } else {
         for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
+        if (FIXED && threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
     }
     V2_U(1);
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
@@ -156,6 +157,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // EVERY bin, as in the reference -- its p * weight is added for all B bins, and NaN * 0 = inf * 0 = NaN
     auto bins_general = [&](acc_t *base, int local, float tn, float p) {
         if (tn != tn) {
+            if constexpr (FIXED) {   // no NaN among integers: one bit per cell, as in the counting mode (both grids of a split call)
+                __hip_atomic_fetch_or(poison + (local >> 5), 1u << (local & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
             for (int b = 0; b < B; ++b) add(base + b * ppix + local, tn * p);
             return;
         }
@@ -582,7 +587,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             return (float)((double)v * (1.0 / G_ONE));
         }
         const acc_t a = acc[b * ppix + l];
-        if constexpr (FIXED) return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V2_FIXED_ONE));
+        if constexpr (FIXED) {
+            if ((poison[l >> 5] >> (l & 31)) & 1u) return __uint_as_float(0x7FC00000u);
+            return (float)((double)__builtin_bit_cast(long long, a) * (1.0 / V2_FIXED_ONE));
+        }
         return (float)a;
     };
     if (nparts == 1) {
@@ -615,6 +623,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             if ((poison[l >> 5] >> (l & 31)) & 1u) return (long long)0x8000000000000000ull;
             return ((long long)s0[b * ppix + l] << 31) - (long long)gq[(b + 1) * ppix + l] + (long long)gq[b * ppix + l];
         }
+        if (FIXED && ((poison[l >> 5] >> (l & 31)) & 1u)) return (long long)0x8000000000000000ull;
         return __builtin_bit_cast(long long, acc[b * ppix + l]);
     };
     float *mine = staging + 2 * (int64_t)item * stride;

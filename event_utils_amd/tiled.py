@@ -157,7 +157,8 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
 
 def voxel_deterministic():
     """EVK_VOXEL_DETERMINISTIC=1: the tile kernel of the one-pass path accumulates 64-bit fixed point (order-free integer
-    adds) instead of float64 -- bit-identical grids from run to run.  One synchronisation per call (range check)."""
+    adds) instead of float64 -- bit-identical grids from run to run and for any order of the events.  Such a call takes the
+    one-pass path at any event count (voxel_f32) and costs one synchronisation (range check)."""
     return os.environ.get("EVK_VOXEL_DETERMINISTIC", "0") == "1"
 
 
@@ -371,6 +372,15 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     native = events.NativeColumns: the tiled path buckets the on-disk dtypes directly (xd..pd may then be callables
     producing the widened float32 columns, only called when the direct kernel has to take over)."""
     impl = impl or default_impl()
+    det = voxel_deterministic()
+    if det:
+        # the integer tile kernel belongs to the one-pass path: the call takes it at ANY event count (the direct kernel adds
+        # float32 atomics in whatever order they arrive), after copying columns that path cannot read in place
+        if impl == "direct":
+            raise ValueError("EVK_VOXEL_DETERMINISTIC=1 needs the one-pass path; EVK_IMPL=direct selects the float-atomic kernels")
+        impl = "tiled"
+        if native is None:
+            xd, yd, td, pd = (c if c.data_ptr() % 16 == 0 else c.clone() for c in (c.contiguous() for c in (xd, yd, td, pd)))
     if native is not None:
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
     else:
@@ -381,6 +391,9 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
             voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
                    out, oob, fresh)
             return out
+    if det and (xd.shape[0] if native is None else native.n):
+        raise ValueError("EVK_VOXEL_DETERMINISTIC=1: the one-pass path cannot take this call (%d bins of %dx%d: no tiling "
+                         "fits the LDS, or unaligned on-disk columns)" % (B, H, W))
     if t_first is None:          # the direct kernel takes ts[0] / ts[-1] as host scalars
         if native is None:
             t_first, t_last = D.ends(td)

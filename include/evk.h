@@ -328,9 +328,9 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  *            takes them from the same column), so the caller needs no device-to-host transfer before the launch;
  *            EVK_VOXEL2_PARTITION_ONLY / EVK_VOXEL2_TILES_ONLY: launch one of the two kernels (timing).
  *            EVK_VOXEL_DETERMINISTIC: the tile kernel accumulates int64 multiples of 2^-32 instead of float64 (integer
- *            adds commute: the grid is bit-identical from run to run and for any order of the events); every
- *            contribution must be finite and below 2^30, anything else is counted in index[4] (the caller reads and
- *            clears it) and left out.
+ *            adds commute: the grid is bit-identical from run to run and for any order of the events); a NaN t_norm
+ *            (t_last == t_first, Q9) marks its cell NaN in every bin as in the reference; every other contribution must be
+ *            finite and below 2^30, anything else is counted in index[4] (the caller reads and clears it) and left out.
  * Tiles: tile_w x tile_h PIXELS, any size with (tile_w | 1) * tile_h <= 1024 (evk_voxel2_num_tiles() > 0), at most
  * evk_voxel2_max_tiles() of them.  The tile kernel runs one workgroup per tile, all resident at once, so a tile COUNT
  * that is a multiple of the 256 CUs (640x480: 512 tiles of 20x30) keeps every CU equally busy. */

@@ -134,6 +134,46 @@ def test_voxel_deterministic_mode_is_bit_reproducible_at_full_size(E, monkeypatc
                                 sensor_size=(H, W))
 
 
+def test_deterministic_mode_at_small_event_counts_views_and_constant_time_stamps(E, monkeypatch):
+    """EVK_VOXEL_DETERMINISTIC=1 is a property of the CALL, not of its size: 5 000 events (far below the 'auto' threshold,
+    where the float-atomic kernel would run) handed over as strided, unaligned views take the one-pass path and give the same
+    bits for a permuted order; EVK_IMPL=direct contradicts the mode and raises; ts[-1] == ts[0] (Q9) gives the reference's
+    NaN cells, not a refusal."""
+    from oracle import reference_np as R
+    n, H, W, B = 5000, 180, 240, 5
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    hot = rng.random(n) < 0.6
+    x[hot] = 17.0; y[hot] = 23.0                       # thousands of float32 weights on one pixel: the order would matter
+    t = np.repeat(np.sort(rng.uniform(0, 1, n // 50)), 50).astype(np.float32)
+    p = rng.normal(size=n).astype(np.float32)
+    monkeypatch.setenv("EVK_VOXEL_DETERMINISTIC", "1")
+
+    def views(cols):      # every second element of a buffer that starts 4 bytes off a 16-byte boundary
+        out = []
+        for a in cols:
+            buf = torch.zeros(2 * n + 1, dtype=torch.float32, device="cuda")
+            buf[1::2] = torch.from_numpy(a).cuda()
+            out.append(buf[1::2])
+        return out
+    base = E.events_to_voxel_torch(*views((x, y, t, p)), B, sensor_size=(H, W)).cpu().numpy()
+    close(base, R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+    perm = np.concatenate([rng.permutation(50) + 50 * i for i in range(n // 50)])
+    again = E.events_to_voxel_torch(*views(tuple(a[perm] for a in (x, y, t, p))), B, sensor_size=(H, W)).cpu().numpy()
+    assert np.array_equal(base, again)
+    monkeypatch.setenv("EVK_IMPL", "direct")
+    with pytest.raises(ValueError):
+        E.events_to_voxel_torch(*views((x, y, t, p)), B, sensor_size=(H, W))
+    monkeypatch.delenv("EVK_IMPL")
+    tc = np.full(n, 2.5, np.float32)
+    got = E.events_to_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, tc, p)), B, sensor_size=(H, W)).cpu().numpy()
+    with np.errstate(all="ignore"):
+        ref = R.events_to_voxel_torch(x, y, tc, p, B, sensor_size=(H, W), accum="f64")
+    assert np.isnan(ref).any() and np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+    E.check_errors()
+
+
 @pytest.mark.parametrize("mode", ["counting", "fixed"])
 def test_integer_modes_are_order_free_also_where_hot_tiles_are_cut(E, monkeypatch, mode):
     """Half of the events in a 100x100 px blob: its tiles are cut into pieces whose partial tiles the last piece sums.  The
