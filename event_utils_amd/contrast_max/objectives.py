@@ -546,8 +546,13 @@ class rms_objective(_reduction_objective):
         blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         if blur_sigma > 0:
             iwe = gaussian_filter_device(iwe.contiguous(), blur_sigma)
-        norm = torch.linalg.matrix_norm(iwe.double(), ord=2).item()   # float64: the device f32 SVD is only good to ~1e-5
-        return np.float32(-(norm * norm) / (iwe.shape[0] * iwe.shape[1]))
+        # largest singular value squared = largest eigenvalue of the (smaller) Gram matrix, float64 on the device.  (The
+        # device SVD -- torch.linalg.matrix_norm -> rocSOLVER -- does not converge on the nearly rank-one images of a handful
+        # of events: "too many repeated singular values"; the symmetric eigensolver does, and is the cheaper of the two.)
+        a = iwe.double()
+        gram = a @ a.T if a.shape[0] <= a.shape[1] else a.T @ a
+        norm2 = max(float(torch.linalg.eigvalsh(gram)[-1].item()), 0.0)
+        return np.float32(-norm2 / (iwe.shape[0] * iwe.shape[1]))
 
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                           blur_sigma=None, showimg=False, iwe=None, d_iwe=None):

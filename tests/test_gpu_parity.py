@@ -610,6 +610,22 @@ def test_f12_other_objectives(E, golden):
     assert np.all(np.isfinite(np.asarray(argmax, float)))
 
 
+def test_rms_objective_of_a_handful_of_events(E):
+    """objectives.py:266-306 on nearly rank-one images (one event, blurred): the spectral norm must come out as numpy's does
+    (the device SVD does not converge there; the Gram matrix's largest eigenvalue does) -- found by tools/fuzz_parity.py."""
+    from event_utils_amd.contrast_max import objectives as O
+    from oracle import reference_np as R
+    for n, sigma in ((1, 2.0), (2, 1.0), (5, 0.0)):
+        rng = np.random.default_rng(n)
+        x, y = rng.uniform(20, 200, n), rng.uniform(20, 150, n)
+        t = np.sort(rng.uniform(0, 0.1, n)); p = np.ones(n)
+        ro, eo = R.rms_objective(), O.rms_objective()
+        ro.accum = "f64"
+        rf = ro.evaluate_function(np.array([10., -5.]), x, y, t, p, R.linvel_warp(), (180, 240), blur_sigma=sigma)
+        f = eo.evaluate_function(np.array([10., -5.]), x, y, t, p, E.linvel_warp(), (180, 240), blur_sigma=sigma)
+        assert isinstance(f, np.float32) and abs(float(f) - float(rf)) <= 2e-5 * abs(float(rf)) + 1e-12, (n, f, rf)
+
+
 def test_f13_dense_flow_warp(E, golden):
     from event_utils_amd.transforms.optic_flow import warp_events_flow_torch
     g = golden("f13_flow_warp")

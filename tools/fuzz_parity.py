@@ -1,9 +1,9 @@
-"""Differential fuzzing of the public voxel / event-image calls against the CPU oracle (oracle/reference_np.py), beyond the
+"""Differential fuzzing of the public voxel / event-image / get_iwe / objective calls against the CPU oracle (oracle/reference_np.py), beyond the
 sizes and seeds of tests/: sensor sizes up to 1300 x 800, event counts around every boundary of the one-pass path (one wave,
 one sub-chunk, the 'auto' thresholds, several sub-chunks per workgroup), scenes that cut hot tiles, polarities of every kind
 (+-1, zeros, small integers, float32, huge, NaN / infinite), time stamps that are constant / few-valued / unsorted, every
 EVK_IMPL.  Test infrastructure (imports the oracle): not part of the product.
-usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native]     exit code 1 on any mismatch"""
+usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective]     exit code 1 on any mismatch"""
 import os
 import sys
 import time
@@ -222,11 +222,127 @@ def case_native(rng):
     return desc, same(got, ref, None, "grid")
 
 
+N_IWE = [1, 2, 64, 1000, 8193, 149_999, 150_001, 400_000, 1_200_000]
+
+
+def iwe_inputs(rng):
+    sensor = None if rng.random() < 0.2 else ([(180, 240), (260, 346), (480, 640), (720, 1280)][int(rng.integers(0, 4))]
+                                               if rng.random() < 0.4 else (int(rng.integers(8, 720)), int(rng.integers(8, 1280))))
+    canvas = (180, 240) if sensor is None else sensor
+    img_size = canvas if rng.random() < 0.5 else (max(2, canvas[0] + int(rng.integers(-10, 30))), max(2, canvas[1] + int(rng.integers(-10, 30))))
+    n = int(rng.choice(N_IWE))
+    H, W = canvas
+    scene = str(rng.choice(["uniform", "uniform", "blob", "edge", "pixels"]))
+    x = rng.uniform(-2, W + 2, n); y = rng.uniform(-2, H + 2, n)
+    if scene == "blob" and n > 8:
+        hot = rng.random(n) < 0.7
+        x[hot] = W / 2 + rng.uniform(-3, 3, hot.sum()); y[hot] = H / 3 + rng.uniform(-3, 3, hot.sum())
+    elif scene == "edge" and n > 8:
+        hot = rng.random(n) < 0.8
+        x[hot] = W * 0.37 + rng.normal(0, 0.6, hot.sum())
+    elif scene == "pixels":        # sensor events: integer pixels
+        x, y = np.floor(np.clip(x, 0, W - 1)), np.floor(np.clip(y, 0, H - 1))
+    T = float(rng.choice([0.05, 0.2, 1.0]))
+    t = np.sort(rng.uniform(0, T, n))
+    f32 = rng.random() < 0.75
+    if f32:          # float32-representable columns -> float32 device columns; else float64 ones
+        x, y, t = (a.astype(np.float32).astype(np.float64) for a in (x, y, t))
+        t = np.sort(t)
+    pk = str(rng.choice(["pm1", "pm1", "float", "x100"]))
+    p = rng.choice([-1.0, 1.0], n) * (100.0 if pk == "x100" else 1.0)
+    if pk == "float":
+        p = rng.normal(size=n).astype(np.float32).astype(np.float64)
+    scale = float(rng.choice([0.0, 10.0, 100.0, 1000.0]))
+    prm = rng.normal(0, 1, 2) * scale
+    impl = str(rng.choice(["auto", "tiled", "direct"]))
+    desc = "sensor=%s img_size=%s n=%d %s f32=%d p=%s T=%g prm=(%.1f, %.1f) impl=%s" % (sensor, img_size, n, scene, f32, pk, T, prm[0], prm[1], impl)
+    return desc, sensor, img_size, n, scene, x, y, t, p, prm, impl
+
+
+def case_iwe(rng):
+    desc, sensor, img_size, n, scene, x, y, t, p, prm, impl = iwe_inputs(rng)
+    grad, pol = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    desc = "iwe grad=%d pol=%d %s" % (grad, pol, desc)
+    with np.errstate(all="ignore"):
+        ri, rd = R.get_iwe(prm, x, y, t, p, R.linvel_warp(), img_size, compute_gradient=grad, use_polarity=pol,
+                           sensor_size=sensor, accum="f64")
+        mi, _ = R.get_iwe(prm, x, y, t, p, R.linvel_warp(), img_size, compute_gradient=False, use_polarity=False,
+                          sensor_size=sensor, accum="f64")
+    os.environ["EVK_IMPL"] = impl
+    try:
+        iwe, diwe = E.get_iwe(prm, x, y, t, p, E.linvel_warp(), img_size, compute_gradient=grad, use_polarity=pol, sensor_size=sensor)
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None)
+    hot = scene in ("blob", "edge")
+    # (float64 columns that are not float32-representable stay float64 on the device and take the direct kernels)
+    direct_like = impl == "direct" or (impl == "auto" and n < tiled.TILED_MIN_EVENTS_IWE) or "f32=0" in desc
+    err = same(iwe, ri, mi, "iwe", 1e-4 if direct_like and hot else 4e-7)
+    if err is None and grad:
+        if diwe is None:
+            return desc, "d_iwe is None"
+        # the derivative image's magnitudes: |p| * |t_ref - t| <= T per event and weight -- bounded through the IWE of |p|
+        dm = np.broadcast_to(np.asarray(mi, np.float64) * float(t[-1] - t[0]) * 4.0, np.asarray(rd).shape)
+        err = same(diwe, rd, dm, "d_iwe", 1e-4 if direct_like and hot else 4e-7)
+    elif err is None and diwe is not None:
+        err = "d_iwe returned without compute_gradient"
+    return desc, err
+
+
+def case_objective(rng):
+    from event_utils_amd.contrast_max import objectives as O
+    from event_utils_amd.events import DeviceEvents
+    desc, sensor, img_size, n, scene, x, y, t, p, prm, impl = iwe_inputs(rng)
+    if n < 64:
+        n = 1000; x, y, t, p = (np.resize(a, n) for a in (x, y, t, p)); t = np.sort(t)
+    name = str(rng.choice(["variance", "variance", "variance", "sos", "soe", "moa", "sosa", "r1", "rms"]))
+    sigma = [None, 0.0, 1.0, 2.0][int(rng.integers(0, 4))]
+    resident = bool(rng.integers(0, 2))
+    desc = "objective %s sigma=%s resident=%d %s" % (name, sigma, resident, desc)
+    mk = {"variance": "variance_objective", "sos": "sos_objective", "soe": "soe_objective", "moa": "moa_objective",
+          "sosa": "sosa_objective", "r1": "r1_objective", "rms": "rms_objective"}[name]
+    ro, eo = getattr(R, mk)(), getattr(O, mk)()
+    ro.sensor_size, ro.accum = sensor, "f64"
+    eo.sensor_size = sensor
+    with np.errstate(all="ignore"):
+        rf = float(ro.evaluate_function(prm, x, y, t, p, R.linvel_warp(), img_size, blur_sigma=sigma))
+        rg = np.asarray(ro.evaluate_gradient(prm, x, y, t, p, R.linvel_warp(), img_size, blur_sigma=sigma), np.float64) \
+            if getattr(ro, "has_derivative", True) and hasattr(ro, "evaluate_gradient") else None
+    os.environ["EVK_IMPL"] = impl
+    try:
+        args = (DeviceEvents.from_arrays(x, y, t, p), None, None, None) if resident else (x, y, t, p)
+        f = float(eo.evaluate_function(prm, *args, E.linvel_warp(), img_size, blur_sigma=sigma))
+        g = np.asarray(eo.evaluate_gradient(prm, *args, E.linvel_warp(), img_size, blur_sigma=sigma), np.float64) \
+            if rg is not None and eo.has_derivative else None
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None)
+    if not np.isfinite(rf) or not np.isfinite(f):
+        return desc, None if (np.isnan(rf) and np.isnan(f)) or rf == f else "f %r vs %r" % (f, rf)
+    # float32 images summed / squared: 2e-5 relative (as tests/test_gpu_parity.py for the other objectives); tiny objectives
+    # (a handful of events on a large canvas) get the absolute floor of the float32 image they are computed from
+    # (soe = sum of exp(image): a relative error of the image's largest value times that value)
+    rel = 3e-5 * (max(1.0, abs(np.log(max(abs(rf), 1e-300)))) if name == "soe" else 1.0)
+    if abs(f - rf) > rel * abs(rf) + 1e-12:
+        return desc, "f %.9g vs %.9g" % (f, rf)
+    if g is not None:
+        if g.shape != rg.shape:
+            return desc, "gradient shape %s vs %s" % (g.shape, rg.shape)
+        direct_like = impl == "direct" or (impl == "auto" and n < tiled.TILED_MIN_EVENTS_IWE) or "f32=0" in desc
+        gtol = 1e-3 if direct_like and scene in ("blob", "edge") else 1e-4     # float32 atomics on hot pixels, as the reference's
+        gtol *= max(1.0, abs(np.log(max(abs(rf), 1e-300)))) if name == "soe" else 1.0
+        if np.isfinite(rg).all() and np.max(np.abs(g - rg)) > gtol * np.max(np.abs(rg)) + 1e-6 * abs(rf) + 1e-12:
+            return desc, "gradient %s vs %s" % (g, rg)
+    return desc, None
+
+
 if __name__ == "__main__":
     budget = float(arg("--seconds", "240"))
     seed = int(arg("--seed0", "0"))
-    kinds = arg("--kinds", "voxel,image,native").split(",")
-    fns = {"voxel": case_voxel, "image": case_image, "native": case_native}
+    kinds = arg("--kinds", "voxel,image,native,iwe,objective").split(",")
+    fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective}
     t0, done, failed = time.time(), {k: 0 for k in kinds}, []
     while time.time() - t0 < budget:
         kind = kinds[seed % len(kinds)]
