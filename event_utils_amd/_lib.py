@@ -29,6 +29,7 @@ SIGNATURES = {
     "evk_splat_drv_indexed_f32": [P, P, P, P, P, P, c_int, c_int64, c_int, c_int, P, P, P],
     "evk_image_drv_f64": [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P, P, P, P],
     "evk_image_gather_bilinear_f64": [P, P, c_int64, P, c_int, c_int, P, P, P],
+    "evk_image_gather_bilinear_f64img": [P, P, c_int64, P, c_int, c_int, P, P, P],
     "evk_timestamp_images_f32": [P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_float, c_float, P, P, P],
     "evk_voxel_f32": [P, P, P, P, c_int64, c_float, c_float, c_int, c_int, c_int, P, P, P],
     "evk_voxel_segments_f32": [P, P, P, P, P, c_int, c_int64, c_int, c_int, c_int, P, P, P],

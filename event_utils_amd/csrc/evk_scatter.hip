@@ -209,10 +209,12 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_image_drv_f64(const double *__res
     });
 }
 
-// image_to_event_weights (image.py:138-160): bilinear GATHER of a float32 image at float64 event coordinates.
+// image_to_event_weights (image.py:138-160): bilinear GATHER of a float32 (the IWE) or float64 image at float64 event
+// coordinates; the products are float64 either way, as numpy's promotion makes them upstream.
+template <typename IMG>
 __global__ void __launch_bounds__(EVK_BLOCK) k_image_gather_f64(const double *__restrict__ x,
                                                                 const double *__restrict__ y, int64_t n,
-                                                                const float *__restrict__ img, int h, int wd,
+                                                                const IMG *__restrict__ img, int h, int wd,
                                                                 double *__restrict__ out, uint32_t *oob) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const double clipx = (double)(wd - 1), clipy = (double)(h - 1);
@@ -627,7 +629,15 @@ extern "C" int evk_image_gather_bilinear_f64(const double *x, const double *y, i
                                              int wd, double *out, uint32_t *oob, void *stream) {
     if (n < 0 || h <= 1 || wd <= 1 || !img || (n > 0 && (!x || !y || !out))) return EVK_EINVAL;
     if (n == 0) return EVK_OK;
-    k_image_gather_f64<<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, n, img, h, wd, out, oob);
+    k_image_gather_f64<float><<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, n, img, h, wd, out, oob);
+    return launch_status();
+}
+
+extern "C" int evk_image_gather_bilinear_f64img(const double *x, const double *y, int64_t n, const double *img, int h,
+                                                int wd, double *out, uint32_t *oob, void *stream) {
+    if (n < 0 || h <= 1 || wd <= 1 || !img || (n > 0 && (!x || !y || !out))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_image_gather_f64<double><<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, n, img, h, wd, out, oob);
     return launch_status();
 }
 

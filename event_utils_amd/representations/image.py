@@ -207,10 +207,17 @@ def image_to_event_weights(xs, ys, img):
     dev = D.require_gpu()
     on_device = isinstance(xs, torch.Tensor)
     xd, yd = D.to_device(xs, torch.float64, dev), D.to_device(ys, torch.float64, dev)
-    imgd = D.to_device(img, torch.float32, dev)
+    # float32 images (the IWE) are read as they are; anything wider (float64, integers) as float64 -- numpy promotes
+    # img[...] * weights to float64 either way, so the values that enter the products are the image's own
+    if isinstance(img, torch.Tensor):
+        wide = img.dtype not in (torch.float32, torch.float16, torch.bfloat16)
+    else:
+        wide = np.asarray(img).dtype not in (np.float32, np.float16)
+    imgd = D.to_device(img, torch.float64 if wide else torch.float32, dev)
     out = torch.empty_like(xd)
     oob = D.OobCounter(dev)
-    _lib.call("evk_image_gather_bilinear_f64", D.ptr(xd), D.ptr(yd), xd.shape[0], D.ptr(imgd), imgd.shape[0],
+    _lib.call("evk_image_gather_bilinear_f64img" if wide else "evk_image_gather_bilinear_f64", D.ptr(xd), D.ptr(yd),
+              xd.shape[0], D.ptr(imgd), imgd.shape[0],
               imgd.shape[1], D.ptr(out), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(imgd.shape),))
     return out if on_device else out.cpu().numpy()

@@ -93,6 +93,9 @@ int evk_image_drv_f64(const double *x, const double *y, const double *p, const d
  * (objectives.py:196-198). */
 int evk_image_gather_bilinear_f64(const double *x, const double *y, int64_t n, const float *img, int h, int wd,
                                   double *out, uint32_t *oob, void *stream);
+/* the same for a float64 image (upstream takes any numpy array: img[...] * weights promotes to float64 either way) */
+int evk_image_gather_bilinear_f64img(const double *x, const double *y, int64_t n, const double *img, int h, int wd,
+                                     double *out, uint32_t *oob, void *stream);
 
 /* events_to_timestamp_image[_torch] (image.py:219-353): out4 = (4, h, wd) float32 = [sum of normalised timestamps of
  * positive events, count of positive events, the same two for non-positive events], bilinear splat, accumulated into

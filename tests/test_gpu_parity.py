@@ -570,6 +570,13 @@ def test_f11_gather_contrast_and_timestamp_images(E, golden):
         close(a.numpy(), g["ti_t_pos_rev%d" % rev]); close(b.numpy(), g["ti_t_neg_rev%d" % rev])
     with pytest.raises(IndexError):
         E.image_to_event_weights(np.array([-500.0]), np.array([1.0]), g["g_img"])
+    # a float64 image (upstream takes any numpy array; found by tools/fuzz_parity.py): its own values enter the products
+    from oracle import reference_np as R
+    rng = np.random.default_rng(3)
+    img64 = rng.normal(size=(37, 53)); gx, gy = rng.uniform(0, 54, 5000), rng.uniform(0, 38, 5000)
+    assert np.array_equal(E.image_to_event_weights(gx, gy, img64), R.image_to_event_weights(gx, gy, img64))
+    imgi = rng.integers(-9, 9, (37, 53))
+    assert np.array_equal(E.image_to_event_weights(gx, gy, imgi), R.image_to_event_weights(gx, gy, imgi))
 
 
 def test_f12_other_objectives(E, golden):

@@ -3,7 +3,7 @@ sizes and seeds of tests/: sensor sizes up to 1300 x 800, event counts around ev
 one sub-chunk, the 'auto' thresholds, several sub-chunks per workgroup), scenes that cut hot tiles, polarities of every kind
 (+-1, zeros, small integers, float32, huge, NaN / infinite), time stamps that are constant / few-valued / unsorted, every
 EVK_IMPL.  Test infrastructure (imports the oracle): not part of the product.
-usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective]     exit code 1 on any mismatch"""
+usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc]     exit code 1 on any mismatch"""
 import os
 import sys
 import time
@@ -222,6 +222,130 @@ def case_native(rng):
     return desc, same(got, ref, None, "grid")
 
 
+def case_windows(rng):
+    """voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch / events_to_voxel_timesync_torch / events_to_neg_pos_voxel_torch
+    (voxel_grid.py:37-112,155-182): the reference loops events_to_voxel_torch over slices; so does the check"""
+    H, W = int(rng.integers(2, 300)), int(rng.integers(2, 400))
+    B = int(rng.integers(1, 8))
+    n = int(rng.choice([65, 1000, 8193, 100_000, 400_000, 1_000_003]))
+    which = str(rng.choice(["fixed_n", "fixed_t", "timesync", "neg_pos"]))
+    scene = str(rng.choice(["uniform", "blob", "edge"]))
+    impl = str(rng.choice(["auto", "tiled", "direct"]))
+    x, y = coords(rng, n, H, W, bool(rng.integers(0, 2)), scene)
+    t = times(rng, n, "sorted")
+    p = weights(rng, n, str(rng.choice(["pm1", "pm1z", "float"])))
+    desc = "windows %s %dx%dx%d n=%d %s impl=%s" % (which, B, H, W, n, scene, impl)
+    tt = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    os.environ["EVK_IMPL"] = impl
+    try:
+        with np.errstate(all="ignore"):
+            if which == "fixed_n":
+                k = int(rng.choice([max(2, n // 7), max(2, n // 3), n, 33 if n <= 1000 else max(2, n // 11)]))
+                got = E.voxel_grids_fixed_n_torch(*tt, B, k, sensor_size=(H, W))
+                ref = [R.events_to_voxel_torch(x[i:i + k], y[i:i + k], t[i:i + k], p[i:i + k], B, sensor_size=(H, W), accum="f64")
+                       for i in range(0, n - k, k)]
+                desc += " k=%d" % k
+            elif which == "fixed_t":
+                span = float(t[-1] - t[0])
+                dt = span / float(rng.choice([1.5, 3.0, 7.3]))
+                got = E.voxel_grids_fixed_t_torch(*tt, B, dt, sensor_size=(H, W))
+                ref = []
+                for ts0 in np.arange(t[0].item(), t[-1].item() - dt, dt):
+                    a, b = np.searchsorted(t, ts0), np.searchsorted(t, ts0 + dt)
+                    ref.append(R.events_to_voxel_torch(x[a:b], y[a:b], t[a:b], p[a:b], B, sensor_size=(H, W), accum="f64"))
+            elif which == "timesync":
+                t0 = float(t[0]) + 0.2 * float(t[-1] - t[0]); t1 = float(t[0]) + 0.7 * float(t[-1] - t[0])
+                got = [E.events_to_voxel_timesync_torch(*tt, B, t0, t1, sensor_size=(H, W))]
+                a, b = np.searchsorted(t, t0), np.searchsorted(t, t1)
+                ref = [R.events_to_voxel_torch(x[a:b], y[a:b], t[a:b], p[a:b], B, sensor_size=(H, W), accum="f64")]
+            else:
+                got = list(E.events_to_neg_pos_voxel_torch(*tt, B, sensor_size=(H, W)))
+                ref = [R.events_to_voxel_torch(x, y, t, np.where(p > 0, 1, 0).astype(np.float32), B, sensor_size=(H, W), accum="f64"),
+                       R.events_to_voxel_torch(x, y, t, np.where(p <= 0, 1, 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")]
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None)
+    if len(got) != len(ref):
+        return desc, "%d grids vs %d" % (len(got), len(ref))
+    for k, (a, b) in enumerate(zip(got, ref)):
+        hot = scene in ("blob", "edge")
+        err = same(a.cpu().numpy(), b, np.abs(b) if hot else None, "grid %d" % k, 1e-3)   # windows / small calls: float32 atomics
+        if err is not None:
+            return desc, err
+    return desc, None
+
+
+def case_misc(rng):
+    """events_to_voxel (numpy float64 path), the timestamp images, the event-weights gather, batched objective evaluation"""
+    from event_utils_amd.events import DeviceEvents
+    which = str(rng.choice(["voxel_np", "ts_image", "ts_image_torch", "gather", "batch"]))
+    H, W = int(rng.integers(4, 300)), int(rng.integers(4, 400))
+    n = int(rng.choice([2, 65, 1000, 8193, 100_000, 400_000]))
+    impl = str(rng.choice(["auto", "tiled", "direct"]))
+    desc = "misc %s %dx%d n=%d impl=%s" % (which, H, W, n, impl)
+    os.environ["EVK_IMPL"] = impl
+    try:
+        with np.errstate(all="ignore"):
+            if which == "voxel_np":
+                B = int(rng.integers(1, 9))
+                x, y = rng.integers(0, W + 1, n), rng.integers(0, H + 1, n)       # the (H+1, W+1) canvas of events_to_image
+                t = np.sort(rng.uniform(0, 1, n)); p = rng.choice([-1.0, 1.0], n) if rng.random() < 0.5 else rng.normal(size=n)
+                got = E.events_to_voxel(x, y, t, p, B, sensor_size=(H, W))
+                ref = R.events_to_voxel(x, y, t, p, B, sensor_size=(H, W))
+                if got.dtype != np.float64:
+                    return desc, "dtype %s" % got.dtype
+                return desc + " B=%d" % B, same(got, ref, None, "grid")
+            if which in ("ts_image", "ts_image_torch"):
+                x = rng.uniform(0, W + 2, n); y = rng.uniform(0, H + 2, n)
+                t = np.sort(rng.uniform(10, 11, n)); p = rng.choice([-1.0, 1.0], n)
+                pad = bool(rng.integers(0, 2))
+                if which == "ts_image":
+                    norm = bool(rng.integers(0, 2))
+                    got = E.events_to_timestamp_image(x, y, t, p, sensor_size=(H, W), padding=pad, normalize_timestamps=norm)
+                    ref = R.events_to_timestamp_image(x, y, t, p, sensor_size=(H, W), padding=pad, normalize_timestamps=norm, accum="f64")
+                else:
+                    rev = bool(rng.integers(0, 2))
+                    c = [torch.from_numpy(a.astype(np.float32)) for a in (x, y, t - 10.0, p)]
+                    got = [g.cpu().numpy() for g in E.events_to_timestamp_image_torch(*c, sensor_size=(H, W), padding=pad, timestamp_reverse=rev)]
+                    ref = R.events_to_timestamp_image_torch(*(a.numpy() for a in c), sensor_size=(H, W), padding=pad, timestamp_reverse=rev, accum="f64")
+                for k in range(2):
+                    # a ratio of two float32 images: where the count is a handful of weights, the quotient carries their rounding
+                    err = same(got[k], ref[k], np.ones_like(ref[k]), "image %d" % k, 2e-5)
+                    if err is not None:
+                        return desc, err
+                return desc, None
+            if which == "gather":
+                img = rng.normal(size=(H, W))
+                x = rng.uniform(0, W + 1, n); y = rng.uniform(0, H + 1, n)
+                got, ref = E.image_to_event_weights(x, y, img), R.image_to_event_weights(x, y, img)
+                return desc, None if (got.dtype == np.float64 and np.array_equal(got, ref)) else "gather not bit-exact"
+            # batch: evaluate_function_batch at K flows against K oracle evaluations
+            H, W = max(H, 32), max(W, 32)
+            x = rng.uniform(1, W - 1, n).astype(np.float32).astype(np.float64); y = rng.uniform(1, H - 1, n).astype(np.float32).astype(np.float64)
+            t = np.sort(rng.uniform(0, 0.1, n).astype(np.float32).astype(np.float64)); p = rng.choice([-1.0, 1.0], n)
+            K = int(rng.integers(1, 8))
+            flows = [rng.normal(0, 1, 2) * float(rng.choice([5.0, 100.0, 1500.0])) for _ in range(K)]
+            eo, ro = E.variance_objective(), R.variance_objective()
+            eo.sensor_size = ro.sensor_size = (H, W); ro.accum = "f64"
+            ev = DeviceEvents.from_arrays(x, y, t, p)
+            got = eo.evaluate_function_batch(flows, ev, None, None, None, E.linvel_warp(), (H, W), 1.0)
+            gnum = eo.evaluate_numeric_gradient(flows[0], ev, None, None, None, E.linvel_warp(), (H, W), 1.0, epsilon=1.0)
+            ref = [float(ro.evaluate_function(q, x, y, t, p, R.linvel_warp(), (H, W), blur_sigma=1.0)) for q in flows]
+            for k in range(K):
+                if abs(float(got[k]) - ref[k]) > 3e-5 * abs(ref[k]) + 1e-12:
+                    return desc + " K=%d" % K, "flow %d %s: %.9g vs %.9g" % (k, flows[k], float(got[k]), ref[k])
+            f1 = [float(ro.evaluate_function(flows[0] + np.eye(2)[i], x, y, t, p, R.linvel_warp(), (H, W), blur_sigma=1.0)) for i in range(2)]
+            rnum = np.array([f1[0] - ref[0], f1[1] - ref[0]])
+            if np.max(np.abs(np.asarray(gnum, np.float64) - rnum)) > 1e-4 * abs(ref[0]) + 1e-12:     # a difference of two float32 values
+                return desc, "numeric gradient %s vs %s" % (gnum, rnum)
+            return desc + " K=%d" % K, None
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None)
+
+
 N_IWE = [1, 2, 64, 1000, 8193, 149_999, 150_001, 400_000, 1_200_000]
 
 
@@ -341,8 +465,9 @@ def case_objective(rng):
 if __name__ == "__main__":
     budget = float(arg("--seconds", "240"))
     seed = int(arg("--seed0", "0"))
-    kinds = arg("--kinds", "voxel,image,native,iwe,objective").split(",")
-    fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective}
+    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc").split(",")
+    fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective,
+           "windows": case_windows, "misc": case_misc}
     t0, done, failed = time.time(), {k: 0 for k in kinds}, []
     while time.time() - t0 < budget:
         kind = kinds[seed % len(kinds)]
