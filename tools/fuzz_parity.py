@@ -3,7 +3,7 @@ sizes and seeds of tests/: sensor sizes up to 1300 x 800, event counts around ev
 one sub-chunk, the 'auto' thresholds, several sub-chunks per workgroup), scenes that cut hot tiles, polarities of every kind
 (+-1, zeros, small integers, float32, huge, NaN / infinite), time stamps that are constant / few-valued / unsorted, every
 EVK_IMPL.  Test infrastructure (imports the oracle): not part of the product.
-usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc]     exit code 1 on any mismatch"""
+usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc,errors]     exit code 1 on any mismatch"""
 import os
 import sys
 import time
@@ -276,6 +276,77 @@ def case_windows(rng):
     return desc, None
 
 
+def case_errors(rng):
+    """coordinates beyond the sensor: index_put_ wraps -size <= index < 0 and raises IndexError outside (image.py:93-99 re-raises
+    it); the oracle decides which, the call must do the same -- for every EVK_IMPL, synchronous and deferred reporting"""
+    H, W = int(rng.integers(4, 500)), int(rng.integers(4, 700))
+    n = int(rng.choice([3, 65, 1000, 8193, 100_000, 400_000, 1_000_003]))
+    which = str(rng.choice(["voxel", "nearest", "bilinear"]))
+    impl = str(rng.choice(["auto", "tiled", "direct"]))
+    how = str(rng.choice(["neg_wrap", "neg_far", "beyond", "edge", "frac_neg"]))
+    errs = str(rng.choice(["strict", "deferred"]))
+    clip = bool(rng.integers(0, 2)) or which == "bilinear"
+    pad = bool(rng.integers(0, 2))
+    desc = "errors %s %dx%d n=%d impl=%s %s clip=%d pad=%d EVK_ERRORS=%s" % (which, H, W, n, impl, how, clip, pad, errs)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    if which == "bilinear":
+        x = np.minimum(x + rng.random(n).astype(np.float32), np.float32(W - 1)); y = np.minimum(y + rng.random(n).astype(np.float32), np.float32(H - 1))
+    k = rng.integers(0, n, min(n, 3))
+    if how == "neg_wrap":
+        x[k] = -float(rng.integers(1, W)); y[k[:1]] = -float(rng.integers(1, H))
+    elif how == "neg_far":
+        x[k[:1]] = -float(W + 1 + rng.integers(0, 50))
+    elif how == "beyond":
+        if rng.random() < 0.5:
+            x[k[:1]] = float(W + rng.integers(0, 3))
+        else:
+            y[k[:1]] = float(H + rng.integers(0, 3))
+    elif how == "edge":
+        x[k] = float(W - 1); y[k] = float(H - 1)
+    else:
+        x[k] = -0.5; y[k[:1]] = -0.25          # truncation toward zero (nearest) vs floor (bilinear)
+    t = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+    p = weights(rng, n, str(rng.choice(["pm1", "float"])))
+    B = int(rng.integers(1, 6))
+    ref, ref_exc = None, None
+    try:
+        with np.errstate(all="ignore"):
+            if which == "voxel":
+                ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+            else:
+                ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), clip_out_of_range=clip,
+                                              interpolation=None if which == "nearest" else "bilinear", padding=pad, accum="f64")
+    except IndexError as e:
+        ref_exc = e
+    os.environ["EVK_IMPL"] = impl
+    os.environ["EVK_ERRORS"] = errs
+    got, exc = None, None
+    try:
+        c = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+        if which == "voxel":
+            got = E.events_to_voxel_torch(*c, B, sensor_size=(H, W))
+        else:
+            got = E.events_to_image_torch(c[0], c[1], c[3], sensor_size=(H, W), clip_out_of_range=clip,
+                                          interpolation=None if which == "nearest" else "bilinear", padding=pad)
+        E.check_errors()           # deferred reports surface here at the latest
+        got = got.cpu().numpy()
+    except IndexError as e:
+        exc = e
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None); os.environ.pop("EVK_ERRORS", None)
+        try:
+            E.check_errors()
+        except Exception:  # noqa: BLE001
+            pass
+    if (ref_exc is None) != (exc is None):
+        return desc, "reference %s, here %s" % ("raises IndexError" if ref_exc else "returns", "raises IndexError" if exc else "returns")
+    if ref_exc is not None:
+        return desc, None
+    return desc, same(got, ref, None, which)
+
+
 def case_misc(rng):
     """events_to_voxel (numpy float64 path), the timestamp images, the event-weights gather, batched objective evaluation"""
     from event_utils_amd.events import DeviceEvents
@@ -465,9 +536,9 @@ def case_objective(rng):
 if __name__ == "__main__":
     budget = float(arg("--seconds", "240"))
     seed = int(arg("--seed0", "0"))
-    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc").split(",")
+    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc,errors").split(",")
     fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective,
-           "windows": case_windows, "misc": case_misc}
+           "windows": case_windows, "misc": case_misc, "errors": case_errors}
     t0, done, failed = time.time(), {k: 0 for k in kinds}, []
     while time.time() - t0 < budget:
         kind = kinds[seed % len(kinds)]
