@@ -515,7 +515,7 @@ def bench_image_10m(E, tiled, dev, impl):
     xi, yi, pi = xd.int(), yd.int(), pud.int()
     alg = 12.0 * n + H * W * 4.0
     res = {"workload": "10M events, 640x480, uniform-random; 12 B/event (x, y, weight) + the image = %.1f MB algorithmic" % (alg / 1e6),
-           "impl": "one-pass partition (k_part_sorted, 4-byte nearest / 8+4-byte bilinear records) + k_image_tiles_n / _b; tiles %dx%d"
+           "impl": "one-pass partition (k_part_sorted, 4-byte nearest / 8-byte bilinear records, exact float weights as a side run where needed) + k_image_tiles_n / _b; tiles %dx%d"
                    % tiled.voxel2_shape(H, W, 1)}
 
     def block(k, public_ms=None, tag=None):
