@@ -344,7 +344,12 @@ def case_errors(rng):
         return desc, "reference %s, here %s" % ("raises IndexError" if ref_exc else "returns", "raises IndexError" if exc else "returns")
     if ref_exc is not None:
         return desc, None
-    return desc, same(got, ref, None, which)
+    mag = None
+    if which != "voxel":       # clipped events pile up at (0, 0) with their weights (Q8): float32 atomics in the direct kernels
+        with np.errstate(all="ignore"):
+            mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), clip_out_of_range=clip,
+                                          interpolation=None if which == "nearest" else "bilinear", padding=pad, accum="f64")
+    return desc, same(got, ref, mag, which, 1e-4)
 
 
 def case_misc(rng):
