@@ -108,6 +108,36 @@ def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear
 def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
     """Separate voxel grids of positive / non-positive events (reference: voxel_grid.py:155-182).  Above the tiled
     crossover both grids come from ONE pass over the events (EVK_VOXEL_SPLIT_POLARITY) instead of two voxelisations."""
+    from ..events import DeviceEvents
+    ev = xs if isinstance(xs, DeviceEvents) else None
+    if (ev is None and temporal_bilinear and all(isinstance(a, torch.Tensor) for a in (xs, ys, ts, ps)) and len(xs)
+            and xs.dtype == torch.int16 and ys.dtype == torch.int16 and ts.dtype == torch.float32
+            and ps.dtype in (torch.uint8, torch.int8, torch.bool)):
+        # int16 coordinates / 8-bit polarities as stored on disk (valid upstream too: ps > 0 / ps <= 0 on the stored values)
+        ev = DeviceEvents.from_native(xs, ys, ts, ps, polarity="literal", t_offset=0.0)
+    if ev is not None:
+        # resident events (ys, ts, ps ignored): the on-disk dtypes are partitioned as they are (9 / 13 B per event)
+        if not temporal_bilinear:
+            raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:144-147)")
+        if len(ev) == 0:
+            raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
+        from .. import tiled
+        H, W = int(sensor_size[0]), int(sensor_size[1])
+        native = ev.native if ev._cols is None else None
+        oob = D.OobCounter(ev.device)
+        cols = (None,) * 4 if native is not None else (ev.x, ev.y, ev.t, ev.p)
+        both = tiled.voxel_neg_pos_f32(*cols, ev.t_at(0), ev.t_at(-1), B, H, W, oob, native=native)
+        if both is not None:
+            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+            both = both if device is None else both.to(device)
+            return both[0], both[1]
+        x, y, t, p = ev.x, ev.y, ev.t, ev.p          # (widened once) -> the two-voxelisation route below
+        out_dev = ev.device if device is None else device
+        pos = events_to_voxel_torch(x, y, t, torch.where(p > 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,
+                                    sensor_size=sensor_size)
+        neg = events_to_voxel_torch(x, y, t, torch.where(p <= 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,
+                                    sensor_size=sensor_size)
+        return pos, neg
     if (temporal_bilinear and all(isinstance(a, torch.Tensor) for a in (xs, ys, ts, ps)) and len(xs)
             and ts.dtype != torch.float64 and ps.dtype != torch.float64):
         from .. import tiled

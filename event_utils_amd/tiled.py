@@ -350,19 +350,24 @@ def can_tile_image(cols, impl, bilinear=False):
     return impl == "tiled" or n >= (TILED_MIN_EVENTS_IMAGE_BILINEAR if bilinear else TILED_MIN_EVENTS_IMAGE)
 
 
-def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None):
+def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=None, native=None):
     """events_to_neg_pos_voxel_torch core: (2, B, H, W) float32 = [positive events, non-positive events] from ONE
     partition and ONE tile-kernel pass, or None when the one-pass path does not apply (the caller then voxelises the
-    two weight columns one after the other, as upstream)."""
+    two weight columns one after the other, as upstream).  native = events.NativeColumns: the on-disk dtypes, read as stored."""
     import torch
     impl = impl or default_impl()
-    if not can_tile((xd, yd, td, pd), impl):
+    if native is not None:
+        if not (impl != "direct" and native.aligned() and native.n and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)):
+            return None
+    elif not can_tile((xd, yd, td, pd), impl):
         return None
     shape2 = voxel2_shape(H, W, 2 * B)
     if shape2 is None:
         return None
-    out = torch.empty((2, B, H, W), dtype=torch.float32, device=xd.device)
-    voxel2((xd, yd, td, pd), None, xd.shape[0], t_first, t_last, B, H, W, *shape2, out, oob, True, split_polarity=True)
+    dev = xd.device if native is None else native.t.device
+    out = torch.empty((2, B, H, W), dtype=torch.float32, device=dev)
+    voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2, out, oob,
+           True, split_polarity=True)
     return out
 
 

@@ -172,3 +172,32 @@ def test_optimize_on_native_events_equals_optimize_on_float_columns(E, golden):
     fa = obj.evaluate_function(np.asarray(a), E.DeviceEvents.from_native(xs, ys, ts, ps), None, None, None, E.linvel_warp(), size, 1.0)
     fb = obj.evaluate_function(np.asarray(a), *cols, E.linvel_warp(), size, 1.0)
     assert abs(float(fa) - float(fb)) <= TOL * abs(float(fb))
+
+
+@pytest.mark.parametrize("impl", ["tiled", "direct", "auto"])
+def test_neg_pos_voxel_grids_from_on_disk_dtypes(E, monkeypatch, impl):
+    """events_to_neg_pos_voxel_torch (voxel_grid.py:155-182; the Dataset's combined_voxel_channels=False call,
+    base_dataset.py:451) on events in their on-disk dtypes: resident NativeColumns (the loaders' 2p - 1) and raw int16 / uint8
+    tensors (the stored values: ps > 0 / ps <= 0) -- one partition + one tile pass on the stored columns, against the
+    reference's two voxelisations of the widened columns."""
+    monkeypatch.setenv("EVK_IMPL", impl)
+    H, W, B = 260, 346, 5
+    for n in (4099, 600_001):
+        xs, ys, ts, ps = _native(50 + n, n, H, W)
+        x, y, t, p = R.widen_native_events(xs, ys, ts, ps)                  # float32 columns, p = 2 ps - 1
+        pos = R.events_to_voxel_torch(x, y, t, np.where(p > 0, 1, 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
+        neg = R.events_to_voxel_torch(x, y, t, np.where(p <= 0, 1, 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
+        ev = E.DeviceEvents.from_native(xs, ys, ts, ps)
+        a, b = E.events_to_neg_pos_voxel_torch(ev, None, None, None, B, sensor_size=(H, W))
+        assert a.is_cuda and a.dtype == torch.float32 and tuple(a.shape) == (B, H, W)
+        close(a.cpu().numpy(), pos); close(b.cpu().numpy(), neg)
+        if impl != "direct":
+            assert ev._cols is None or n < 350_000            # above the threshold nothing was widened
+        tt = [torch.from_numpy(v).cuda() for v in (xs, ys, t, ps.astype(np.uint8))]
+        a, b = E.events_to_neg_pos_voxel_torch(*tt, B, sensor_size=(H, W))
+        close(a.cpu().numpy(), pos); close(b.cpu().numpy(), neg)
+        xy = np.stack((xs, ys), axis=1)
+        ev2 = E.DeviceEvents.from_native(xy, None, ts, ps)
+        a, b = E.events_to_neg_pos_voxel_torch(ev2, None, None, None, B, sensor_size=(H, W))
+        close(a.cpu().numpy(), pos); close(b.cpu().numpy(), neg)
+    E.check_errors()
