@@ -182,9 +182,25 @@ def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
     H, W = int(sensor_size[0]), int(sensor_size[1])
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
+    bounds = np.asarray(bounds, dtype=np.int64)
+    from .. import tiled
+    impl = tiled.default_impl()
+    if (impl != "direct" and (impl == "tiled" or int(np.min(np.diff(bounds))) >= tiled.TILED_MIN_EVENTS)
+            and tiled.voxel2_shape(H, W, B) is not None and tiled.can_tile((xd, yd, td, pd), "tiled")):
+        # LARGE windows: each one through the one-pass path (partition + LDS tiles, two launches per window, ts[0] / ts[-1] of
+        # the window read on the device) instead of two global atomics per event: 10 windows of 1 M events 0.3 ms against 1 ms
+        grids = []
+        oob = D.OobCounter(dev)
+        for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
+            cols = [c[a:b] for c in (xd, yd, td, pd)]
+            cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]     # (a window may start at any event)
+            out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            tiled.voxel_f32(*cols, None, None, B, H, W, out, oob, fresh=True)
+            grids.append(out.to(device))
+        oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+        return grids
     # one launch per chunk of windows: blockIdx.y holds at most 65535 of them, and a chunk's grids are bounded in memory
     # (they move to xs.device before the next chunk is built, as the reference's per-window list would)
-    bounds = np.asarray(bounds, dtype=np.int64)
     per_chunk = int(max(1, min(65535, _WINDOW_CHUNK_BYTES // (B * H * W * 4))))
     grids = []
     for c0 in range(0, nseg, per_chunk):

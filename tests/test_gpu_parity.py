@@ -547,6 +547,39 @@ def test_voxel_windows_fixed_n_and_fixed_t(E, monkeypatch):
         close(a.numpy(), b.numpy())
 
 
+def test_large_voxel_windows_take_the_one_pass_path(E, monkeypatch):
+    """Windows of >= 350 k events are voxelised one by one by the partition + LDS-tile path (two launches per window instead of
+    two global atomics per event); windows that start at any event index (fixed_t: unaligned slices) included."""
+    from event_utils_amd import _lib
+    from event_utils_amd.representations import voxel_grid as V
+    rng = np.random.default_rng(12)
+    n, H, W, B = 1_600_003, 180, 240, 5
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 1.0, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    tt = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    calls = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    win = 400_001                                             # odd: every window but the first starts off a 16-byte boundary
+    got = V.voxel_grids_fixed_n_torch(*tt, B, win, sensor_size=(H, W))
+    assert len(got) == 3 and calls.count("evk_voxel2_f32") == 3 and "evk_voxel_segments_f32" not in calls
+    for k, g in enumerate(got):
+        sl = slice(k * win, (k + 1) * win)
+        close(g.cpu().numpy(), R.events_to_voxel_torch(x[sl], y[sl], t[sl], p[sl], B, sensor_size=(H, W), accum="f64"))
+    del calls[:]
+    got = V.voxel_grids_fixed_t_torch(*tt, B, 0.3, sensor_size=(H, W))
+    t_starts = np.arange(float(t[0]), float(t[-1]) - 0.3, 0.3)
+    assert len(got) == len(t_starts) == 3 and calls.count("evk_voxel2_f32") == 3
+    for g, ts0 in zip(got, t_starts):
+        a, b = np.searchsorted(t, ts0), np.searchsorted(t, ts0 + np.float32(0.3))
+        close(g.cpu().numpy(), R.events_to_voxel_torch(x[a:b], y[a:b], t[a:b], p[a:b], B, sensor_size=(H, W), accum="f64"))
+    del calls[:]
+    small = V.voxel_grids_fixed_n_torch(*tt, B, 100_000, sensor_size=(H, W))     # short windows: one launch for all of them
+    assert len(small) == 16 and "evk_voxel2_f32" not in calls and calls.count("evk_voxel_segments_f32") == 1
+    E.check_errors()
+
+
 # ------------------------------------------------------------------------------------------------ F11 next rows
 def test_f11_gather_contrast_and_timestamp_images(E, golden):
     g = golden("f11_gather_timestamp")
