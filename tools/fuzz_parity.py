@@ -3,7 +3,7 @@ sizes and seeds of tests/: sensor sizes up to 1300 x 800, event counts around ev
 one sub-chunk, the 'auto' thresholds, several sub-chunks per workgroup), scenes that cut hot tiles, polarities of every kind
 (+-1, zeros, small integers, float32, huge, NaN / infinite), time stamps that are constant / few-valued / unsorted, every
 EVK_IMPL.  Test infrastructure (imports the oracle): not part of the product.
-usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc,errors]     exit code 1 on any mismatch"""
+usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc,errors,prims]     exit code 1 on any mismatch"""
 import os
 import sys
 import time
@@ -352,6 +352,82 @@ def case_errors(rng):
     return desc, same(got, ref, mag, which, 1e-4)
 
 
+def case_prims(rng):
+    """the building blocks: linvel_warp.warp and events_bounds_mask (bit-exact, float64), events_to_image_drv with arbitrary
+    Jacobians, interpolate_to_image / interpolate_to_derivative_img, the dense-flow warp, the Gaussian blur (bit-identical to
+    scipy's: oracle gaussian_filter_reflect is pinned to it by fixture f10)"""
+    from event_utils_amd.contrast_max.objectives import gaussian_filter_device
+    from event_utils_amd.transforms.optic_flow import warp_events_flow_torch
+    which = str(rng.choice(["warp", "drv", "splat", "flow", "blur"]))
+    H, W = int(rng.integers(4, 300)), int(rng.integers(4, 400))
+    n = int(rng.choice([1, 65, 1000, 8193, 100_000, 400_000]))
+    desc = "prims %s %dx%d n=%d" % (which, H, W, n)
+    try:
+        with np.errstate(all="ignore"):
+            if which == "warp":
+                x = rng.uniform(-5, W + 5, n); y = rng.uniform(-5, H + 5, n); t = np.sort(rng.uniform(0, 10 ** float(rng.integers(-3, 10)), n))
+                prm = rng.normal(0, 1, 2) * float(rng.choice([0.0, 1e-3, 50.0, 1e4]))
+                t0 = float(t[-1]) if rng.random() < 0.7 else float(rng.uniform(t[0], t[-1]))
+                got = E.linvel_warp().warp(x, y, t, np.ones(n), t0, prm, compute_grad=True)
+                ref = R.linvel_warp().warp(x, y, t, np.ones(n), t0, prm, compute_grad=True)
+                for a, b, nm in zip(got, ref, ("x'", "y'", "jx", "jy")):
+                    if not (np.asarray(a).dtype == np.float64 and np.array_equal(a, b)):
+                        return desc, "%s not bit-exact" % nm
+                lim = (0, W, 0, H) if rng.random() < 0.5 else (float(rng.uniform(-3, 3)), float(rng.uniform(3, W + 3)), float(rng.uniform(-3, 3)), float(rng.uniform(3, H + 3)))
+                if not np.array_equal(E.events_bounds_mask(got[0], got[1], *lim), R.events_bounds_mask(ref[0], ref[1], *lim)):
+                    return desc, "bounds mask differs"
+                return desc, None
+            if which == "drv":
+                x = rng.uniform(-1, W + 2, n); y = rng.uniform(-1, H + 2, n)
+                x, y = np.maximum(x, 0), np.maximum(y, 0)           # (negative pixels wrap or raise: the errors kind)
+                p = rng.normal(size=n); jx = rng.normal(size=(2, n)); jy = rng.normal(size=(2, n))
+                grad = bool(rng.integers(0, 2))
+                gi, gd = E.events_to_image_drv(x, y, p, jx, jy, sensor_size=(H, W), compute_gradient=grad)
+                ri, rd = R.events_to_image_drv(x, y, p, jx, jy, sensor_size=(H, W), compute_gradient=grad, accum="f64")
+                mi, md = R.events_to_image_drv(x, y, np.abs(p), np.abs(jx), np.abs(jy), sensor_size=(H, W), compute_gradient=grad, accum="f64")
+                err = same(gi, ri, mi, "iwe", 1e-6)
+                if err is None and grad:
+                    err = same(gd, rd, None, "d_iwe") if gd is not None else "d_iwe is None"
+                return desc, err
+            if which == "splat":
+                px = rng.integers(0, W - 1, n); py = rng.integers(0, H - 1, n)
+                dx = rng.random(n).astype(np.float32); dy = rng.random(n).astype(np.float32)
+                w = rng.normal(size=n).astype(np.float32)
+                w1 = rng.normal(size=(2, n)).astype(np.float32); w2 = rng.normal(size=(2, n)).astype(np.float32)
+                ref = R.interpolate_to_image(px, py, dx, dy, w, np.zeros((H, W), np.float32), accum="f64")
+                img = torch.zeros(H, W, device="cuda")
+                E.interpolate_to_image(*(torch.from_numpy(a).cuda() for a in (px, py, dx, dy, w)), img)
+                err = same(img.cpu().numpy(), ref, R.interpolate_to_image(px, py, dx, dy, np.abs(w), np.zeros((H, W), np.float32), accum="f64"), "splat", 1e-6)
+                if err is not None:
+                    return desc, err
+                refd = R.interpolate_to_derivative_img(px, py, dx, dy, np.zeros((2, H, W), np.float32), w1, w2, accum="f64")
+                dimg = torch.zeros(2, H, W, device="cuda")
+                E.interpolate_to_derivative_img(*(torch.from_numpy(a).cuda() for a in (px, py, dx, dy)), dimg, torch.from_numpy(w1).cuda(), torch.from_numpy(w2).cuda())
+                magd = R.interpolate_to_derivative_img(px, py, dx, dy, np.zeros((2, H, W), np.float32), np.abs(w1), np.abs(w2), accum="f64")
+                return desc, same(dimg.cpu().numpy(), refd, np.full(refd.shape, np.max(np.abs(magd)) * 4 + 1.0), "derivative splat", 1e-6)
+            if which == "flow":
+                n = max(n, 2)           # (the oracle squeezes its inputs as upstream does: one event is a 0-d array there)
+                x = rng.uniform(-2, W + 1, n).astype(np.float32); y = rng.uniform(-2, H + 1, n).astype(np.float32)
+                t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+                flow = (rng.normal(size=(2, H, W)) * 30).astype(np.float32)
+                t0 = None if rng.random() < 0.5 else float(rng.uniform(0, 0.1))
+                gx, gy = warp_events_flow_torch(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(t).cuda(), None,
+                                                torch.from_numpy(flow).cuda(), t0=t0)
+                rx, ry = R.warp_events_flow_torch(x, y, t, None, flow, t0=t0)
+                for a, b, nm in ((gx, rx, "x"), (gy, ry, "y")):
+                    err = same(a.cpu().numpy(), b, None, "warped " + nm)
+                    if err is not None:
+                        return desc, err
+                return desc, None
+            sigma = float(rng.choice([0.5, 1.0, 2.0, 3.3]))
+            a = rng.normal(size=(2, H, W) if rng.random() < 0.5 else (H, W)).astype(np.float32)
+            got = gaussian_filter_device(torch.from_numpy(a).cuda(), sigma).cpu().numpy()
+            ref = R.gaussian_filter_reflect(a, sigma)
+            return desc + " sigma=%g" % sigma, None if np.array_equal(got, ref) else "blur not bit-identical (max %.3e)" % np.max(np.abs(got - ref))
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+
+
 def case_misc(rng):
     """events_to_voxel (numpy float64 path), the timestamp images, the event-weights gather, batched objective evaluation"""
     from event_utils_amd.events import DeviceEvents
@@ -541,9 +617,9 @@ def case_objective(rng):
 if __name__ == "__main__":
     budget = float(arg("--seconds", "240"))
     seed = int(arg("--seed0", "0"))
-    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc,errors").split(",")
+    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc,errors,prims").split(",")
     fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective,
-           "windows": case_windows, "misc": case_misc, "errors": case_errors}
+           "windows": case_windows, "misc": case_misc, "errors": case_errors, "prims": case_prims}
     t0, done, failed = time.time(), {k: 0 for k in kinds}, []
     while time.time() - t0 < budget:
         kind = kinds[seed % len(kinds)]
