@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 @pytest.mark.parametrize("kind,seed0,cases", [("voxel", 100, 60), ("image", 200, 60), ("native", 300, 30), ("iwe", 400, 40),
                                               ("objective", 500, 40), ("windows", 600, 40), ("misc", 700, 60),
-                                              ("errors", 800, 80), ("prims", 900, 60)])
+                                              ("errors", 800, 80), ("prims", 900, 60), ("search", 1000, 8)])
 def test_random_cases_agree_with_the_oracle(kind, seed0, cases):
     argv, sys.argv = sys.argv, sys.argv[:1]
     try:
@@ -24,7 +24,8 @@ def test_random_cases_agree_with_the_oracle(kind, seed0, cases):
     finally:
         sys.argv = argv
     fn = {"voxel": F.case_voxel, "image": F.case_image, "native": F.case_native, "iwe": F.case_iwe, "objective": F.case_objective,
-          "windows": F.case_windows, "misc": F.case_misc, "errors": F.case_errors, "prims": F.case_prims}[kind]
+          "windows": F.case_windows, "misc": F.case_misc, "errors": F.case_errors, "prims": F.case_prims,
+          "search": F.case_search}[kind]
     failed = []
     for seed in range(seed0, seed0 + cases):
         desc, err = fn(np.random.default_rng(910_000 + seed))

@@ -3,7 +3,7 @@ sizes and seeds of tests/: sensor sizes up to 1300 x 800, event counts around ev
 one sub-chunk, the 'auto' thresholds, several sub-chunks per workgroup), scenes that cut hot tiles, polarities of every kind
 (+-1, zeros, small integers, float32, huge, NaN / infinite), time stamps that are constant / few-valued / unsorted, every
 EVK_IMPL.  Test infrastructure (imports the oracle): not part of the product.
-usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc,errors,prims]     exit code 1 on any mismatch"""
+usage: python tools/fuzz_parity.py [--seconds S] [--seed0 K] [--kinds voxel,image,native,iwe,objective,windows,misc,errors,prims,search]     exit code 1 on any mismatch"""
 import os
 import sys
 import time
@@ -428,6 +428,56 @@ def case_prims(rng):
         return desc, "raised %s: %s" % (type(e).__name__, e)
 
 
+def case_search(rng):
+    """grid_search_initial (every sample and the best one) and the objective landscape.  (The optimisers are not fuzzed: BFGS on
+    forward differences over a rugged landscape amplifies a 1e-7 difference of the objective into another local optimum -- on the
+    oracle and on the HIP path alike; their parity is the golden trace f9 and tests/test_gpu_parity.py::test_f9_*.)"""
+    from event_utils_amd.contrast_max import events_cmax as C
+    which = str(rng.choice(["grid", "landscape"]))
+    H, W = int(rng.integers(60, 200)), int(rng.integers(80, 260))
+    n = int(rng.choice([20_000, 60_000, 200_000]))
+    v = rng.uniform(-60, 60, 2)
+    desc = "search %s %dx%d n=%d true flow (%.1f, %.1f)" % (which, H, W, n, v[0], v[1])
+    # edges moving at v: events at x = x_edge + v t (vertical lines) and y = y_edge + v t (horizontal lines), a little noise
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32).astype(np.float64)
+    vert = rng.random(n) < 0.5
+    ex, ey = rng.choice(np.linspace(0.25, 0.75, 4) * W, n), rng.choice(np.linspace(0.25, 0.75, 3) * H, n)
+    x = np.where(vert, ex, rng.uniform(0.15 * W, 0.85 * W, n)) + v[0] * t + rng.normal(0, 0.3, n)
+    y = np.where(vert, rng.uniform(0.15 * H, 0.85 * H, n), ey) + v[1] * t + rng.normal(0, 0.3, n)
+    x, y = (np.clip(a, 1, lim - 2).astype(np.float32).astype(np.float64) for a, lim in ((x, W), (y, H)))
+    p = rng.choice([-1.0, 1.0], n) if rng.random() < 0.5 else np.ones(n)
+    eo, ro = E.variance_objective(), R.variance_objective()
+    eo.sensor_size = ro.sensor_size = (H, W)
+    ro.accum = "f64"
+    try:
+        with np.errstate(all="ignore"):
+            if which == "grid":
+                kw = dict(log_scale=bool(rng.integers(0, 2)), num_samples_per_param=int(rng.choice([3, 5])))
+                if rng.random() < 0.5:
+                    kw["param_ranges"] = [[-80, 80], [-100, 60]]
+                r = C.grid_search_initial(x, y, t, p, E.linvel_warp(), eo, (H, W), **kw)
+                ref = R.grid_search_initial(x, y, t, p, R.linvel_warp(), ro, (H, W), **kw)
+                if not np.array_equal(np.array(r["params"]), np.array(ref["params"])):
+                    return desc, "sample positions differ"
+                ev, rv = np.asarray(r["eval"], np.float64), np.asarray(ref["eval"], np.float64)
+                if np.max(np.abs(ev - rv)) > 2e-5 * np.max(np.abs(rv)):
+                    return desc, "sample values: max error %.3e of %.3e" % (np.max(np.abs(ev - rv)), np.max(np.abs(rv)))
+                # the best sample: the same one unless two samples tie within the tolerance
+                if tuple(r["min_params"]) != tuple(ref["min_params"]):
+                    i = ref["params"].index(tuple(r["min_params"]))
+                    if abs(rv[i] - ref["min_func_eval"]) > 2e-5 * abs(ref["min_func_eval"]):
+                        return desc, "best sample %s vs %s" % (r["min_params"], ref["min_params"])
+                return desc, None
+            if which == "landscape":
+                res = int(rng.choice([40, 50]))
+                got = C.objective_landscape(x, y, t, p, eo, E.linvel_warp(), x_range=(-100, 100), y_range=(-100, 100), resolution=res, img_size=(H, W))
+                ref = R.objective_landscape(x, y, t, p, ro, R.linvel_warp(), x_range=(-100, 100), y_range=(-100, 100), resolution=res, img_size=(H, W))
+                return desc, same(got, ref, None, "landscape", 0) if np.max(np.abs(np.asarray(got) - ref)) > 3e-5 else None
+            return desc, None
+    except Exception as e:  # noqa: BLE001
+        return desc, "raised %s: %s" % (type(e).__name__, e)
+
+
 def case_misc(rng):
     """events_to_voxel (numpy float64 path), the timestamp images, the event-weights gather, batched objective evaluation"""
     from event_utils_amd.events import DeviceEvents
@@ -617,9 +667,9 @@ def case_objective(rng):
 if __name__ == "__main__":
     budget = float(arg("--seconds", "240"))
     seed = int(arg("--seed0", "0"))
-    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc,errors,prims").split(",")
+    kinds = arg("--kinds", "voxel,image,native,iwe,objective,windows,misc,errors,prims,search").split(",")
     fns = {"voxel": case_voxel, "image": case_image, "native": case_native, "iwe": case_iwe, "objective": case_objective,
-           "windows": case_windows, "misc": case_misc, "errors": case_errors, "prims": case_prims}
+           "windows": case_windows, "misc": case_misc, "errors": case_errors, "prims": case_prims, "search": case_search}
     t0, done, failed = time.time(), {k: 0 for k in kinds}, []
     while time.time() - t0 < budget:
         kind = kinds[seed % len(kinds)]
