@@ -155,6 +155,22 @@ class _ErrorState:
         self.poll(wait=True)
         self._raise(int(self.counter.item()), exc_type, msg)      # synchronises; the reference is synchronous too
 
+    def strict_report(self, seq, exc_type, msg):
+        """'strict' for a call whose kernels report {sequence number, counter} to the pinned slot themselves (the one-pass
+        paths: written when the partition kernel's last workgroup finishes; the tile kernel behind it drops nothing): wait for
+        THAT report instead of synchronising the stream and reading the counter back -- the exception is as synchronous as
+        the reference's, the tile kernel keeps running and the next call's launches are not held up (10 M events: 0.106 ->
+        ~0.08 ms per call).  A stream that went idle without reporting (a failed launch) falls back to the read-back."""
+        if self.pending:
+            self.poll(wait=True)
+        spins = 0
+        while ((int(self.report_np[0]) - seq) & 0xFFFFFFFF) >= 0x80000000:
+            spins += 1
+            if spins % 2048 == 0 and torch.cuda.current_stream(self.counter.device).query():
+                if ((int(self.report_np[0]) - seq) & 0xFFFFFFFF) >= 0x80000000:
+                    return self.strict(exc_type, msg)
+        self._raise(int(self.report_np[1]) & 0xFFFFFFFF, exc_type, msg)
+
     def next_seq(self):
         self.seq = (self.seq + 1) & 0x7FFFFFFF
         return self.seq
@@ -230,6 +246,8 @@ class OobCounter:
     def raise_if_set(self, exc_type, msg, deferrable=False):
         if deferrable and error_mode() == "deferred":
             self.state.defer(exc_type, msg, self.seq)
+        elif deferrable and self.seq is not None:
+            self.state.strict_report(self.seq, exc_type, msg)     # (results stay on the device: only the REPORT is waited for)
         else:
             self.state.strict(exc_type, msg)
 
