@@ -32,6 +32,7 @@ SIGNATURES = {
     "evk_image_gather_bilinear_f64img": [P, P, c_int64, P, c_int, c_int, P, P, P],
     "evk_timestamp_images_f32": [P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_float, c_float, P, P, P],
     "evk_voxel_f32": [P, P, P, P, c_int64, c_float, c_float, c_int, c_int, c_int, P, P, P],
+    "evk_voxel_from_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, P, P, P],
     "evk_voxel_segments_f32": [P, P, P, P, P, c_int, c_int64, c_int, c_int, c_int, P, P, P],
     "evk_voxel_f64": [P, P, P, P, c_int64, c_double, c_double, c_int, c_int, c_int, P, P, P],
     "evk_warp_linvel_f64": [P, P, P, c_int64, c_double, c_double, c_double, P, P, P, P, P],

@@ -340,8 +340,9 @@ template <bool VEC>
 __global__ void __launch_bounds__(EVK_BLOCK) k_voxel_f32(const float *__restrict__ x, const float *__restrict__ y,
                                                          const float *__restrict__ t, const float *__restrict__ p,
                                                          int64_t n, float t_first, float dt, float bm1, int B, int h,
-                                                         int wd, float *__restrict__ vox, uint32_t *oob) {
+                                                         int wd, float *__restrict__ vox, uint32_t *oob, int t_from_events) {
     const int64_t plane = (int64_t)h * wd;
+    if (t_from_events) t_first = t[0], dt = t[n - 1] - t_first;   // ts[0], ts[-1] (voxel_grid.py:133): no transfer before the launch
     foreach_events<VEC>(n, [&](int64_t base, int cnt, bool vec) {
         Vec4<float> xv = load_col(x, base, cnt, vec), yv = load_col(y, base, cnt, vec),
                     tv = load_col(t, base, cnt, vec), pv = load_col(p, base, cnt, vec);
@@ -660,18 +661,26 @@ extern "C" int evk_warp_flow_field_f32(const float *x, const float *y, const flo
     return launch_status();
 }
 
-extern "C" int evk_voxel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first,
-                             float t_last, int B, int h, int wd, float *vox, uint32_t *oob, void *stream) {
+static int voxel_direct(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first, float t_last,
+                        int from_events, int B, int h, int wd, float *vox, uint32_t *oob, void *stream) {
     if (n < 0 || B <= 0 || h <= 0 || wd <= 0 || !vox || (n > 0 && (!x || !y || !t || !p))) return EVK_EINVAL;
     if (n == 0) return EVK_OK;
     const float dt = t_last - t_first, bm1 = (float)(B - 1);
     if (aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))
         k_voxel_f32<true><<<stream_grid(n, 4), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, n, t_first, dt, bm1, B,
-                                                                                h, wd, vox, oob);
+                                                                                h, wd, vox, oob, from_events);
     else
         k_voxel_f32<false><<<stream_grid(n), EVK_BLOCK, 0, EVK_STREAM(stream)>>>(x, y, t, p, n, t_first, dt, bm1, B, h,
-                                                                              wd, vox, oob);
+                                                                              wd, vox, oob, from_events);
     return launch_status();
+}
+extern "C" int evk_voxel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first,
+                             float t_last, int B, int h, int wd, float *vox, uint32_t *oob, void *stream) {
+    return voxel_direct(x, y, t, p, n, t_first, t_last, 0, B, h, wd, vox, oob, stream);
+}
+extern "C" int evk_voxel_from_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int B,
+                                         int h, int wd, float *vox, uint32_t *oob, void *stream) {
+    return voxel_direct(x, y, t, p, n, 0.0f, 0.0f, 1, B, h, wd, vox, oob, stream);
 }
 
 extern "C" int evk_voxel_f64(const int32_t *x, const int32_t *y, const double *t, const double *p, int64_t n,

@@ -185,7 +185,7 @@ def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
     bounds = np.asarray(bounds, dtype=np.int64)
     from .. import tiled
     impl = tiled.default_impl()
-    if (impl != "direct" and (impl == "tiled" or int(np.min(np.diff(bounds))) >= tiled.TILED_MIN_EVENTS)
+    if (impl != "direct" and (impl == "tiled" or int(np.min(np.diff(bounds))) >= _WINDOW_MIN_EVENTS)
             and tiled.voxel2_shape(H, W, B) is not None and tiled.can_tile((xd, yd, td, pd), "tiled")):
         # LARGE windows: each one through the one-pass path (partition + LDS tiles, two launches per window, ts[0] / ts[-1] of
         # the window read on the device) instead of two global atomics per event: 10 windows of 1 M events 0.3 ms against 1 ms
@@ -218,6 +218,9 @@ def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
 
 
 _WINDOW_CHUNK_BYTES = 8 << 30
+# windows at least this long go through the one-pass path one by one (~25 us of launches and host work per window against two
+# global atomics per event in the all-windows launch: tools/windows_time.py)
+_WINDOW_MIN_EVENTS = 350_000
 
 
 def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temporal_bilinear=True):

@@ -27,10 +27,17 @@ FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu
          "iwe_fixed": True, "image_fixed": True}
 
 
-# 'auto' thresholds, measured (profiles/r01_direct_tiled_crossover.txt): the single-shot voxel call pays ~40 us of fixed
-# bucketing cost, the direct kernel 2 global atomics per event at ~21 G/s -> crossover ~350 k events; the IWE path
-# re-uses its buckets over many evaluations and has 4-12 atomics per event -> crossover ~150 k events
-TILED_MIN_EVENTS = 350_000
+# 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, tools/crossover.py).  Voxel grid: the one-pass path's two
+# launches cost 17-22 us whatever the event count; the direct kernel (a memset + 2 global atomics per event at ~21 G/s; ts[0] /
+# ts[-1] read by the kernel itself since round 4 -- with the device-to-host read it needed before, it never took less than
+# 34 us) 11 us up to 50 k events, 14 us at 100 k, 24 us at 200 k -> crossover ~150 k events.  Events in their on-disk dtypes
+# have no cheap direct route (widening kernel + the read of the time stamps' ends): the one-pass path at any size.  The two
+# grids of events_to_neg_pos_voxel_torch cost two direct calls: crossover at half the count.  The IWE path re-uses its buckets
+# over many evaluations (41 against 50-60 us per evaluation already at 2 k events) but its FIRST evaluation of a new event set
+# pays ~110 us of bucketing: 150 k events is where a handful of evaluations break even
+TILED_MIN_EVENTS = 150_000
+TILED_MIN_EVENTS_NATIVE = 1
+TILED_MIN_EVENTS_NEG_POS = 75_000
 TILED_MIN_EVENTS_IWE = 150_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
@@ -357,9 +364,9 @@ def voxel_neg_pos_f32(xd, yd, td, pd, t_first, t_last, B, H, W, oob=None, impl=N
     import torch
     impl = impl or default_impl()
     if native is not None:
-        if not (impl != "direct" and native.aligned() and native.n and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)):
+        if not (impl != "direct" and native.aligned() and native.n and (impl == "tiled" or native.n >= TILED_MIN_EVENTS_NATIVE)):
             return None
-    elif not can_tile((xd, yd, td, pd), impl):
+    elif not can_tile((xd, yd, td, pd), impl, TILED_MIN_EVENTS_NEG_POS):
         return None
     shape2 = voxel2_shape(H, W, 2 * B)
     if shape2 is None:
@@ -387,7 +394,7 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
         if native is None:
             xd, yd, td, pd = (c if c.data_ptr() % 16 == 0 else c.clone() for c in (c.contiguous() for c in (xd, yd, td, pd)))
     if native is not None:
-        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS)
+        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS_NATIVE)
     else:
         tileable = can_tile((xd, yd, td, pd), impl)
     if tileable:
@@ -399,9 +406,13 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     if det and (xd.shape[0] if native is None else native.n):
         raise ValueError("EVK_VOXEL_DETERMINISTIC=1: the one-pass path cannot take this call (%d bins of %dx%d: no tiling "
                          "fits the LDS, or unaligned on-disk columns)" % (B, H, W))
-    if t_first is None:          # the direct kernel takes ts[0] / ts[-1] as host scalars
-        if native is None:
-            t_first, t_last = D.ends(td)
+    if t_first is None:
+        if native is None:       # ts[0] / ts[-1] are read by the kernel itself: no transfer, no synchronisation before the launch
+            if fresh:
+                out.zero_()
+            _lib.call("evk_voxel_from_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], B, H, W,
+                      D.ptr(out), oob.ptr if oob is not None else None, D.stream())
+            return out
         else:                    # the loaders' (ts - ts_0).float(): subtraction in float64, then float32
             import numpy as np
             a, b = D.ends(native.t)

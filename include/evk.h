@@ -116,6 +116,10 @@ int evk_timestamp_images_f32(const float *x, const float *y, const float *t, con
  * rank of an event-sharded run must agree on). */
 int evk_voxel_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, float t_first,
                   float t_last, int B, int h, int wd, float *vox, uint32_t *oob, void *stream);
+/* the same with t_first = t[0], t_last = t[n-1] read by the kernel itself (voxel_grid.py:133-134 takes them from the same
+ * column): a caller whose events are on the device needs no device-to-host transfer before the launch */
+int evk_voxel_from_events_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int B, int h,
+                              int wd, float *vox, uint32_t *oob, void *stream);
 
 /* Windowed voxelisation: voxel_grids_fixed_n_torch / voxel_grids_fixed_t_torch (voxel_grid.py:37-80) call
  * events_to_voxel_torch once per window; this builds all nseg grids in ONE launch.  seg = nseg+1 device int64 offsets

@@ -16,7 +16,7 @@ import event_utils_amd as E  # noqa: E402
 from event_utils_amd import tiled  # noqa: E402
 from oracle import reference_np as R  # noqa: E402
 
-N_CHOICES = [1, 2, 63, 64, 65, 1000, 8191, 8192, 8193, 12_289, 79_999, 80_001, 319_999, 320_001, 350_001, 1_000_003, 2_500_000]
+N_CHOICES = [1, 2, 63, 64, 65, 1000, 8191, 8192, 8193, 12_289, 79_999, 80_001, 149_999, 150_001, 319_999, 320_001, 1_000_003, 2_500_000]
 
 
 def arg(name, default):
