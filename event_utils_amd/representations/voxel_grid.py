@@ -52,7 +52,8 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
             raise RuntimeError("events_to_voxel_torch needs float32 event columns (voxel_grid.py:138-142)")
         native = ev.native if ev._cols is None else None
         cols = (None,) * 4 if native is not None else (ev.x, ev.y, ev.t, ev.p)
-        out = _voxel_f32_device(*cols, B, sensor_size, ev.t_at(0), ev.t_at(-1), native=native)
+        out = _voxel_f32_device(*cols, B, sensor_size, ev.t_at(0), ev.t_at(-1), native=native,
+                                deferrable=device is None or torch.device(device).type == "cuda")
         return out if device is None else out.to(device)
     if device is None:
         device = xs.device
@@ -128,7 +129,8 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
         cols = (None,) * 4 if native is not None else (ev.x, ev.y, ev.t, ev.p)
         both = tiled.voxel_neg_pos_f32(*cols, ev.t_at(0), ev.t_at(-1), B, H, W, oob, native=native)
         if both is not None:
-            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),),
+                             deferrable=device is None or torch.device(device).type == "cuda")
             both = both if device is None else both.to(device)
             return both[0], both[1]
         x, y, t, p = ev.x, ev.y, ev.t, ev.p          # (widened once) -> the two-voxelisation route below
@@ -145,9 +147,11 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
         cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
         H, W = int(sensor_size[0]), int(sensor_size[1])
         oob = D.OobCounter(dev)
-        both = tiled.voxel_neg_pos_f32(*cols, *D.ends(cols[2]), B, H, W, oob)
+        both = tiled.voxel_neg_pos_f32(*cols, None, None, B, H, W, oob)     # (ts[0], ts[-1] are read on the device)
         if both is not None:
-            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),))
+            # events and grids that stay on the device never wait for the host (as events_to_voxel_torch: _device.error_mode)
+            resident = xs.is_cuda and torch.device(xs.device if device is None else device).type == "cuda"
+            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),), deferrable=resident)
             both = both.to(xs.device if device is None else device)
             return both[0], both[1]
     pos_weights = torch.where(ps > 0, 1.0, 0.0).to(torch.float32)

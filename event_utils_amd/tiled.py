@@ -27,17 +27,19 @@ FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu
          "iwe_fixed": True, "image_fixed": True}
 
 
-# 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, tools/crossover.py).  Voxel grid: the one-pass path's two
-# launches cost 17-22 us whatever the event count; the direct kernel (a memset + 2 global atomics per event at ~21 G/s; ts[0] /
-# ts[-1] read by the kernel itself since round 4 -- with the device-to-host read it needed before, it never took less than
-# 34 us) 11 us up to 50 k events, 14 us at 100 k, 24 us at 200 k -> crossover ~150 k events.  Events in their on-disk dtypes
-# have no cheap direct route (widening kernel + the read of the time stamps' ends): the one-pass path at any size.  The two
-# grids of events_to_neg_pos_voxel_torch cost two direct calls: crossover at half the count.  The IWE path re-uses its buckets
-# over many evaluations (41 against 50-60 us per evaluation already at 2 k events) but its FIRST evaluation of a new event set
-# pays ~110 us of bucketing: 150 k events is where a handful of evaluations break even
-TILED_MIN_EVENTS = 150_000
+# 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, profiles/r04_small_calls.txt; tools/crossover.py,
+# tools/small_calls.py).  DEVICE time: the one-pass path's two launches cost 17-22 us whatever the event count, the direct voxel
+# kernel (a memset + 2 global atomics per event at ~21 G/s; ts[0] / ts[-1] read by the kernel itself since round 4) 11 us up to
+# 50 k events, 24 us at 200 k: crossover ~150 k events (event images: 320 k nearest, 80 k bilinear).  But a public call on
+# device tensors is HOST-bound at these sizes, and the one-pass call is the cheaper one to issue -- its kernels report dropped
+# events themselves, the direct route copies the counter and records an event: 23-31 us per call against 36-41 us (135 us for the
+# two grids of events_to_neg_pos_voxel_torch) at 30 k, 100 k and 300 k events alike.  So 'auto' takes the one-pass path whenever
+# the columns allow it (can_tile); the direct kernels keep unaligned views, float64 columns and EVK_IMPL=direct.  The IWE path
+# re-uses its buckets over many evaluations (41 against 50-60 us per evaluation already at 2 k events) but its FIRST evaluation
+# of a new event set pays ~110 us of bucketing: 150 k events is where a handful of evaluations break even
+TILED_MIN_EVENTS = 1
 TILED_MIN_EVENTS_NATIVE = 1
-TILED_MIN_EVENTS_NEG_POS = 75_000
+TILED_MIN_EVENTS_NEG_POS = 1
 TILED_MIN_EVENTS_IWE = 150_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
@@ -301,11 +303,11 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
                              "accumulated in fixed point" % bad)
 
 
-# 'auto' thresholds of the event images (evk_image2.hip): below them the two launches of the one-pass path (~15 / ~18 us
-# whatever the event count) cost more than one global atomic (nearest) or four (bilinear) per event at ~21 G/s -- measured,
-# profiles/r04_image_crossover.txt: nearest 17 us direct at 400 k events, bilinear 24 us at 100 k
-TILED_MIN_EVENTS_IMAGE = 320_000
-TILED_MIN_EVENTS_IMAGE_BILINEAR = 80_000
+# event images (evk_image2.hip): in device time the two launches of the one-pass path (~15 / ~18 us whatever the event count) beat
+# one global atomic (nearest) or four (bilinear) per event at ~21 G/s from 320 k / 80 k events (profiles/r04_image_crossover.txt);
+# the public call is host-bound below that and cheaper to issue on the one-pass path (see above): any count
+TILED_MIN_EVENTS_IMAGE = 1
+TILED_MIN_EVENTS_IMAGE_BILINEAR = 1
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):

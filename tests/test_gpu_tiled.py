@@ -631,8 +631,11 @@ def test_neg_pos_voxel_edge_cases(E):
     rp = R.events_to_voxel_torch(x, y, t_same, (p > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
     assert np.array_equal(np.isnan(vp.cpu().numpy()), np.isnan(rp)) and np.array_equal(np.isnan(vn.cpu().numpy()), np.isnan(rp))
     x[11] = W + 2.0
-    with pytest.raises(IndexError):
+    with pytest.raises(IndexError):      # device tensors in, device grids out: reported as events_to_voxel_torch does
         V.events_to_neg_pos_voxel_torch(*cols(), B, sensor_size=(H, W))
+        E.check_errors()
+    with pytest.raises(IndexError):      # host tensors: before the call returns
+        V.events_to_neg_pos_voxel_torch(*(torch.from_numpy(a) for a in (x, y, t, p)), B, sensor_size=(H, W))
 
 
 def test_objective_at_1080p_and_three_planes(E):
