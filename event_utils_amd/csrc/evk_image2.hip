@@ -5,23 +5,26 @@
 // event -- i.e. 1-3.5 % of the 12 B/event HBM roofline.  Here the events take the voxel grid's route: k_part_sorted
 // (evk_part2.h) sorts sub-chunks of 8 K consecutive events by output tile in LDS and writes each one back as a contiguous
 // run of records, plus a (sub-chunk, tile) table; a tile kernel then pulls every tile's ~16-record segments out of the runs
-// and accumulates in LDS.  12 B/event are read (x, y, weight), 4 (nearest) or 12 (bilinear) written and read once more.
+// and accumulates in LDS.  12 B/event are read (x, y, weight), 4 (nearest) or 8 (bilinear) written and read once more -- plus
+// 4 for the exact float32 weight, only in sub-chunks that hold a weight the record cannot carry.
 //
 // Nearest: record = [31:11] top 21 bits of the weight | [10] wide | [9:0] cell (evk_part2.h, V2_FMT_IMGN).  The tile
 // kernel adds integers (int32 LDS atomics) whenever it can -- the integer image of the numpy path, which stays BIT-EXACT
 // with np.bincount, and float32 calls all of whose weights are +1, -1 or +0 (the partition kernel counts the others) -- and
 // float64 otherwise; every pixel of a tile is then written once (plain stores, no global atomics).
-// Bilinear: record = {x - tile x0, y - tile y0} + the weight (V2_FMT_IMGB); the tile's accumulator is a window one pixel
+// Bilinear: record = {x - tile x0, y - tile y0} as exact float32 (both >= 0), the weight's code -- +1, -1, +0, other -- in their
+// two sign bits; a sub-chunk with an "other" weight writes its float32 weights as a second dense run (V2_FMT_IMGB, evk_part2.h:
+// 8 B/event for the unit weights of real event streams instead of 12).  The tile's accumulator is a window one pixel
 // wider and higher than the tile (px + 1, py + 1 of its last column / row); the four products are evaluated in float32
 // in the reference's order (image.py:111-114) and added as int64 fixed point (2^-30 steps, unit weights) or float64; the
 // window's interior is added to the image with plain read-modify-writes, its one-pixel ring -- shared with the
 // neighbouring tiles' windows -- with global float atomics (2 (tw + th) of them per tile).
 //
-// A tile's segments are handed out one per LANE: with 4- and 8-byte records a segment of ~16 records is one or two cache
-// lines, which the lane fetches with 16-byte loads (four in flight) and accumulates itself.  Segments longer than
-// IMG_LONG records (clustered scenes, the pieces of a hot tile) are streamed by the whole wave.  Hot tiles are cut by the
-// partition kernel's plan exactly as for the voxel grid (pieces = ranges of sub-chunks, partial tiles summed by the last
-// piece to arrive, in piece order).
+// A tile's ~16-record segments are cut into 8-record chunks, listed per wave in LDS and handed to groups of 4 lanes, the next
+// round's loads in flight while a round is accumulated (img_records below: the scheme of k_voxel_tiles2 as a function template
+// over the record type).  (The first version gave every LANE one segment: 40 % idle lanes, the bilinear kernel VALU-bound at
+// 72 us against 30 us.)  Hot tiles are cut by the partition kernel's plan exactly as for the voxel grid (pieces = ranges of
+// sub-chunks, partial tiles summed by the last piece to arrive, in piece order; integer accumulators hand over exact values).
 #include "evk_part2.h"
 #include "evk_splat.h"
 
