@@ -567,7 +567,7 @@ def bench_image_10m(E, tiled, dev, impl):
 def bench_image_c1(E, tiled, dev, impl):
     """configs[0]: 1 M events, 240x180, events_to_image (nearest pixel, integer count) -- the plumbing / bit-exactness
     configuration (12 B/event at int32).  (a) the kernels on device-resident int32 columns, against the
-    12 B/event HBM roofline: the one-pass path the call takes above 320 k events, and the direct kernel; (b) the public
+    12 B/event HBM roofline: the one-pass path the call takes, and the direct kernel; (b) the public
     numpy-in / numpy-out call (host arrays: PCIe both ways, never a roofline figure)."""
     from event_utils_amd import _lib, _device as D
     n1, H1, W1 = 1_000_000, 180, 240
