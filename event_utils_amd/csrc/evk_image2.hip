@@ -53,7 +53,8 @@ struct SrcImgF32 {
     __device__ __forceinline__ int key_of(const uint32_t *r, int e, const TileGridG &g, uint32_t &cell) const {
         const float xf = __uint_as_float(r[e]), yf = __uint_as_float(r[4 + e]);
         const bool keep = !(xf >= clipx) & !(yf >= clipy);   // the mask multiplies the INDICES only (image.py:93-95)
-        return nearest_key_cell_int(keep ? (int)xf : 0, keep ? (int)yf : 0, (xf == xf) & (yf == yf), g, cell);
+        // (a masked event's indices are x.long() * 0 = 0 also when its other coordinate is NaN; an unmasked NaN raises)
+        return nearest_key_cell_int(keep ? (int)xf : 0, keep ? (int)yf : 0, !keep | ((xf == xf) & (yf == yf)), g, cell);
     }
     // Bilinear: tile of (floor(x), floor(y)) and the coordinates relative to that tile's origin.  -3 (xr, yr = x, y):
     // an event the LDS windows cannot take -- masked (it lands on pixel (0, 0) with weight w * 0), a pixel or its right /

@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_image_nearest_f32(const float *__
             // mask multiplies the INDICES only; the weight survives (image.py:93-95)
             const bool keep = !(xf >= clipx) && !(yf >= clipy);
             long long xi = keep ? (long long)xf : 0, yi = keep ? (long long)yf : 0;  // .long(): toward zero
-            if (xf == xf && yf == yf && wrap_index(xi, wd) && wrap_index(yi, h))
+            // (a MASKED event's indices are x.long() * 0 = 0 whatever x was -- also NaN, whose .long() is INT64_MIN: it lands
+            // on pixel (0, 0); an unmasked NaN is an index out of range)
+            if ((!keep || (xf == xf && yf == yf)) && wrap_index(xi, wd) && wrap_index(yi, h))
                 atomic_add(img + yi * wd + xi, wv.v[k]);
             else
                 count_oob(oob);

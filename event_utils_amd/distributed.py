@@ -41,6 +41,27 @@ def _collective_device(group=None):
     return torch.device("cpu")
 
 
+class _staged:
+    """`with _staged(t, group) as h:` -- h is the tensor a collective of `group`'s backend can take: `t` itself for nccl
+    (= RCCL, device buffers) or for host tensors; for gloo and a DEVICE tensor a host copy that is written back to `t` on
+    exit.  gloo moves host memory only (its device-tensor support covers two collectives and depends on the build), so an
+    event-sharded job on gloo -- two ranks sharing one GPU in the tests, machines without RCCL -- stages its grids
+    through the host: the same sums, PCIe instead of xGMI."""
+
+    def __init__(self, t, group=None, write_back=True):
+        self.t, self.write_back = t, write_back
+        self.host = t.is_cuda and _dist().get_backend(group) != "nccl"
+
+    def __enter__(self):
+        self.h = self.t.cpu() if self.host else self.t
+        return self.h
+
+    def __exit__(self, *exc):
+        if self.host and self.write_back and exc[0] is None:
+            self.t.copy_(self.h)
+        return False
+
+
 # ---- the C-ABI collective (include/evk.h: evk_comm_*, evk_allreduce_*) -------------------------------------------------
 _comms = {}
 
@@ -111,6 +132,10 @@ def reduce_scatter_all_gather_sum_(grid, group=None):
     world_size equal chunks; a tail that does not divide is handled by a small all-reduce)."""
     dist = _dist()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if grid.is_cuda and dist.get_backend(group) != "nccl":
+        with _staged(grid, group) as h:
+            reduce_scatter_all_gather_sum_(h, group)
+        return grid
     flat = grid.view(-1)
     chunk = flat.numel() // world
     if chunk:
@@ -147,7 +172,8 @@ def all_reduce_sum_(grid, group=None, force=False, form=None):
         fn = "evk_allreduce_f32" if grid.dtype == torch.float32 else "evk_allreduce_i32"
         _lib.call(fn, D.ptr(grid), grid.numel(), evk_comm(group), D.stream())
         return grid
-    dist.all_reduce(grid, op=dist.ReduceOp.SUM, group=group)
+    with _staged(grid, group) as h:
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     return grid
 
 
@@ -184,10 +210,13 @@ def banded_exchange(bands, out, group=None):
     behind the band's kernel), so it overlaps the accumulation of the bands that follow; the reduced bands are copied into
     `out` (B, H, W) at the end.  The same bytes as one all-reduce of the grid, in len(bands) pieces."""
     dist = _dist()
+    live = dist.is_available() and dist.is_initialized()
+    host = live and dist.get_backend(group) != "nccl"
     pending = []
     for y0, y1, band in bands:
-        work = dist.all_reduce(band, op=dist.ReduceOp.SUM, group=group, async_op=True) \
-            if (dist.is_available() and dist.is_initialized()) else None
+        if host and band.is_cuda:        # gloo: the band goes through the host (_staged); the copy waits for the band's kernel
+            band = band.cpu()
+        work = dist.all_reduce(band, op=dist.ReduceOp.SUM, group=group, async_op=True) if live else None
         pending.append((y0, y1, band, work))
     for y0, y1, band, work in pending:
         if work is not None:
@@ -229,11 +258,19 @@ def events_to_voxel_torch_sharded(xs, ys, ts, ps, B, sensor_size=(180, 240), gro
     from . import tiled
     oob = D.OobCounter(D.require_gpu(), poll=False)
     bands = None
-    if K >= 2 and n:
+    # Whether the exchange runs in bands -- K collectives of a band each instead of one of the grid -- must be the SAME
+    # decision on every rank, or the ranks' collectives differ in count and size: it depends on K, the grid and the
+    # library's tiling only, never on this rank's events.  A rank with an empty shard contributes zero bands with the same
+    # edges; columns the one-pass path cannot read in place (views that are not 16-byte aligned, other dtypes) are copied.
+    edges = tiled.voxel2_band_rows(H, W, B, K) if (K >= 2 and tiled.default_impl() != "direct") else None
+    if edges is not None:
         dev = D.require_gpu()
-        cols = [D.to_device(a, torch.float32, dev) for a in (xs, ys, ts, ps)]
-        if tiled.can_tile(cols, tiled.default_impl()):
+        if n:
+            cols = [D.to_device(a, torch.float32, dev).contiguous() for a in (xs, ys, ts, ps)]
+            cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]
             bands = tiled.voxel2_bands(cols, n, float(t_first), float(t_last), B, H, W, K, oob)
+        else:
+            bands = ((y0, y1, torch.zeros((B, y1 - y0, W), dtype=torch.float32, device=dev)) for y0, y1 in edges)
     if bands is not None:
         out = banded_exchange(bands, torch.empty((B, H, W), dtype=torch.float32, device=dev), group)
     else:
@@ -331,11 +368,13 @@ def sharded_evaluate_rows(local_iwe, rows_post, radius, mode, group=None):
         in_splits = [planes * (b[3] - b[2]) * cw for b in blocks]
         mine = planes * (hi - lo) * cw
         recv = torch.empty(world * mine, dtype=img.dtype, device=img.device)
-        dist.all_to_all_single(recv, send, [mine] * world, in_splits, group=group)
+        with _staged(recv, group) as hr, _staged(send, group, write_back=False) as hs:
+            dist.all_to_all_single(hr, hs, [mine] * world, in_splits, group=group)
         block = recv.view(world, planes, hi - lo, cw).sum(dim=0)   # rank order: the same sum on every run
     sums = rows_post(block.contiguous(), y0 - lo, y1 - lo)
     if world > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        with _staged(sums, group) as h:
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     return finalise_sums(sums.cpu().numpy(), ch * cw, mode)
 
 

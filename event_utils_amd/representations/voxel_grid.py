@@ -111,10 +111,12 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
     crossover both grids come from ONE pass over the events (EVK_VOXEL_SPLIT_POLARITY) instead of two voxelisations."""
     from ..events import DeviceEvents
     ev = xs if isinstance(xs, DeviceEvents) else None
+    raw_dev = None      # the device of raw tensors wrapped below: grids go back THERE by default, as upstream (xs.device)
     if (ev is None and temporal_bilinear and all(isinstance(a, torch.Tensor) for a in (xs, ys, ts, ps)) and len(xs)
             and xs.dtype == torch.int16 and ys.dtype == torch.int16 and ts.dtype == torch.float32
             and ps.dtype in (torch.uint8, torch.int8, torch.bool)):
         # int16 coordinates / 8-bit polarities as stored on disk (valid upstream too: ps > 0 / ps <= 0 on the stored values)
+        raw_dev = xs.device
         ev = DeviceEvents.from_native(xs, ys, ts, ps, polarity="literal", t_offset=0.0)
     if ev is not None:
         # resident events (ys, ts, ps ignored): the on-disk dtypes are partitioned as they are (9 / 13 B per event)
@@ -128,13 +130,16 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
         oob = D.OobCounter(ev.device)
         cols = (None,) * 4 if native is not None else (ev.x, ev.y, ev.t, ev.p)
         both = tiled.voxel_neg_pos_f32(*cols, ev.t_at(0), ev.t_at(-1), B, H, W, oob, native=native)
+        # where the grids go: resident DeviceEvents stay on the GPU; raw tensors get them on THEIR device (host tensors
+        # therefore synchronously, errors included -- the float path below and events_to_voxel_torch do the same)
+        target = device if device is not None else (raw_dev if raw_dev is not None else ev.device)
         if both is not None:
-            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),),
-                             deferrable=device is None or torch.device(device).type == "cuda")
-            both = both if device is None else both.to(device)
+            resident = (raw_dev is None or raw_dev.type == "cuda") and torch.device(target).type == "cuda"
+            oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),), deferrable=resident)
+            both = both.to(target)
             return both[0], both[1]
         x, y, t, p = ev.x, ev.y, ev.t, ev.p          # (widened once) -> the two-voxelisation route below
-        out_dev = ev.device if device is None else device
+        out_dev = target
         pos = events_to_voxel_torch(x, y, t, torch.where(p > 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,
                                     sensor_size=sensor_size)
         neg = events_to_voxel_torch(x, y, t, torch.where(p <= 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,

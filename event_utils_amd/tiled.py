@@ -43,7 +43,20 @@ TILED_MIN_EVENTS_NEG_POS = 1
 TILED_MIN_EVENTS_IWE = 150_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
-_staging_bytes = {}
+
+
+class _BoundedCache(dict):
+    """Size answers of the library keyed by (geometry, event count).  A stream of windows with ever-changing event counts
+    (voxel_grids_fixed_t, a live sensor) would add one entry per distinct count for ever: past 4096 entries the cache starts
+    over (an entry costs two cheap library calls to rebuild)."""
+
+    def __setitem__(self, k, v):
+        if len(self) >= 4096:
+            self.clear()
+        dict.__setitem__(self, k, v)
+
+
+_staging_bytes = _BoundedCache()
 
 
 def _buf(key, nbytes, device):
@@ -222,10 +235,11 @@ def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
     key = (ver, ntiles, n, planes, tw, th)
     sizes = _staging_bytes.get(key)
     if sizes is None:
-        sizes = _staging_bytes[key] = (int(getattr(L, "evk_%s_index_len" % ver)(ntiles, n)),
-                                       int(getattr(L, "evk_%s_scratch_bytes" % ver)(ntiles, n, planes, tw, th)))
+        sizes = (int(getattr(L, "evk_%s_index_len" % ver)(ntiles, n)),
+                 int(getattr(L, "evk_%s_scratch_bytes" % ver)(ntiles, n, planes, tw, th)))
         if sizes[0] <= 0:
             raise _lib.EvkError("evk_%s: unsupported geometry (%d tiles, %d events)" % (ver, ntiles, n))
+        _staging_bytes[key] = sizes
     index = _zbuf(ver + "_index", sizes[0], dev)
     scratch = _buf(ver + "_scratch", sizes[1], dev)
     flags = _lib.EVK_VOXEL_SPLIT_POLARITY if split_polarity else 0
@@ -243,6 +257,20 @@ def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
     return index, scratch, sizes[1], flags
 
 
+def voxel2_band_rows(H, W, B, nbands):
+    """Pixel-row ranges [(y_lo, y_hi), ...] of the row bands voxel2_bands cuts a (B, H, W) grid into (whole tile rows), or
+    None when the one-pass path has no tiling for this grid.  A function of the grid and the library's tiling ONLY: every
+    rank of an event-sharded run gets the same bands, whatever its own events are."""
+    shape = voxel2_shape(H, W, B)
+    if shape is None:
+        return None
+    th = shape[1]
+    tiles_y = -(-H // th)
+    nbands = max(1, min(int(nbands), tiles_y))
+    edges = [k * tiles_y // nbands for k in range(nbands + 1)]
+    return [(edges[k] * th, min(edges[k + 1] * th, H)) for k in range(nbands) if edges[k + 1] > edges[k]]
+
+
 def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
     """The one-pass voxel path in ROW BANDS (evk_voxel2_band_f32), for event-sharded runs: ONE partition, then the tile kernel
     of every band of tile rows launched on the current stream, each writing a contiguous (B, rows, W) buffer of its own.
@@ -255,9 +283,7 @@ def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
     tw, th = shape
     dev = cols[0].device
     index, scratch, nbytes, flags = _voxel2_env(dev, n, B, H, W, tw, th)
-    tiles_y = -(-H // th)
-    nbands = max(1, min(int(nbands), tiles_y))
-    edges = [k * tiles_y // nbands for k in range(nbands + 1)]
+    rows = voxel2_band_rows(H, W, B, nbands)
     report, seq = oob.report_args() if oob is not None else (None, 0)
     dummy = torch.empty(1, dtype=torch.float32, device=dev)      # (the partition does not touch the grid)
     _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, H, W, tw, th, t_first, t_last, B,
@@ -265,11 +291,8 @@ def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
               oob.ptr if oob is not None else None, report, seq, D.stream())
 
     def gen():
-        for k in range(nbands):
-            r0, r1 = edges[k], edges[k + 1]
-            if r1 <= r0:
-                continue
-            y0, y1 = r0 * th, min(r1 * th, H)
+        for y0, y1 in rows:
+            r0, r1 = y0 // th, -(-y1 // th)
             band = torch.empty((B, y1 - y0, W), dtype=torch.float32, device=dev)
             _lib.call("evk_voxel2_band_f32", n, H, W, tw, th, B, flags, r0, r1, D.ptr(band), D.ptr(index), D.ptr(scratch), nbytes,
                       D.stream())
@@ -326,10 +349,10 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     key = ("image2", ntiles, n, tw, th)
     sizes = _staging_bytes.get(key)
     if sizes is None:
-        sizes = _staging_bytes[key] = (int(L.evk_voxel2_index_len(ntiles, n)),
-                                       int(L.evk_image2_scratch_bytes(ntiles, n, tw, th)))
-        if sizes[0] <= 0:
+        sizes = (int(L.evk_voxel2_index_len(ntiles, n)), int(L.evk_image2_scratch_bytes(ntiles, n, tw, th)))
+        if sizes[0] <= 0:                 # (checked BEFORE it is cached: a later call with the same key must not skip this)
             return False
+        _staging_bytes[key] = sizes
     index = _zbuf("image2_index", sizes[0], dev)          # (its own: the header words [0], [1] mean something else here)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
     flags = stage | (_lib.EVK_VOXEL_OVERWRITE if (fresh and kind != "bilinear") else 0)

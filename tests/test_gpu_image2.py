@@ -133,6 +133,25 @@ def test_rare_events_take_the_direct_kernels_route(E):
         mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), accum="f64", **kw)
         got = E.events_to_image_torch(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), sensor_size=(H, W), **kw)
         assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag)
+    # a MASKED event whose other coordinate is NaN: its indices are x.long() * 0 = 0 (image.py:93-95) -- pixel (0, 0), with
+    # its weight, no error; both kernel families
+    import os
+    import warnings
+    xn, yn = x.copy(), y.copy()
+    xn[9500:9510] = np.float32(W + 1); yn[9500:9510] = np.nan
+    yn[9510:9520] = np.float32(H + 1); xn[9510:9520] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # (numpy's NaN -> int64 cast warns; the value is INT64_MIN as in torch)
+        ref = R.events_to_image_torch(xn, yn, p, sensor_size=(H, W), accum="f64", interpolation=None, padding=False)
+    mag = R.events_to_image_torch(x, y, np.abs(p), sensor_size=(H, W), accum="f64", interpolation=None, padding=False)
+    for impl in ("tiled", "direct"):
+        os.environ["EVK_IMPL"] = impl
+        try:
+            got = E.events_to_image_torch(torch.from_numpy(xn), torch.from_numpy(yn), torch.from_numpy(p), sensor_size=(H, W),
+                                          interpolation=None, padding=False)
+        finally:
+            os.environ["EVK_IMPL"] = "tiled"
+        assert np.max(np.abs(got.numpy().astype(np.float64) - ref)) <= 1e-5 * np.max(np.abs(ref)) + 2e-7 * np.max(mag), impl
     # without clipping the out-of-range events raise, as index_put_ does -- on both kernel families, with the same count
     xs, ys, ps = (torch.from_numpy(a) for a in (x, y, p))
     msgs = []
@@ -140,7 +159,6 @@ def test_rare_events_take_the_direct_kernels_route(E):
         with pytest.raises(IndexError) as ei:
             E.events_to_image_torch(xs, ys, ps, sensor_size=(H, W), clip_out_of_range=False, **kw)
         msgs.append(str(ei.value))
-    import os
     os.environ["EVK_IMPL"] = "direct"
     try:
         for i, kw in enumerate((dict(interpolation='bilinear', padding=False), dict(interpolation=None, padding=False))):
