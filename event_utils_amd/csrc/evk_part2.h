@@ -16,7 +16,12 @@ namespace evk {
                              // +0 (cumulative), [6] its value after the previous call, [7] 1 if THIS call had any
 #define V2_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
 #define V2_TOTALS V2_HDR
-#define V2_PART (V2_HDR + V2_MAX_TILES)            // part_start[T + 1]
+// words of the LIVE hand-over (evk_voxel_live.h), at a FIXED place whatever the tiling and the event count -- a buffer that
+// serves calls of several shapes must never show these kernels a word that something else wrote there:
+// progress[256] (one per partition workgroup), status[V2_MAX_TILES] (one per tile)
+#define V2_LIVE_PROGRESS (V2_HDR + V2_MAX_TILES)
+#define V2_LIVE_STATUS (V2_LIVE_PROGRESS + 256)
+#define V2_PART (V2_LIVE_STATUS + V2_MAX_TILES)    // part_start[T + 1]
 #define V2_COUNTER(T) (V2_PART + (T) + 1)          // counters[T]   (split-tile combine)
 #define V2_ITEM(T) (V2_PART + 2 * (T) + 1)         // item_tile[max_items]
 #ifndef V2_LB
@@ -173,14 +178,23 @@ struct Part2 {
 #define V2_CODE_SHIFT 10
 // bytes of LDS per event of the sorted buffer
 __host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : (rec == V2_FMT_VOX8W ? 12 : rec); }
-template <int THREADS, int EPT, int REC, typename C>
+// LIVE (round 5; evk_voxel_live.hip): the runs are consumed WHILE the partition is still sorting, by a second kernel on a
+// second stream (k_voxel_live: two tiles per workgroup, one workgroup per CU beside this kernel's).  What that needs here:
+// the table row of a sub-chunk leaves with its run, as write-through 16-byte stores out of an LDS copy (plain 4-byte stores
+// from the scan stay in this XCD's L2 until the kernel ends); and when every wave has drained the stores of run j -- the
+// wait in front of pass j + 1's placement, then that pass's closing barrier -- one lane publishes
+// {epoch, runs of this workgroup that are out} in `live_progress[blockIdx.x]` (an agent-scope store: the hand-over form
+// "write-through payload, drained, flag" of MI355X_MICROARCH.md).  Nothing else changes; without LIVE the code is what it was.
+template <int THREADS, int EPT, int REC, typename C, bool LIVE = false>
 __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n, TileGridG g, int ntiles, Part2 q, float t_first,
                                                             float t_last, float bm1, int t_from_events,
                                                             void *__restrict__ rec_, void *__restrict__ side_,
                                                             uint32_t *__restrict__ bases,
                                                             uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                             uint32_t cap, uint32_t part, uint32_t *oob, uint32_t *host_report,
-                                                            uint32_t seq) {
+                                                            uint32_t seq, uint32_t *live_progress = nullptr,
+                                                            uint32_t live_epoch = 0) {
+    static_assert(!LIVE || (REC == 8 && V2_STORE_SC1), "the live consumer reads 8-byte records written through");
     static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_VOX8W, "record format");
     constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
     constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB;   // exact weights staged in LDS, dense side run on demand
@@ -200,6 +214,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     uint32_t *tmp = tot + ((ntiles + 4) & ~3);                                  // [72] scan scratch; [67] escapes of the pass;
                                                                                 // [65] IMGN: the pass has a wide weight; [66], [68]:
                                                                                 // the workgroup's wide / non-unit weights
+    uint32_t *trow_l = tmp + 72 + 4;                                            // LIVE: [nt_pad] the table row of the current pass (16-byte aligned)
     uint32_t *sorted4 = reinterpret_cast<uint32_t *>(smem);                     // REC 4 / IMGN: the same buffer, one word per record
     // IMGB: the weights, behind the 8-byte records; IMGN: the exact weights, behind the one-word records
     uint32_t *sortedp = reinterpret_cast<uint32_t *>(smem + (size_t)THREADS * EPT * (REC == V2_FMT_IMGN ? 4 : 8));
@@ -269,6 +284,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     // write-out 11.3 us + closing barrier 14.5 us of a 52 us kernel; a scan by one wave 13 us.)
     uint32_t kept_prev = 0;   // records of the previous pass's run (uniform)
     int64_t lo_prev = 0;
+    int sc_prev = 0;          // LIVE: its sub-chunk
     // one contiguous, coalesced run of `n16` 16-byte pieces from the sorted buffer
     auto store_run = [&](const uint4 *src, uint4 *dst, const int n16) {
         if constexpr (REC != 4 && V2_STORE_SC1) {
@@ -300,6 +316,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 store_run(src, reinterpret_cast<uint4 *>(rec + lo_prev), (int)((kept_prev + 1) >> 1));
             else
                 store_run(src, reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev), (int)((kept_prev + 3) >> 2));
+            if constexpr (LIVE)   // the run's table row (LDS copy, whole 16-byte pieces: nt_pad % 16 == 0), written through as well
+                store_run(reinterpret_cast<const uint4 *>(trow_l), reinterpret_cast<uint4 *>(table + (int64_t)sc_prev * q.nt_pad), q.nt_pad >> 2);
             if constexpr (STAGE_W) {
                 // the exact weights of the run, as a second run at the records' indices -- only when one of them does not fit
                 // its record (tmp[65], set by the placement; cleared by the next pass's scan, i.e. after every wave has been
@@ -390,7 +408,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                     cur[i] = start;
                     hist[i] = 0;            // zero again for the next pass (this thread is the only one touching it now)
                     tot[i] += cnt;
-                    trow[i] = start | (cnt << 16);
+                    if constexpr (LIVE) trow_l[i] = start | (cnt << 16);
+                    else trow[i] = start | (cnt << 16);
                 }
                 kept += __shfl(wi, NWV - 1, 64);
                 if (base + THREADS < ntiles) lds_barrier();   // tmp is reused by the next round
@@ -546,11 +565,18 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         }
         V2_T(5);
         lds_barrier();   // the sorted sub-chunk is complete
+        if constexpr (LIVE) {
+            // every wave waited for its stores of the PREVIOUS run (and its table row) in front of this placement: that run is
+            // out.  runs published = sc - sc0.
+            if (sc > sc0 && tid == 0)
+                __hip_atomic_store(live_progress + blockIdx.x, (live_epoch << 8) | (uint32_t)(sc - sc0), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
         V2_T(6);
         EVK_WAIT_VM0();   // x, y of the next sub-chunk have landed during the placement: the stores below (next pass, or the
                           // epilogue) then never sit between a load and its use
         V2_T(7);
-        kept_prev = kept, lo_prev = lo;
+        kept_prev = kept, lo_prev = lo, sc_prev = sc;
     }
     // ---- totals -> global (the last block to arrive builds the work-item plan), issued AHEAD of the last run's stores so
     //      that the two drain together
@@ -588,6 +614,11 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         }
     }
     EVK_HANDOVER_DRAIN();
+    if constexpr (LIVE) {   // the last run is out (every wave drained its stores above)
+        if (sc0 < sc_end && tid == 0)
+            __hip_atomic_store(live_progress + blockIdx.x, (live_epoch << 8) | (uint32_t)(sc_end - sc0), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
     // Everything the last block reads from the others -- tile totals, dropped-event count, wide-record count -- was written
     // with AGENT-SCOPE ATOMICS and is read with agent-scope atomic loads: performed at the level all XCDs share, and complete
     // (vmcnt) only when they are.  Every wave has drained its own (the wait above), so the ticket needs NO release / acquire
@@ -683,8 +714,9 @@ static const V2Config &v2_config(bool share = false, int ntiles = 0) {
 #define V2_MIN_SUBCHUNK 8192
 #define V2_LDS_LIMIT (160 * 1024 - 512)   // (the partition kernel also has a few bytes of static LDS)
 // LDS of the partition kernel: sorted records | counts | cursors | totals | scan scratch
-static size_t v2_part_lds(int threads, int ept, int rec, int ntiles) {
-    return (size_t)threads * ept * v2_fmt_lds_bytes(rec) + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 72 * 4 + 16;
+static size_t v2_part_lds(int threads, int ept, int rec, int ntiles, bool live = false) {
+    return (size_t)threads * ept * v2_fmt_lds_bytes(rec) + 16 + 3 * (size_t)((ntiles + 4) & ~3) * 4 + 72 * 4 + 16 +
+           (live ? (size_t)((ntiles + 15) & ~15) * 4 + 16 : 0);   // LIVE: the table row's LDS copy (nt_pad words)
 }
 
 static Part2 v2_geometry(int64_t n, int ntiles, bool share = false) {
@@ -757,21 +789,22 @@ static V2Layout v2_layout(int ntiles, int64_t n, int planes, int tw, int th, boo
     return L;
 }
 
-template <int THREADS, int EPT, int REC, typename C>
+template <int THREADS, int EPT, int REC, typename C, bool LIVE = false>
 static void launch_part(const C &c, int64_t n, const TileGridG &g, int ntiles, const Part2 &q, float t_first, float t_last,
                         float bm1, int t_from_events, void *rec, void *pw, uint32_t *bases, uint32_t *table, uint32_t *index,
-                        uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s) {
-    const size_t lds = v2_part_lds(THREADS, EPT, REC, ntiles);
+                        uint32_t *oob, uint32_t *host_report, uint32_t seq, hipStream_t s, uint32_t *live_progress = nullptr,
+                        uint32_t live_epoch = 0) {
+    const size_t lds = v2_part_lds(THREADS, EPT, REC, ntiles, LIVE);
     static std::once_flag once[64];   // per device and instantiation: the attribute belongs to the loaded code object
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {   // (the kernel also has a few bytes of static LDS: ask for less than the full 160 KiB)
-        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, REC, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_part_sorted<THREADS, EPT, REC, C, LIVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 256);
     });
-    k_part_sorted<THREADS, EPT, REC, C><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
-                                                                    rec, pw, bases, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
-                                                                    host_report, seq);
+    k_part_sorted<THREADS, EPT, REC, C, LIVE><<<q.nblk, THREADS, lds, s>>>(c, n, g, ntiles, q, t_first, t_last, bm1, t_from_events,
+                                                                          rec, pw, bases, table, index, (uint32_t)v2_cap(n, ntiles), (uint32_t)v2_part(n, ntiles), oob,
+                                                                          host_report, seq, live_progress, live_epoch);
 }
 
 }  // namespace evk

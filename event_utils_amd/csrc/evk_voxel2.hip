@@ -20,7 +20,12 @@
 // Hot tiles (clustered data): every partition block adds its per-tile counts to global totals; the LAST block to
 // finish (a relaxed ticket: everything it reads from the others is an agent-scope atomic, no fence) builds the work-item
 // plan -- a tile with more than 2.5 x the mean is cut into pieces of 1.25 x the mean, by sub-chunk range.
+#include <atomic>
+
+#include <hip/hip_ext.h>
+
 #include "evk_part2.h"
+#include "evk_voxel_live.h"
 
 namespace evk {
 
@@ -52,7 +57,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                                                      const uint32_t *__restrict__ bases,
                                                      const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
                                                      TileGridG g, Part2 q, int B, int flags, float *__restrict__ vox,
-                                                     float *__restrict__ staging, Band band) {
+                                                     float *__restrict__ staging, Band band, uint32_t *live_status = nullptr,
+                                                     uint32_t live_epoch = 0) {
     constexpr int NW = WG / 64, E = V2_ENT(REC);
     // REC 8: a lane takes 16 bytes = 2 records {t_norm, polarity | cell}; REC 4: 8 bytes = 2 one-word records (k_part_sorted),
     // decoded with the base of their sub-chunk, which travels with the chunk list
@@ -104,6 +110,15 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         first_item = part_start[tile], nparts = part_start[tile + 1] - first_item;
     }
     const uint32_t part_id = item - first_item;
+    if (live_status) {
+        // LIVE call (evk_voxel_live.h): the consumer kernel on the second stream has accumulated this tile while the
+        // partition was sorting -- then there is nothing to do here -- unless it LEFT it (a polarity that is not a unit, a hot
+        // tile, a round that did not arrive in time) or never came: then the tile is accumulated here, as ever
+        __shared__ int live_mine;
+        if (threadIdx.x == 0) live_mine = v2l_tile_is_mine(live_status + tile, live_epoch) ? 1 : 0;
+        __syncthreads();
+        if (!live_mine) return;
+    }
     const int tx0 = (tile % g.tiles_x) * tw, ty0 = (tile / g.tiles_x) * th;
     // (64-bit fixed-point cells as in k_iwe_tiled -- ds_add_u64 is the faster LDS atomic -- with the scale from a max |p|
     // the partition kernel collects: no faster here (33.9 vs 34.6 us at 10 M events, 152.6 vs 148 us at 50 M) and the
@@ -675,7 +690,7 @@ using namespace evk;
 
 extern "C" int64_t evk_voxel2_index_len(int ntiles, int64_t n) {
     if (ntiles <= 0 || ntiles > V2_MAX_TILES || n < 0) return 0;
-    return (int64_t)V2_ITEM(ntiles) + v2_max_items(n, ntiles);
+    return (int64_t)V2_ITEM(ntiles) + v2_max_items(n, ntiles);   // (header, totals, the live words, then the plan)
 }
 
 extern "C" int64_t evk_voxel2_scratch_bytes(int ntiles, int64_t n, int planes, int tile_w, int tile_h) {
@@ -729,7 +744,7 @@ extern "C" int evk_voxel2_max_tiles(void) {
 template <int WG, int U, bool SPLIT, bool FIXED, int REC>
 static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *rec, const void *pw, const uint32_t *bases,
                          const uint32_t *table, uint32_t *index, const TileGridG &g, const Part2 &q, int B, int kf, float *vox,
-                         float *staging, const Band &band) {
+                         float *staging, const Band &band, uint32_t *live_status = nullptr, uint32_t live_epoch = 0) {
     static std::once_flag once[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -737,7 +752,43 @@ static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *r
         (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED, REC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP(WG) - 256);
     });
-    k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);
+    k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging, band,
+                                                                        live_status, live_epoch);
+}
+
+// ---- LIVE calls (evk_voxel_live.h): the second stream, the epoch counter, what a call must look like --------------------
+#ifndef V2L_U
+#define V2L_U 2   // chunk loads per lane in flight in a stage of the consumer's pipeline (two stages: 4 x 16 bytes per lane)
+#endif
+static hipStream_t v2_live_stream() {
+    static std::once_flag once[64];
+    static hipStream_t side[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [dev] {
+        side[dev & 63] = nullptr;
+        if (hipStreamCreateWithFlags(&side[dev & 63], hipStreamNonBlocking) != hipSuccess) side[dev & 63] = nullptr;
+        (void)hipFuncSetAttribute((const void *)k_voxel_live<V2L_U>, hipFuncAttributeMaxDynamicSharedMemorySize, V2L_LDS_REQUEST);
+    });
+    return side[dev & 63];
+}
+static uint32_t v2_live_epoch() {
+    static std::atomic<uint32_t> counter{0};
+    uint32_t e;
+    do e = (counter.fetch_add(1, std::memory_order_relaxed) + 1u) & V2L_EPOCH_MASK; while (e == 0u);
+    return e;
+}
+// bytes of static LDS of k_voxel_live (chunk lists, poison bits, a few words)
+#define V2L_STATIC_LDS (V2L_NW * V2L_CAP * 8 + 2 * ((1 << V2_LB) / 32) * 4 + 64)
+// can this call run live?  (the geometry the consumer kernel is written for: <= 2 x 256 tiles, 8-byte records in the 8 K-event
+// partition geometry, <= 255 runs per partition workgroup, the accumulators of two tiles beside the chunk lists, and the
+// partition's and the consumer's LDS together on one CU)
+static bool v2_live_fits(const TileGridG &g, int ntiles, const Part2 &q, int64_t n, int B, int recb, const V2Config &cfg) {
+    const size_t acc = (size_t)2 * B * g.pitch * g.th * 8;
+    return recb == 8 && cfg.threads == 1024 && cfg.ept == 8 && ntiles <= 2 * EVK_NUM_CU && q.nblk <= V2L_PROGRESS_WORDS &&
+           q.per_block >= 2 && q.per_block <= 255 && n < ((int64_t)1 << 28) && (int64_t)q.nsc * q.S * 8 < ((int64_t)1 << 32) &&
+           acc + V2L_STATIC_LDS <= (size_t)V2L_LDS_REQUEST &&
+           v2_part_lds(1024, 8, 8, ntiles, true) + 256 + V2L_LDS_REQUEST <= (size_t)160 * 1024;
 }
 
 template <typename C>
@@ -747,7 +798,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC |
-                      EVK_VOXEL2_REC4 | EVK_VOXEL2_REC8 | EVK_VOXEL2_NO_COUNT | EVK_VOXEL2_WG512;
+                      EVK_VOXEL2_REC4 | EVK_VOXEL2_REC8 | EVK_VOXEL2_NO_COUNT | EVK_VOXEL2_WG512 | EVK_VOXEL2_LIVE;
     if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
         n > (int64_t)4000000000LL || (flags & ~known))
         return EVK_EINVAL;
@@ -771,7 +822,34 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     const float bm1 = (float)(B - 1);
     const int tfe = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     const int recb = v2_rec_bytes(n, flags);
-    if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
+    // LIVE (evk_voxel_live.h): partition on this stream, the consumer kernel on the library's second stream, then the tile
+    // kernel proper here for whatever the consumers leave.  A request, not a demand: calls the consumer kernel is not written
+    // for (other geometries, split polarities, shared CUs, single stages, a stream that is being captured) run as ever.
+    bool live = false;
+    hipStream_t s2 = nullptr;
+    uint32_t epoch = 0;
+    if constexpr (std::is_same<C, SrcF32>::value) {
+        if ((flags & EVK_VOXEL2_LIVE) && band.tile_hi == 0 &&
+            !(flags & (EVK_VOXEL2_PARTITION_ONLY | EVK_VOXEL2_TILES_ONLY | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL2_SHARE_CU |
+                       EVK_VOXEL2_NO_COUNT)) &&
+            v2_live_fits(g, ntiles, q, n, B, recb, cfg)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone && (s2 = v2_live_stream()) != nullptr)
+                live = true, epoch = v2_live_epoch();
+            else
+                (void)hipGetLastError();
+        }
+    }
+    uint32_t *const live_progress = index + V2_LIVE_PROGRESS, *const live_status = index + V2_LIVE_STATUS;
+    if (live) {
+        if constexpr (std::is_same<C, SrcF32>::value) {
+            launch_part<1024, 8, 8, C, true>(c, n, g, ntiles, q, t_first, t_last, bm1, tfe, rec, pw, bases, table, index, oob,
+                                             host_report, seq, s, live_progress, epoch);
+            LiveArgs la{live_progress, live_status, epoch, (uint32_t)v2_cap(n, ntiles), 400u};
+            k_voxel_live<V2L_U><<<(ntiles + 1) / 2, V2L_WG, V2L_LDS_REQUEST - V2L_STATIC_LDS, s2>>>(
+                rec, (uint32_t)((int64_t)q.nsc * q.S * 8), table, g, q, B, flags & EVK_VOXEL_OVERWRITE, vox, la);
+        }
+    } else if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
         // (8-byte records in the 8 K-event geometry of a call that has its CUs to itself: the exact polarities are staged in
         // LDS and wide ones leave as a dense run -- V2_FMT_VOX8W, evk_part2.h)
 #ifndef V2_USE_VOX8W
@@ -816,11 +894,12 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
 #define V2_UU(R) ((R) == 4 ? V2_U4 : V2_U8)
 #define V2_TILES(W, R)                                                                                                     \
     do {                                                                                                                   \
-        if (sp && fx) launch_tiles<W, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
-        else if (sp) launch_tiles<W, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
-        else if (fx) launch_tiles<W, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);   \
-        else launch_tiles<W, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band);          \
+        if (sp && fx) launch_tiles<W, V2_UU(R), true, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band, lst, epoch);   \
+        else if (sp) launch_tiles<W, V2_UU(R), true, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band, lst, epoch);   \
+        else if (fx) launch_tiles<W, V2_UU(R), false, true, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band, lst, epoch);   \
+        else launch_tiles<W, V2_UU(R), false, false, R>(items, lds_dyn, s, rec, pw, bases, table, index, g, q, B, kf, vox, staging, band, lst, epoch);          \
     } while (0)
+        uint32_t *const lst = live ? live_status : nullptr;
         // Threads per tile workgroup.  8-byte records (cache-resident calls): 768 -- twelve waves per tile -- while TWO such
         // workgroups fit a CU's LDS (accumulators + 12 chunk lists <= 80 KB: VGA at 5 bins; not split polarities or 720p
         // tiles).  Uniform events do not care (29.5 us either way, 512 tiles in one generation); the pieces of a hot tile are

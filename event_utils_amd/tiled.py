@@ -23,8 +23,10 @@ def default_impl():
 #   iwe_records  "auto" | "compact" | "full"   8-byte compact records of the bucketed IWE path
 #   iwe_fixed    True | False       64-bit fixed-point LDS windows of the IWE kernels (False: float64)
 #   image_fixed  True | False       fixed-point windows of the bilinear image tile kernel for unit weights
+#   live         None | True | False   the voxel tiles accumulated while the partition sorts (EVK_VOXEL2_LIVE; None: only
+#                                   with EVK_VOXEL_LIVE=1 -- measured SLOWER than the two launches)
 FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu": None, "iwe_records": "auto",
-         "iwe_fixed": True, "image_fixed": True}
+         "iwe_fixed": True, "image_fixed": True, "live": None}
 
 
 # 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, profiles/r04_small_calls.txt; tools/crossover.py,
@@ -41,6 +43,10 @@ TILED_MIN_EVENTS = 1
 TILED_MIN_EVENTS_NATIVE = 1
 TILED_MIN_EVENTS_NEG_POS = 1
 TILED_MIN_EVENTS_IWE = 150_000
+# EVK_VOXEL2_LIVE (round 5) is NOT a default: at 10 M events the live call takes 0.085 ms against 0.072 ms for the two launches
+# (profiles/r05_live_ab.txt).  EVK_VOXEL_LIVE=1 requests it from this many events (fewer than ~3 sub-chunks per partition
+# workgroup leave the consumer kernel nothing to overlap; the library itself refuses calls it cannot run live)
+LIVE_MIN_EVENTS = 6_000_000
 _WIN_MAX = {1: 64, 3: 48}       # LDS window edge cap (f64 cells): 64x64x8 B = 32 KB; 3 planes x 48x48x8 B = 54 KB
 _persist = {}
 
@@ -252,6 +258,11 @@ def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
         flags |= _lib.EVK_VOXEL2_NO_COUNT
     if FORCE["tiles_wg"] == 512:
         flags |= _lib.EVK_VOXEL2_WG512
+    live = FORCE["live"]
+    if live is None:
+        live = n >= LIVE_MIN_EVENTS and os.environ.get("EVK_VOXEL_LIVE", "0") == "1"
+    if live and not split_polarity and not (flags & 128):
+        flags |= _lib.EVK_VOXEL2_LIVE
     if voxel_deterministic():
         flags |= _lib.EVK_VOXEL_DETERMINISTIC
     return index, scratch, sizes[1], flags

@@ -355,6 +355,15 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 #define EVK_VOXEL2_REC8 2048
 #define EVK_VOXEL2_NO_COUNT 4096
 #define EVK_VOXEL2_WG512 8192
+/* EVK_VOXEL2_LIVE (round 5): the tiles are accumulated WHILE the partition sorts -- a consumer kernel on a second stream of the
+ * library's own (one per device, created on first use) takes every run as soon as it is written, two tiles per workgroup, one
+ * workgroup beside the partition's on every CU; the tile kernel proper still follows on `stream` and accumulates only what
+ * the consumers leave (polarities other than +1 / -1 / +0, hot tiles, rounds that did not arrive in time), so the call is
+ * complete in `stream`'s order exactly as without the flag, and the grid is bit-identical to the counting mode's.  A request:
+ * calls the consumer kernel is not written for (more than 512 tiles, accumulators beyond 52 KB per pair of tiles, fewer than
+ * two sub-chunks per partition workgroup, 4-byte records, split polarities, EVK_VOXEL2_SHARE_CU, single stages, a stream that
+ * is being captured into a graph) run as without it.  evk_voxel2_f32 only. */
+#define EVK_VOXEL2_LIVE 16384
 int evk_voxel2_max_tiles(void);
 int64_t evk_voxel2_index_len(int ntiles, int64_t n);
 int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h);   /* 0 = this tiling is not supported */

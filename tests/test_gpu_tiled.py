@@ -788,3 +788,47 @@ def test_voxel_on_bucketed_records_entry_point(E):
         _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), n, H, W, tw, th, float(t[0]), float(t[-1]), B,
                   _lib.EVK_VOXEL_OVERWRITE, D.ptr(out), D.ptr(staging), nbytes, D.stream())
         close(out.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+
+
+@pytest.mark.timeout(300)
+def test_live_voxel_call_is_bit_identical_to_the_two_launches(E, monkeypatch):
+    """EVK_VOXEL2_LIVE (evk_voxel_live.h; opt-in: measured slower than the two launches it overlaps): the
+    consumer kernel on the library's second stream accumulates the tiles while the partition sorts, the tile kernel proper
+    only what it LEAVES.  Same integer sums as the counting mode: the grid equals the two-launch grid bit for bit -- on
+    uniform events (every tile done by the consumers), on a blob (hot tiles left to the plan's pieces), with arbitrary
+    polarities (everything left), with time stamps out of order (edge bins), over repeated calls on the same buffers (a
+    stale record, table row or status word of the previous call would show), and against the oracle."""
+    tiled = _tiled()
+    H, W, B, n = 480, 640, 5, 5_000_000
+    rng = np.random.default_rng(77)
+
+    def grids(cols):
+        out = []
+        for live in (True, False, True):
+            monkeypatch.setitem(tiled.FORCE, "live", live)
+            out.append(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)))
+        torch.cuda.synchronize()
+        return out
+    for k, kind in enumerate(("uniform", "uniform", "blob", "float polarity", "unsorted", "uniform")):
+        x, y, t, p = _events(100 + k, n, H, W)
+        if kind == "blob":
+            hot = rng.random(n) < 0.5
+            x[hot] = (200 + rng.integers(0, 60, hot.sum())).astype(np.float32)
+            y[hot] = (100 + rng.integers(0, 60, hot.sum())).astype(np.float32)
+        elif kind == "float polarity":
+            p = (p * rng.uniform(0.1, 3.0, n)).astype(np.float32)
+        elif kind == "unsorted":
+            t = rng.permutation(t); t[0], t[-1] = 0.02, 0.08
+        cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+        a, b, c = grids(cols)
+        assert torch.equal(a, c), kind
+        if kind == "float polarity":       # (the two-launch call stages exact polarities differently: same values, float64 sums)
+            assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item(), kind
+        else:
+            assert torch.equal(a, b), kind
+        if kind in ("uniform", "blob") and k != 1:
+            close(a.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+    # who did the work: on uniform events every tile was finished by a consumer (status word = epoch << 2 | DONE)
+    idx = [v for key, v in tiled._zpersist.items() if key[0] == "voxel2_index"][0].cpu().numpy().astype(np.uint32)
+    status = idx[8 + 2048 + 256: 8 + 2048 + 256 + 512]
+    assert np.all((status & 3) == 2) and len(np.unique(status >> 2)) == 1, np.unique(status & 3, return_counts=True)
