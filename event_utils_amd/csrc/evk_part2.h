@@ -28,6 +28,7 @@ namespace evk {
 #define V2_LB 10  // bits of the pixel-in-tile field (tiles of <= 2^V2_LB pixels); the polarity keeps 32 - V2_LB - 1 bits
 #endif
 #define EVK_VOXEL2_COUNT (1 << 20)   // kernel-internal flag: the launch has the LDS of the counting mode (k_voxel_tiles2)
+#define EVK_VOXEL2_COUNT2 (1 << 21)  // kernel-internal flag: unit polarities are counted in the B planes of the float64 mode
 #define V2_LOCAL_MASK ((1u << V2_LB) - 1u)
 #define V2_WIDE (1u << V2_LB)
 #define V2_P_MASK (~((2u << V2_LB) - 1u))

@@ -140,6 +140,13 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     __shared__ uint32_t poison[(1 << V2_LB) / 32];
     constexpr bool COUNTING = !SPLIT;   // (also in the EVK_VOXEL_DETERMINISTIC instantiation: the counting mode IS deterministic)
     const bool unit = COUNTING && (flags & EVK_VOXEL2_COUNT) && index[7] == 0u;
+    // UNIT-POLARITY COUNTING IN B PLANES (round 5, EVK_VOXEL2_COUNT2): the same integer sums with TWO int64 atomics per event --
+    // p 2^31 - fx to bin b0 and fx to bin b0 + 1, fx = (int)(p f 2^31), i.e. S0[b0] 2^31 - G[b0] formed per event -- in the B
+    // planes the float64 mode has: no extra LDS, so the tiles of a 1280x720 call (38x24 pixels: 37 KB, where the planes above
+    // would need 64 KB and leave ONE workgroup per CU) count in integers as well: ds_add_u64 is the faster LDS atomic (4.1
+    // against 2.9 lane-operations per clock and CU), no float64 multiply-adds, and the grid is bit-reproducible and equal,
+    // bit for bit, to the other counting mode's.
+    const bool unit2 = COUNTING && !unit && (flags & EVK_VOXEL2_COUNT2) && index[7] == 0u;
     int *const s0 = reinterpret_cast<int *>(acc + (B + 1) * ppix);   // unit mode: acc = G[-1 .. B-1], then S0[0 .. B-1]
     V2_U(0);
     unsigned long long *const gq = reinterpret_cast<unsigned long long *>(acc);   // unit mode: G as int64
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         if (threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
     } else {
         for (int i = threadIdx.x; i < NB * ppix; i += WG) acc[i] = 0.0;
-        if (FIXED && threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
+        if ((FIXED || unit2) && threadIdx.x < (1 << V2_LB) / 32) poison[threadIdx.x] = 0u;
     }
     V2_U(1);
     const int sc_lo = (int)(((int64_t)q.nsc * part_id) / nparts), sc_hi = (int)(((int64_t)q.nsc * (part_id + 1)) / nparts);
@@ -215,8 +222,20 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    // (B planes: bin 0 takes what G[-1] takes above, bin B - 1 what -G[B - 1] takes)
+    auto unit2_general = [&](int local, float tn, float p) {
+        if (tn != tn) {
+            __hip_atomic_fetch_or(poison + (local >> 5), 1u << (local & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        const float edge = tn < 0.0f ? 0.0f : bm1;
+        const float val = p * fmaxf(0.0f, 1.0f - fabsf(tn - edge));
+        if (val != 0.0f)
+            __hip_atomic_fetch_add(gq + (tn < 0.0f ? 0 : (B - 1) * ppix) + local, (unsigned long long)__double2ll_rn((double)val * G_ONE),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     auto one = [&](auto unit_tag, uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
-        constexpr bool UNIT = decltype(unit_tag)::value;
+        constexpr int UNIT = decltype(unit_tag)::value;   // 0: float64 / fixed-point cells, 1: S0 + G planes, 2: B int64 planes
         // REC 8: lo_w = t_norm bits, hi_w = polarity | cell.  REC 4: lo_w = the record word, hi_w = its sub-chunk's base.
         int local;
         float p, tn;
@@ -247,7 +266,22 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             if (tn * p == 1.2345e-30f) acc[local] = 1.0;
             return;
         }
-        if constexpr (UNIT) {
+        if constexpr (UNIT == 2) {
+            if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
+                const int b0 = (int)tn;
+                unsigned long long *cell = gq + __mul24(b0, ppix) + local;
+                const int fx = (int)((p * (tn - (float)b0)) * 2147483648.0f);
+                __hip_atomic_fetch_add(cell, (unsigned long long)(((long long)(int)p << 31) - (long long)fx), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (b0 + 1 == B only for t_norm == B - 1, where fx is 0)
+                __hip_atomic_fetch_add(cell + (b0 + 1 < B ? ppix : 0), (unsigned long long)(long long)fx, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                unit2_general(local, tn, p);
+            }
+            return;
+        }
+        if constexpr (UNIT == 1) {
             if (__builtin_expect(tr >= 0.0f && tr <= bm1, 1)) {
                 const int b0 = (int)tn;
                 const int off = __mul24(b0, ppix) + local;
@@ -565,10 +599,11 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     }
     };
     if constexpr (COUNTING) {
-        if (unit) batches(std::true_type{});
-        else batches(std::false_type{});
+        if (unit) batches(std::integral_constant<int, 1>{});
+        else if (unit2) batches(std::integral_constant<int, 2>{});
+        else batches(std::integral_constant<int, 0>{});
     } else {
-        batches(std::false_type{});
+        batches(std::integral_constant<int, 0>{});
     }
     V2_U(7);
     __syncthreads();
@@ -601,6 +636,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             const long long v = ((long long)s0[b * ppix + l] << 31) - (long long)gq[(b + 1) * ppix + l] + (long long)gq[b * ppix + l];
             return (float)((double)v * (1.0 / G_ONE));
         }
+        if (unit2) {
+            if ((poison[l >> 5] >> (l & 31)) & 1u) return __uint_as_float(0x7FC00000u);
+            return (float)((double)(long long)gq[b * ppix + l] * (1.0 / G_ONE));
+        }
         const acc_t a = acc[b * ppix + l];
         if constexpr (FIXED) {
             if ((poison[l >> 5] >> (l & 31)) & 1u) return __uint_as_float(0x7FC00000u);
@@ -628,8 +667,8 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // tiles were cut, i.e. it is bit-identical for any order of the events also on scenes with hot tiles.  (Round 3 staged
     // float32 partial tiles for every mode: a permuted stream moved events between the pieces and changed their roundings.)
     // LLONG_MIN marks a poisoned cell (NaN t_norm).
-    const bool exactq = unit || FIXED;
-    const double qscale = unit ? 1.0 / G_ONE : 1.0 / V2_FIXED_ONE;
+    const bool exactq = unit || unit2 || FIXED;
+    const double qscale = (unit || unit2) ? 1.0 / G_ONE : 1.0 / V2_FIXED_ONE;
     auto lds_cell_q = [&](int c) -> long long {
         int b, row, col;
         split_cell(c, b, row, col);
@@ -638,7 +677,7 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
             if ((poison[l >> 5] >> (l & 31)) & 1u) return (long long)0x8000000000000000ull;
             return ((long long)s0[b * ppix + l] << 31) - (long long)gq[(b + 1) * ppix + l] + (long long)gq[b * ppix + l];
         }
-        if (FIXED && ((poison[l >> 5] >> (l & 31)) & 1u)) return (long long)0x8000000000000000ull;
+        if ((FIXED || unit2) && ((poison[l >> 5] >> (l & 31)) & 1u)) return (long long)0x8000000000000000ull;
         return __builtin_bit_cast(long long, acc[b * ppix + l]);
     };
     float *mine = staging + 2 * (int64_t)item * stride;
@@ -798,7 +837,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     TileGridG g;
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL_SPLIT_POLARITY | EVK_VOXEL_T_FROM_EVENTS | EVK_VOXEL2_PARTITION_ONLY |
                       EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER | EVK_VOXEL2_SHARE_CU | EVK_VOXEL_DETERMINISTIC |
-                      EVK_VOXEL2_REC4 | EVK_VOXEL2_REC8 | EVK_VOXEL2_NO_COUNT | EVK_VOXEL2_WG512 | EVK_VOXEL2_LIVE;
+                      EVK_VOXEL2_REC4 | EVK_VOXEL2_REC8 | EVK_VOXEL2_NO_COUNT | EVK_VOXEL2_WG512 | EVK_VOXEL2_LIVE | EVK_VOXEL2_NO_COUNT2;
     if (make_grid_g(g, h, wd, tile_w, tile_h) != EVK_OK || B <= 0 || !vox || !index || !scratch || n <= 0 ||
         n > (int64_t)4000000000LL || (flags & ~known))
         return EVK_EINVAL;
@@ -915,6 +954,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         else if (may_wide && two_fit(lds_acc, 768, recb)) wg = 768;
         const size_t lds_dyn = count ? lds_count : lds_acc;
         if (count) kf |= EVK_VOXEL2_COUNT;
+        else if (may_count && !(flags & EVK_VOXEL2_NO_COUNT2)) kf |= EVK_VOXEL2_COUNT2;   // the same integers in the float64 mode's B planes
         const bool wide_wg = wg == 768;
         if (recb == 4) V2_TILES(512, 4);
         else if (wide_wg) V2_TILES(768, 8);

@@ -128,8 +128,9 @@ def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_
         img = torch.full(tuple(img_size), float(default), dtype=torch.float32, device=dev)
         _lib.call("evk_image_bilinear_f32" if bilinear else "evk_image_nearest_f32", D.ptr(xd), D.ptr(yd), D.ptr(pd), n,
                   img_size[0], img_size[1], clipx, clipy, D.ptr(img), oob.ptr, D.stream())
-    # events and image that stay on the device never wait for the host (the reference's own CUDA path reports an
-    # out-of-range index_put_ asynchronously too; EVK_ERRORS=strict synchronises every call)
+    # events and image that stay on the device: the default raises before returning, as upstream (one-pass path: the call
+    # waits for its partition kernel's report only); EVK_ERRORS=deferred never waits for the host (the reference's own CUDA
+    # path reports an out-of-range index_put_ asynchronously too)
     resident = xs.is_cuda and torch.device(device).type == "cuda"
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),), deferrable=resident)
     return img.to(device)

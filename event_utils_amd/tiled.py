@@ -17,6 +17,7 @@ def default_impl():
 # 512-thread tile workgroups, the unit-polarity counting mode -- and the tests must be able to run each of them at small sizes:
 #   rec          None | 4 | 8       record size of the one-pass voxel path (EVK_VOXEL2_REC4 / _REC8)
 #   count        True | False       unit-polarity counting mode of its tile kernel (EVK_VOXEL2_NO_COUNT)
+#   count2       True | False       ... in the float64 mode's planes where the counting mode's do not fit (EVK_VOXEL2_NO_COUNT2)
 #   tiles_wg     0 | 512            512-thread tile workgroups everywhere (EVK_VOXEL2_WG512)
 #   xcd_order    True | False       XCD-aware work-item order of the tile kernels (EVK_VOXEL2_NO_XCD_ORDER)
 #   share_cu     None | True | False   leave LDS for a collective's workgroups (None: yes in a multi-rank job)
@@ -26,7 +27,7 @@ def default_impl():
 #   live         None | True | False   the voxel tiles accumulated while the partition sorts (EVK_VOXEL2_LIVE; None: only
 #                                   with EVK_VOXEL_LIVE=1 -- measured SLOWER than the two launches)
 FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu": None, "iwe_records": "auto",
-         "iwe_fixed": True, "image_fixed": True, "live": None}
+         "iwe_fixed": True, "image_fixed": True, "live": None, "count2": True}
 
 
 # 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, profiles/r04_small_calls.txt; tools/crossover.py,
@@ -256,6 +257,8 @@ def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
     flags |= {None: 0, 4: _lib.EVK_VOXEL2_REC4, 8: _lib.EVK_VOXEL2_REC8}[FORCE["rec"]]
     if not FORCE["count"]:
         flags |= _lib.EVK_VOXEL2_NO_COUNT
+    if not FORCE.get("count2", True):
+        flags |= _lib.EVK_VOXEL2_NO_COUNT2
     if FORCE["tiles_wg"] == 512:
         flags |= _lib.EVK_VOXEL2_WG512
     live = FORCE["live"]

@@ -355,6 +355,9 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
 #define EVK_VOXEL2_REC8 2048
 #define EVK_VOXEL2_NO_COUNT 4096
 #define EVK_VOXEL2_WG512 8192
+#define EVK_VOXEL2_NO_COUNT2 32768   /* (A/B, tests) where the counting mode's planes do not fit (1280x720 tiles) unit polarities are
+                                        still counted in integers, two int64 LDS atomics per event in the float64 mode's planes
+                                        (same bits as the counting mode); this flag keeps the float64 atomics there */
 /* EVK_VOXEL2_LIVE (round 5): the tiles are accumulated WHILE the partition sorts -- a consumer kernel on a second stream of the
  * library's own (one per device, created on first use) takes every run as soon as it is written, two tiles per workgroup, one
  * workgroup beside the partition's on every CU; the tile kernel proper still follows on `stream` and accumulates only what

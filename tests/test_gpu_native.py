@@ -110,14 +110,15 @@ def test_voxel_from_on_disk_dtypes_matches_reference(E, golden, monkeypatch, imp
         E.events_to_voxel_torch(torch.from_numpy(g["xs"]), torch.from_numpy(g["ys"]), torch.from_numpy(g["ts"]),
                                 torch.from_numpy(g["ps"].astype(np.uint8)), B, sensor_size=ss)
     bad = g["xs"].copy(); bad[17] = ss[1] + 3
-    with pytest.raises(IndexError):      # resident events, device result: reported like the tensor route (_device.error_mode)
+    with pytest.raises(IndexError):      # resident events, device result: raised before the call returns (the default, as upstream)
         E.events_to_voxel_torch(E.DeviceEvents.from_native(bad, g["ys"], g["ts"], g["ps"]), None, None, None, B,
                                 sensor_size=ss)
+    E.check_errors()                     # (nothing left behind)
+    monkeypatch.setenv("EVK_ERRORS", "deferred")
+    v = E.events_to_voxel_torch(E.DeviceEvents.from_native(bad, g["ys"], g["ts"], g["ps"]), None, None, None, B, sensor_size=ss)
+    assert v.is_cuda                     # ... opt-in: the call only enqueues, the report is collected later
+    with pytest.raises(IndexError):
         E.check_errors()
-    monkeypatch.setenv("EVK_ERRORS", "strict")
-    with pytest.raises(IndexError):      # ... and before the call returns under EVK_ERRORS=strict
-        E.events_to_voxel_torch(E.DeviceEvents.from_native(bad, g["ys"], g["ts"], g["ps"]), None, None, None, B,
-                                sensor_size=ss)
 
 
 def test_voxel_native_at_scale_equals_float_columns(E, monkeypatch):

@@ -832,3 +832,35 @@ def test_live_voxel_call_is_bit_identical_to_the_two_launches(E, monkeypatch):
     idx = [v for key, v in tiled._zpersist.items() if key[0] == "voxel2_index"][0].cpu().numpy().astype(np.uint32)
     status = idx[8 + 2048 + 256: 8 + 2048 + 256 + 512]
     assert np.all((status & 3) == 2) and len(np.unique(status >> 2)) == 1, np.unique(status & 3, return_counts=True)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280)])
+def test_both_counting_modes_give_the_exact_sums(E, monkeypatch, shape):
+    """Unit polarities are accumulated as integers: an int32 count + an int64 fixed-point sum per bin where those planes fit
+    two workgroups per CU (640x480), two int64 atomics per event in the float64 mode's planes where they do not (1280x720:
+    EVK_VOXEL2_COUNT2, round 5).  With dyadic time stamps every contribution p (1 - f), p f is a multiple of 2^-8, both modes
+    hold the EXACT sums, and one rounding to float32 gives the float64 oracle's grid bit for bit -- for a permuted event order
+    too, and on a scene whose hot tiles are cut (the pieces hand over exact int64 cells)."""
+    tiled = _tiled()
+    H, W = shape
+    B, n = 5, 1_500_000
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    x[: n // 3] = 300 + (x[: n // 3] % 9); y[: n // 3] = 200 + (y[: n // 3] % 9)        # a hot spot: cut tiles
+    t = (np.sort(rng.integers(0, 1025, n)) / 1024.0).astype(np.float32)
+    t[0], t[-1] = 0.0, 1.0
+    p = (rng.integers(0, 3, n) - 1).astype(np.float32)                                   # -1, 0, +1
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64").astype(np.float32)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    got = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
+    assert np.array_equal(got, ref)
+    perm = rng.permutation(n)
+    perm[0], perm[-1] = perm[np.where(perm == 0)[0][0]], perm[-1]
+    pc = [c[torch.from_numpy(perm).cuda()] for c in cols]
+    pc[2][0], pc[2][-1] = 0.0, 1.0                                                       # ts[0] / ts[-1] define the normalisation
+    x2, y2, t2, p2 = (c.cpu().numpy() for c in pc)
+    ref2 = R.events_to_voxel_torch(x2, y2, t2, p2, B, sensor_size=(H, W), accum="f64").astype(np.float32)
+    assert np.array_equal(E.events_to_voxel_torch(*pc, B, sensor_size=(H, W)).cpu().numpy(), ref2)
+    # the float64 atomics of the same call (both counting modes off) agree to the parity bar, not to the bit
+    monkeypatch.setitem(tiled.FORCE, "count", False)
+    close(E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy(), ref)

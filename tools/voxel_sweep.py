@@ -116,7 +116,9 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     if os.environ.get("REC") in ("4", "8"):
         tiled.FORCE["rec"] = int(os.environ["REC"])
-    print("variant: REC=%s LIB=%s" % (os.environ.get("REC", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
+    if os.environ.get("COUNT2") == "0":
+        tiled.FORCE["count2"] = False
+    print("variant: REC=%s COUNT2=%s LIB=%s" % (os.environ.get("REC", "-"), os.environ.get("COUNT2", "-"), os.environ.get("EVK_LIB_PATH", "-")), flush=True)
     if "--check" in sys.argv:
         check()
     paths = ("v2", "v1") if "--v1" in sys.argv else ("v2",)
