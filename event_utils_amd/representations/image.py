@@ -284,3 +284,117 @@ def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(18
     img_pos_cnt[img_pos_cnt == 0] = 1
     img_neg_cnt[img_neg_cnt == 0] = 1
     return img_pos.div(img_pos_cnt).to(device), img_neg.div(img_neg_cnt).to(device)
+
+
+# ---- the stateful image classes (image.py:355-396) ------------------------------------------------------------------
+def _f64_columns(dev, *cols):
+    """Event columns of any numeric kind (lists, numpy, torch on any device) -> float64 device columns of the length zip()
+    would iterate (the shortest one)."""
+    n = min(len(c) for c in cols)
+    out = []
+    for c in cols:
+        if not isinstance(c, torch.Tensor):
+            c = np.asarray(c)
+        out.append(D.to_device(c[:n], torch.float64, dev).reshape(-1))
+    return n, out
+
+
+class _DeviceImage:
+    """float64 (H, W) image resident on the GPU with the reference's attributes; `.image` is a numpy COPY (assign to it to
+    replace the device image: in-place edits of the copy are not seen)."""
+
+    def __init__(self, sensor_size):
+        self.sensor_size = sensor_size
+        self.num_pixels = sensor_size[0] * sensor_size[1]
+        self._dev = D.require_gpu()
+        self._img = torch.ones(tuple(int(v) for v in sensor_size), dtype=torch.float64, device=self._dev)
+
+    @property
+    def image(self):
+        return self._img.cpu().numpy()
+
+    @image.setter
+    def image(self, value):
+        a = np.asarray(value, dtype=np.float64)
+        self._img = D.to_device(np.ascontiguousarray(a), torch.float64, self._dev)
+
+    @property
+    def device_image(self):
+        """The resident image (a torch float64 tensor; no copy)."""
+        return self._img
+
+    def _raise(self, oob):
+        oob.raise_if_set(IndexError, "index out of bounds for image of size %s" % (tuple(self._img.shape),))
+
+
+class TimestampImage(_DeviceImage):
+    """Time-stamp image (reference: image.py:355-375): every event writes its time stamp to pixel (int(y), int(x)) in
+    stream order -- the last event of a pixel wins --, get_image() ranks the pixel values densely and scales the ranks to
+    [0, 1].  The image lives on the GPU: add_events is one atomicMax per event on the event's position plus a gather,
+    get_image a radix sort of the pixels.  An out-of-range event raises IndexError as upstream's assignment does (upstream
+    has applied the events before it by then; here the in-range events of the whole batch are applied)."""
+
+    def set_init(self, value):
+        self._img = torch.full_like(self._img, float(value))
+
+    def add_event(self, x, y, t, p):
+        self.add_events([x], [y], [t], None)
+
+    def add_events(self, xs, ys, ts, ps):
+        n, (xd, yd, td) = _f64_columns(self._dev, xs, ys, ts)
+        if n == 0:
+            return
+        H, W = self._img.shape
+        oob = D.OobCounter(self._dev)
+        last = torch.empty(H * W, dtype=torch.int32, device=self._dev)
+        _lib.call("evk_timestamp_image_add_f64", D.ptr(xd), D.ptr(yd), D.ptr(td), n, H, W, D.ptr(self._img), D.ptr(last),
+                  oob.ptr, D.stream())
+        self._raise(oob)
+
+    def get_image(self):
+        H, W = self._img.shape
+        npix = H * W
+        nbytes = int(_lib.lib().evk_dense_rank_scratch_bytes(npix))
+        scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=self._dev)
+        off = (-scratch.data_ptr()) % 256
+        out = torch.empty((H, W), dtype=torch.float64, device=self._dev)
+        import ctypes
+        _lib.call("evk_dense_rank_f64", D.ptr(self._img), npix, D.ptr(out), ctypes.c_void_p(scratch.data_ptr() + off), nbytes,
+                  D.stream())
+        return out.cpu().numpy()
+
+
+class EventImage(_DeviceImage):
+    """Event-count image (reference: image.py:377-396): add_event accumulates p at (int(y), int(x)); get_image() scales the
+    image to [0, 1].  Upstream's add_events passes a literal 0 for the polarity (image.py:387-389), so it changes nothing
+    and only fails on out-of-range indices -- reproduced by default; use_polarity=True (not upstream) accumulates `ps`."""
+
+    def add_event(self, x, y, t, p):
+        self._add([x], [y], [p])
+
+    def add_events(self, xs, ys, ts, ps, use_polarity=False):
+        if use_polarity:
+            self._add(xs, ys, ps)
+        else:
+            n = min(len(xs), len(ys), len(ts))
+            self._add(xs[:n], ys[:n], None)
+
+    def _add(self, xs, ys, ps):
+        if ps is None:
+            n, (xd, yd) = _f64_columns(self._dev, xs, ys)
+            pd = None
+        else:
+            n, (xd, yd, pd) = _f64_columns(self._dev, xs, ys, ps)
+        if n == 0:
+            return
+        H, W = self._img.shape
+        oob = D.OobCounter(self._dev)
+        _lib.call("evk_event_image_add_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, H, W, D.ptr(self._img), oob.ptr, D.stream())
+        self._raise(oob)
+
+    def get_image(self):
+        H, W = self._img.shape
+        out = torch.empty((H, W), dtype=torch.float64, device=self._dev)
+        scratch = torch.empty(int(_lib.lib().evk_minmax_scratch_bytes()) // 8, dtype=torch.float64, device=self._dev)
+        _lib.call("evk_minmax_normalise_f64", D.ptr(self._img), H * W, D.ptr(out), D.ptr(scratch), D.stream())
+        return out.cpu().numpy()

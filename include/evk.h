@@ -512,6 +512,26 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
                                        void *stream);
 
+/* ---- the stateful image classes of image.py:355-396 (float64 images, as the reference's numpy arrays) ----------
+ * TimestampImage.add_events (image.py:366-368): image[int(y), int(x)] = t per event IN STREAM ORDER -- for every pixel the
+ * LAST event that hits it wins.  int() truncates toward zero, a negative index wraps once (numpy indexing), anything else
+ * (also NaN / infinity) is counted in *oob (the reference raises IndexError).  last_scratch: h * w uint32, any content.
+ * n < 2^32 - 1. */
+int evk_timestamp_image_add_f64(const double *x, const double *y, const double *t, int64_t n, int h, int w, double *image,
+                                uint32_t *last_scratch, uint32_t *oob, void *stream);
+/* EventImage.add_event (image.py:384-385): image[int(y), int(x)] += p.  p == NULL: the indices are only checked -- what
+ * upstream's add_events does, which passes a literal 0 for the polarity (image.py:387-389). */
+int evk_event_image_add_f64(const double *x, const double *y, const double *p, int64_t n, int h, int w, double *image,
+                            uint32_t *oob, void *stream);
+/* TimestampImage.get_image (image.py:370-375): out = (scipy.stats.rankdata(image, method='dense') - 1) / its maximum
+ * (0 / 0 = NaN for a constant image, as upstream).  scratch: evk_dense_rank_scratch_bytes(npix) bytes, 256-byte aligned. */
+int64_t evk_dense_rank_scratch_bytes(int64_t npix);
+int evk_dense_rank_f64(const double *image, int64_t npix, double *out, void *scratch, int64_t scratch_bytes, void *stream);
+/* EventImage.get_image (image.py:391-394): out = (image - min) / (max - min), NaN-propagating like np.min / np.max.
+ * scratch: evk_minmax_scratch_bytes() bytes. */
+int64_t evk_minmax_scratch_bytes(void);
+int evk_minmax_normalise_f64(const double *image, int64_t npix, double *out, double *scratch, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Event-sharded data parallelism: the path's only exchange step
  * Every accumulator is a sum over events (image.py:95,111-114,132-135: index_put_(accumulate=True); image.py:37:

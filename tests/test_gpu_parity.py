@@ -804,3 +804,39 @@ def test_f9_evk_bfgs_reaches_the_reference_optimum(E, golden, mode):
         assert np.linalg.norm(out["evk_bfgs"][0] - np.array([40., -25.])) < 0.05
         assert np.linalg.norm(out["evk_bfgs"][0] - out["scipy"][0]) < 0.05
         assert out["evk_bfgs"][1] < out["scipy"][1], out
+
+
+def test_f17_timestamp_image_and_event_image_classes(golden):
+    """TimestampImage / EventImage (image.py:355-396) on the GPU against the fixture the real reference produced: the
+    last-writer-wins images bit for bit (float64 time stamps), the dense-rank and min-max normalised get_image() outputs bit
+    for bit, upstream's no-op add_events; then 3 M events on a 480x640 image against the oracle (one atomicMax per event),
+    an out-of-range event raising IndexError, and the opt-in polarity accumulation."""
+    import event_utils_amd as E
+    from test_oracle_golden import _drive_image_classes
+    g = golden("f17_image_classes")
+    got = _drive_image_classes(E, g)
+    for k, v in got.items():
+        assert v.dtype == np.float64 and np.array_equal(v, g[k], equal_nan=True), k
+    rng = np.random.default_rng(171)
+    n, H, W = 3_000_000, 480, 640
+    xs = rng.uniform(-3, W, n); ys = rng.uniform(-2, H, n)
+    ts = np.sort(rng.uniform(0, 1, n)); ps = rng.integers(0, 2, n) * 2.0 - 1.0
+    a, b = E.TimestampImage((H, W)), R.TimestampImage((H, W))
+    for obj in (a, b):
+        obj.set_init(-0.5)
+        obj.add_events(xs, ys, ts, ps)
+    assert np.array_equal(a.image, b.image) and np.array_equal(a.get_image(), b.get_image())
+    a.add_events(torch.from_numpy(xs[:1000]).cuda(), torch.from_numpy(ys[:1000]).cuda(), torch.from_numpy(ts[:1000] + 5).cuda(), None)
+    b.add_events(xs[:1000], ys[:1000], ts[:1000] + 5, None)
+    assert np.array_equal(a.image, b.image)
+    with pytest.raises(IndexError):
+        a.add_events([1.0, float(W)], [1.0, 1.0], [0.1, 0.2], None)
+    e1, e2 = E.EventImage((H, W)), R.EventImage((H, W))
+    for obj in (e1, e2):
+        obj.add_events(xs, ys, ts, ps, use_polarity=True)
+    assert np.array_equal(e1.image, e2.image) and np.array_equal(e1.get_image(), e2.get_image())
+    with pytest.raises(IndexError):
+        e1.add_events([1.0], [-float(H) - 1.0], [0.1], [1.0])
+    e1.image = np.zeros((H, W)); e1.add_event(2.9, 3.1, 0.0, 4.0)
+    assert e1.image[3, 2] == 4.0 and e1.image.sum() == 4.0
+    assert np.all(np.isnan(E.EventImage((4, 5)).get_image()))

@@ -362,3 +362,48 @@ def test_f16_windowed_and_split_voxel_conventions(golden):
     xi, yi, t64 = x.astype(np.int64), y.astype(np.int64), t.astype(np.float64)
     assert np.array_equal(R.events_to_voxel(xi, yi, t64, np.where(p, 1, 0), B, sensor_size=ss), g["neg_pos_numpy_pos"])
     assert np.array_equal(R.events_to_voxel(xi, yi, t64, np.where(p, 0, 1), B, sensor_size=ss), g["neg_pos_numpy_neg"])
+
+
+def _drive_image_classes(M, g):
+    """The sequence of calls oracle/make_golden_classes.py made on the real reference, on module / namespace M."""
+    xs, ys, ts, ps = g["xs"], g["ys"], g["ts"], g["ps"]
+    H, W = (int(v) for v in g["sensor_size"])
+    n = len(xs)
+    out = {}
+    ti = M.TimestampImage((H, W))
+    out["ts_init_image"] = np.asarray(ti.get_image())
+    ti.set_init(-1.0)
+    half = n // 2
+    ti.add_events(xs[:half], ys[:half], ts[:half], ps[:half])
+    out["ts_image_half"] = np.array(ti.image)
+    out["ts_get_half"] = np.asarray(ti.get_image())
+    ti.add_events(xs[half:], ys[half:], ts[half:], ps[half:])
+    ti.add_event(3.7, 5.2, 0.123, 1)
+    out["ts_image_full"] = np.array(ti.image)
+    out["ts_get_full"] = np.asarray(ti.get_image())
+    ts2 = M.TimestampImage((H, W))
+    ts2.add_events(xs[:300], ys[:300], ts[:300] + 2.0, ps[:300])
+    out["ts_sparse_image"] = np.array(ts2.image)
+    out["ts_sparse_get"] = np.asarray(ts2.get_image())
+    ei = M.EventImage((H, W))
+    ei.add_events(xs, ys, ts, ps)
+    out["ev_image_after_add_events"] = np.array(ei.image)
+    for k in range(0, 2000):
+        ei.add_event(xs[k], ys[k], ts[k], ps[k])
+    out["ev_image"] = np.array(ei.image)
+    out["ev_get"] = np.asarray(ei.get_image())
+    return out
+
+
+def test_f17_timestamp_image_and_event_image_classes(golden):
+    """image.py:355-396: last-writer-wins time-stamp image with dense-rank normalisation, and the event image whose
+    add_events adds zeros upstream -- every intermediate image and get_image() of the reference, bit for bit."""
+    g = golden("f17_image_classes")
+    got = _drive_image_classes(R, g)
+    for k, v in got.items():
+        assert v.dtype == np.float64 and np.array_equal(v, g[k], equal_nan=True), k
+    with pytest.raises(IndexError):
+        R.TimestampImage((4, 4)).add_events(np.array([1.0, 4.0]), np.array([1.0, 1.0]), np.array([0.1, 0.2]), None)
+    ei = R.EventImage((4, 4))
+    ei.add_events(np.array([1.0, 1.0]), np.array([2.0, 2.0]), np.array([0.1, 0.2]), np.array([1.0, 1.0]), use_polarity=True)
+    assert ei.image[2, 1] == 3.0
