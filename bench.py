@@ -321,6 +321,14 @@ def main():
                 keepg[0] = E.events_to_voxel_torch(c[0], c[1], c[2], pgen, B, sensor_size=(H, W))
             result[key] = round(timed(step_general, args.steps, args.warmup) / args.steps * 1e3, 4)
             del pgen, mult
+        # EVK_VOXEL2_LIVE (round 5, opt-in): the same public call with its tiles accumulated WHILE the partition sorts, by a
+        # consumer kernel on the library's second stream -- measured slower than the two launches it overlaps (DESIGN.md
+        # section 3, profiles/r05_live_ab.txt); reported here so that every bench run repeats the A/B
+        tiled.FORCE["live"] = True
+        try:
+            result["voxel_live_ms"] = round(timed(step_public, args.steps, args.warmup) / args.steps * 1e3, 4)
+        finally:
+            tiled.FORCE["live"] = None
         # the headline runs in the DEFAULT error mode (strict since round 5: the reference's synchronous IndexError, the
         # call waits for its partition kernel's report); the opt-in deferred mode beside it
         prev_mode = os.environ.get("EVK_ERRORS")

@@ -397,7 +397,19 @@ class variance_objective(objective_function):
         vals = [None] * K
         blur = self.default_blur if blur_sigma is None else blur_sigma
         setup = self._batch3_setup(xs, ys, ts, ps, warpfunc, blur) if K and all(len(q) == 2 for q in pts) else None
-        if setup is not None:
+        if setup is not None and K <= 3:
+            # one trio (a line search's three step lengths): the call brings its 12 doubles to the host itself -- no
+            # allocation, no copy command, no stream synchronisation (as _one_call)
+            ev, t_ref, launch = setup
+            idx = [min(k, K - 1) for k in range(3)]
+            res = self.__dict__.setdefault("_res12", np.empty(12, dtype=np.float64))
+            done = []
+            if launch([pts[i] for i in idx], D.out4(ev.device, 12), img_size, res):
+                done.append((0, idx))
+                r4 = res.reshape(3, 4)
+                for k, i in enumerate(idx):
+                    vals[i] = np.float32(-r4[k, 1])
+        elif setup is not None:
             ev, t_ref, launch = setup
             out = torch.empty(4 * 3 * ((K + 2) // 3), dtype=torch.float64, device=ev.device)
             done = []

@@ -641,16 +641,46 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
 def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags, weights, radius, buf, out12, scratch,
                          scratch_bytes, impl=None, host_out=None):
     """f at three nearby flows in one pass over the events (evk_cmax_variance_batch3_tiled_f32) -> out12 (3 x 4
-    doubles); False when the tiled plan is not applicable."""
+    doubles); False when the tiled plan is not applicable.  host_out = numpy float64[12]: the call brings the results to
+    the host and synchronises itself.  As cmax_variance, the marshalled arguments are cached on `ev` per (geometry,
+    buffers): a line search (events_cmax.evk_bfgs: three step lengths per pass) changes only the six flow components, which
+    live in two arrays the call reads in place (round 5: ~50 us of Python off every three-flow pass)."""
+    import math
+    import numpy as np
+    ckey = ("batch3", t_ref, bounds_w, bounds_h, ch, cw, flags, radius, impl or default_impl(), FORCE["iwe_fixed"],
+            FORCE["iwe_records"], ev.p_scale)
+    cache = ev.__dict__.setdefault("_cmax_calls", {})
+    c = cache.get(ckey)
+    if c is not None and c["buf"] is buf and c["scratch"] is scratch and c["weights"] is weights \
+            and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys)):
+        span, tw, th = c["geo"]
+        S, win_w, win_h = _iwe_window(0.0, 1.0, max(abs(v) for v in vxs) * span, max(abs(v) for v in vys) * span, 1 << tw, 1 << th, 3)
+        if (S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]:
+            c["vx"][:] = vxs
+            c["vy"][:] = vys
+            args, st = c["args"], c["spill"]
+            if st is not None:
+                args[c["i_parity"]] = st[1] ^ 1
+            args[-7] = D.ptr(out12)          # (the samplers hand in a different slice of their result buffer per trio)
+            args[-2] = D.host_ptr(host_out) if host_out is not None else None
+            args[-1] = D.stream()
+            _spill_call(st, lambda: _lib.check(c["fn"](*args), "evk_cmax_variance_batch3_tiled_f32"))
+            return True
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
         return False
     st = _spill_pair(buf.device, 3, ch, cw)
     spill, parity = (st[0], st[1] ^ 1) if st is not None else (None, 0)
-    _spill_call(st, lambda: _lib.call(
-        "evk_cmax_variance_batch3_tiled_f32", *plan["head"], D.host_ptr(weights) if weights is not None else None, radius,
-        D.ptr(plan["staging"]), plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch), scratch_bytes, D.ptr(spill),
-        parity, D.host_ptr(host_out) if host_out is not None else None, D.stream()))
+    args = list(plan["head"]) + [D.host_ptr(weights) if weights is not None else None, radius, D.ptr(plan["staging"]),
+                                 plan["staging_bytes"], D.ptr(buf), D.ptr(out12), D.ptr(scratch), scratch_bytes, D.ptr(spill),
+                                 parity, D.host_ptr(host_out) if host_out is not None else None, D.stream()]
+    fn = getattr(_lib.lib(), "evk_cmax_variance_batch3_tiled_f32")
+    _spill_call(st, lambda: _lib.check(fn(*args), "evk_cmax_variance_batch3_tiled_f32"))
+    head = plan["head"]
+    cache[ckey] = {"fn": fn, "args": args, "buf": buf, "scratch": scratch, "weights": weights,
+                   "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
+                   "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6]),
+                   "spill": st, "i_parity": len(args) - 3, "vx": plan["keep"][0], "vy": plan["keep"][1], "keep": (plan, spill)}
     return True
 
 
