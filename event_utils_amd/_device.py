@@ -52,9 +52,12 @@ _NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float6
 def to_device(a, dtype, device=None):
     """numpy array / torch tensor (any device) -> contiguous 1-D+ torch tensor of `dtype` on the GPU.
     No copy when `a` already is such a tensor."""
-    device = device or require_gpu()
     if isinstance(a, torch.Tensor):
+        if a.is_cuda and a.dtype == dtype and a.is_contiguous() and (device is None or a.device == device):
+            return a                    # (the common case of a public call on resident columns: no dispatcher round trip)
+        device = device or require_gpu()
         return a.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+    device = device or require_gpu()
     a = np.asarray(a)
     want = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}[dtype]
     if a.dtype != want:
@@ -84,8 +87,7 @@ def error_mode():
     outputs stay on the device only enqueue; the exception surfaces at the next event_utils_amd call on that stream or
     at check_errors() -- the way the reference's own CUDA path reports an out-of-range index_put_ (an asynchronous
     device-side assert).  Calls that hand their result to the host are always strict (they synchronise anyway)."""
-    import os
-    return os.environ.get("EVK_ERRORS", "strict")
+    return _lib.getenv("EVK_ERRORS", "strict")
 
 
 class _ErrorState:

@@ -11,9 +11,10 @@
 
 namespace evk {
 
-#define V2_HDR 8             // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info),
+#define V2_HDR 16            // [0] t_first bits, [1] t_last bits, [2] ticket, [3] events with a wide polarity (info),
                              // [4] contributions the deterministic mode refused, [5] events whose polarity is not +1, -1 or
-                             // +0 (cumulative), [6] its value after the previous call, [7] 1 if THIS call had any
+                             // +0 (cumulative), [6] its value after the previous call, [7] 1 if THIS call had any,
+                             // [8] ticket of the EARLY report of dropped events (round 5), [9..15] spare
 #define V2_MAX_TILES 2048    // totals live at a FIXED offset so that they are zero again after every call
 #define V2_TOTALS V2_HDR
 // words of the LIVE hand-over (evk_voxel_live.h), at a FIXED place whatever the tiling and the event count -- a buffer that
@@ -227,6 +228,27 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
     }
     const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
+    // EARLY REPORT of dropped events (round 5).  A synchronous caller (EVK_ERRORS=strict, the default: the reference raises
+    // before it returns, image.py:96-99) waits for {seq, dropped events} in its pinned slot, then prepares its next call while
+    // the tile kernel runs.  The count is final long before this kernel ends: a workgroup's dropped events are known with the
+    // keys of its last sub-chunk.  So ONE lane per workgroup adds the workgroup's count to *oob at that point -- a returning
+    // atomic, so that its ticket is taken behind it -- and the last of these tickets publishes the report: most of a pass
+    // and the plan's tail earlier than the end of the kernel, which is what lets the host's ~20 us between two calls
+    // disappear behind the tile kernel.  (Not the bilinear image format: its rare path can still drop events in the placement.)
+    constexpr bool EARLY = REC != V2_FMT_IMGB;
+    uint32_t early_prev = 0;   // lane 0: what its early-report ticket returned
+    // (three steps, none of which makes a wave wait where the others need it: the count leaves as a no-return atomic behind the
+    // last pass's histogram barrier; the ticket is taken behind that pass's "everything outstanding has landed" wait, i.e. when
+    // the count has been performed; its answer is looked at only after the placement)
+    auto early_publish = [&]() {
+        EVK_HANDOVER_ACQUIRE();
+        __hip_atomic_store(index + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_report && oob) {
+            const uint32_t cnt = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_report),
+                               (unsigned long long)seq | ((unsigned long long)cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
 
     // Group k of sub-chunk sc = G consecutive events of thread tid.  A group that is only partly inside the stream is
     // loaded whole (the over-read stays inside an aligned block; the extra events are ignored); a group entirely outside
@@ -365,7 +387,15 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         for (int s2 = 0; s2 < EPT; ++s2)
             if (kl[s2] != 0xFFFFFFFFu)
                 __hip_atomic_fetch_add(&hist[kl[s2] >> V2_LB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (EARLY) {
+            // this workgroup's dropped events are all counted once the keys of its LAST sub-chunk are (above)
+            if (sc == sc_end - 1 && dropped) __hip_atomic_fetch_add(&tmp[69], dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         lds_barrier();  // histogram complete
+        if constexpr (EARLY) {
+            if (sc == sc_end - 1 && tid == 0 && oob && tmp[69])
+                __hip_atomic_fetch_add(oob, tmp[69], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         V2_T(2);
         if constexpr (VOX) if (V2_ABLATE_A < 2) {
             uint32_t sink = 0;
@@ -434,6 +464,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         // issued such a wait is a vmcnt(0), i.e. the full latency of those loads in every placement.
         EVK_WAIT_VM0();
         fence();
+        if constexpr (EARLY) {   // (the workgroup's count has been performed: the wait above)
+            if (sc == sc_end - 1 && tid == 0) {
+                EVK_HANDOVER_RELEASE();
+                early_prev = __hip_atomic_fetch_add(index + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (sc + 1 < sc_end) load_xy(sc + 1);  // in flight during the placement
         fence();
         if constexpr (VOX) if (V2_ABLATE_A < 3) {
@@ -566,6 +602,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         }
         V2_T(5);
         lds_barrier();   // the sorted sub-chunk is complete
+        if constexpr (EARLY) {
+            if (sc == sc_end - 1 && tid == 0 && early_prev == gridDim.x - 1) early_publish();
+        }
         if constexpr (LIVE) {
             // every wave waited for its stores of the PREVIOUS run (and its table row) in front of this placement: that run is
             // out.  runs published = sc - sc0.
@@ -582,7 +621,14 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     // ---- totals -> global (the last block to arrive builds the work-item plan), issued AHEAD of the last run's stores so
     //      that the two drain together
     uint32_t *gidx = index;
-    if (dropped && oob) atomicAdd(oob, dropped);
+    if constexpr (EARLY) {
+        if (sc0 >= sc_end && tid == 0) {   // a workgroup without a sub-chunk only takes its ticket
+            early_prev = __hip_atomic_fetch_add(index + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (early_prev == gridDim.x - 1) early_publish();
+        }
+    } else {
+        if (dropped && oob) atomicAdd(oob, dropped);
+    }
     // (131 K atomics at 10 M events / 512 tiles: 1.5 us of the kernel, measured by leaving them out)
     for (int i = tid; i < ntiles; i += THREADS)
         if (tot[i]) __hip_atomic_fetch_add(gidx + V2_TOTALS + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -651,7 +697,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             now3 = __hip_atomic_load(gidx + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prev0 = __hip_atomic_load(gidx + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (host_report && oob) cnt_oob = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!EARLY && host_report && oob) cnt_oob = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int k = 0; k < PER_MAX; ++k) {
@@ -687,7 +733,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             __hip_atomic_store(gidx + 1, now3 != prev0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gidx + 0, now3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
+        if (!EARLY && host_report) {  // every workgroup's dropped-event count is in *oob (added before its ticket): tell the host,
                             // in pinned memory, so that a deferred error check costs no copy and no event on the stream
             const uint32_t cnt = cnt_oob;
             // {seq, count} as ONE 8-byte system-scope store: the pair cannot be seen torn, and no release (a write-back of the

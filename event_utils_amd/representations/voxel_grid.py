@@ -70,15 +70,16 @@ def events_to_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240)
     if ts.dtype == torch.float64 or ps.dtype == torch.float64:
         raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the "
                            "destination and Double for the source.")
-    dev = D.require_gpu()
+    dev = xs.device if (xs.is_cuda and _lib._lib is not None) else D.require_gpu()   # (resident columns: the library is loaded)
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
     if n_ev == 0:
         raise IndexError("index -1 is out of bounds for dimension 0 with size 0")   # ts[-1], voxel_grid.py:133
-    # ts[0] / ts[-1] are read by the kernels themselves; events and grid that stay on the device never wait for the host
-    resident = xs.is_cuda and torch.device(device).type == "cuda"
+    # ts[0] / ts[-1] are read by the kernels themselves; events and grid that stay on the device wait for the partition
+    # kernel's report only (strict, the default) or not at all (EVK_ERRORS=deferred)
+    resident = xs.is_cuda and (device is xs.device or torch.device(device).type == "cuda")
     out = _voxel_f32_device(xd, yd, td, pd, B, sensor_size, None, None, deferrable=resident)
-    return out.to(device)
+    return out if out.device == device else out.to(device)
 
 
 def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True):

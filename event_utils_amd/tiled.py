@@ -9,7 +9,7 @@ from . import _lib
 
 
 def default_impl():
-    return os.environ.get("EVK_IMPL", "auto")
+    return _lib.getenv("EVK_IMPL", "auto")
 
 
 # Hooks for tests and measurements (NOT configuration: the defaults are what the library measured best).  Several kernel shapes
@@ -188,7 +188,7 @@ def voxel_deterministic():
     """EVK_VOXEL_DETERMINISTIC=1: the tile kernel of the one-pass path accumulates 64-bit fixed point (order-free integer
     adds) instead of float64 -- bit-identical grids from run to run and for any order of the events.  Such a call takes the
     one-pass path at any event count (voxel_f32) and costs one synchronisation (range check)."""
-    return os.environ.get("EVK_VOXEL_DETERMINISTIC", "0") == "1"
+    return _lib.getenv("EVK_VOXEL_DETERMINISTIC", "0") == "1"
 
 
 _shape_cache = {}
@@ -263,7 +263,7 @@ def _voxel2_env(dev, n, B, H, W, tw, th, split_polarity=False):
         flags |= _lib.EVK_VOXEL2_WG512
     live = FORCE["live"]
     if live is None:
-        live = n >= LIVE_MIN_EVENTS and os.environ.get("EVK_VOXEL_LIVE", "0") == "1"
+        live = n >= LIVE_MIN_EVENTS and _lib.getenv("EVK_VOXEL_LIVE", "0") == "1"
     if live and not split_polarity and not (flags & 128):
         flags |= _lib.EVK_VOXEL2_LIVE
     if voxel_deterministic():

@@ -830,7 +830,7 @@ def test_live_voxel_call_is_bit_identical_to_the_two_launches(E, monkeypatch):
             close(a.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
     # who did the work: on uniform events every tile was finished by a consumer (status word = epoch << 2 | DONE)
     idx = [v for key, v in tiled._zpersist.items() if key[0] == "voxel2_index"][0].cpu().numpy().astype(np.uint32)
-    status = idx[8 + 2048 + 256: 8 + 2048 + 256 + 512]
+    status = idx[16 + 2048 + 256: 16 + 2048 + 256 + 512]        # (V2_HDR + V2_MAX_TILES + 256 progress words)
     assert np.all((status & 3) == 2) and len(np.unique(status >> 2)) == 1, np.unique(status & 3, return_counts=True)
 
 

@@ -26,7 +26,7 @@ for live in (False, True):
         _voxel_f32_device(*sets[i % 4], B, (H, W), None, None, out=out, check=False, impl="tiled", fresh=True)
     torch.cuda.synchronize()
 idx = [v for k, v in tiled._zpersist.items() if k[0] == "voxel2_index"][0].cpu().numpy().astype(np.uint32)
-V2_HDR, MAXT = 8, 2048
+V2_HDR, MAXT = 16, 2048
 prog = idx[V2_HDR + MAXT: V2_HDR + MAXT + 256]
 status = idx[V2_HDR + MAXT + 256: V2_HDR + MAXT + 256 + 512]
 print("progress words: epoch %s runs %s" % (np.unique(prog >> 8), np.unique(prog & 255)))
