@@ -621,10 +621,10 @@ def bench_image_c1(E, tiled, dev, impl):
 
 def pmc_traffic(kernel, tag):
     """HBM bytes per launch of `kernel` (and of the whole call) from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json: separate --pmc passes for reads and writes of this same workload, gfx950 corrections
+    (profiles/rNN_pmc_traffic.json, newest round first: separate --pmc passes for reads and writes of this same workload, gfx950 corrections
     applied as MI355X_MICROARCH.md prescribes; tools/profile_round.sh).  PMC counters cannot be collected from inside the
     timed process, so this is the recorded measurement of the workload `tag`; None when the profile is absent."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)
         if not os.path.isfile(path):
             continue
