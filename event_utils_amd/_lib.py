@@ -78,6 +78,7 @@ SIGNATURES = {
     "evk_objective_stats_f32": [P, c_int, c_int, P, c_int, c_double, c_double, P, P, c_int64, P],
     "evk_objective_variance_fg_f32": [P, P, c_int, c_int, P, c_int, c_uint32, P, P, c_int64, P],
     "evk_objective_gradsums_f32": [P, P, c_int, c_int, P, c_int, c_uint32, c_int, c_double, P, P, c_int64, P],
+    "evk_spectral_norm_sq_f32": [P, c_int, c_int, P, P, c_int64, P],
     "evk_timestamp_image_add_f64": [P, P, P, c_int64, c_int, c_int, P, P, P, P],
     "evk_event_image_add_f64": [P, P, P, c_int64, c_int, c_int, P, P, P],
     "evk_dense_rank_f64": [P, c_int64, P, P, c_int64, P],
@@ -129,6 +130,7 @@ _SPECIAL = {
     "evk_num_cu": ([], c_int),
     "evk_image2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
     "evk_dense_rank_scratch_bytes": ([c_int64], c_int64),
+    "evk_spectral_scratch_bytes": ([c_int, c_int], c_int64),
     "evk_minmax_scratch_bytes": ([], c_int64),
 }
 

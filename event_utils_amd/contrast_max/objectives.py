@@ -542,8 +542,8 @@ class sos_objective(_reduction_objective):
 class rms_objective(_reduction_objective):
     """"Root mean squared" objective (reference: objectives.py:266-306).  As written upstream the loss is
     -norm(blur(iwe), 2)^2 / pixels with np.linalg.norm(., 2) of a MATRIX, i.e. its largest singular value (:282), not
-    the Frobenius norm; reproduced as is.  The blurred IWE stays on the device and its spectral norm comes from the
-    device SVD (torch.linalg.matrix_norm -> rocSOLVER).  Gradient: -2 mean(iwe * blur3d(d_iwe)[i]), un-blurred IWE."""
+    the Frobenius norm; reproduced as is.  The blurred IWE stays on the device and its spectral norm comes from a Lanczos
+    iteration on the Gram operator (evk_spectral_norm_sq_f32).  Gradient: -2 mean(iwe * blur3d(d_iwe)[i]), un-blurred IWE."""
 
     def __init__(self):
         super().__init__(name="rms", use_polarity=True, has_derivative=True, default_blur=1.0)
@@ -558,12 +558,18 @@ class rms_objective(_reduction_objective):
         blur_sigma = self.default_blur if blur_sigma is None else blur_sigma
         if blur_sigma > 0:
             iwe = gaussian_filter_device(iwe.contiguous(), blur_sigma)
-        # largest singular value squared = largest eigenvalue of the (smaller) Gram matrix, float64 on the device.  (The
-        # device SVD -- torch.linalg.matrix_norm -> rocSOLVER -- does not converge on the nearly rank-one images of a handful
-        # of events: "too many repeated singular values"; the symmetric eigensolver does, and is the cheaper of the two.)
-        a = iwe.double()
-        gram = a @ a.T if a.shape[0] <= a.shape[1] else a.T @ a
-        norm2 = max(float(torch.linalg.eigvalsh(gram)[-1].item()), 0.0)
+        # largest singular value squared = largest eigenvalue of the Gram operator: a Lanczos iteration in float64 in one
+        # workgroup (evk_spectral.hip; round 5: until then torch formed the Gram matrix and rocSOLVER its eigenvalues -- and the
+        # device SVD before that did not converge on the nearly rank-one images of a handful of events)
+        iwe = iwe.contiguous()
+        h, w = int(iwe.shape[0]), int(iwe.shape[1])
+        nbytes = int(_lib.lib().evk_spectral_scratch_bytes(h, w))
+        if nbytes <= 0:
+            raise ValueError("rms_objective: images beyond 4096 pixels a side are not supported")
+        scratch = tiled._buf("spectral", nbytes, dev)
+        out = D.out4(dev)
+        _lib.call("evk_spectral_norm_sq_f32", D.ptr(iwe), h, w, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+        norm2 = max(float(out[0].item()), 0.0)
         return np.float32(-norm2 / (iwe.shape[0] * iwe.shape[1]))
 
     def evaluate_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,

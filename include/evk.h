@@ -512,6 +512,12 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
                                        void *stream);
 
+/* Largest singular value SQUARED of a float32 (h, w) image, float64 -> out[0]: what the "rms" objective needs
+ * (objectives.py:282: np.linalg.norm(iwe, 2) of a 2-D array is the spectral norm).  Lanczos on the Gram operator with full
+ * re-orthogonalisation in one workgroup, then a bisection; h, w <= 4096.  scratch: evk_spectral_scratch_bytes(h, w). */
+int64_t evk_spectral_scratch_bytes(int h, int w);
+int evk_spectral_norm_sq_f32(const float *img, int h, int w, double *out, void *scratch, int64_t scratch_bytes, void *stream);
+
 /* ---- the stateful image classes of image.py:355-396 (float64 images, as the reference's numpy arrays) ----------
  * TimestampImage.add_events (image.py:366-368): image[int(y), int(x)] = t per event IN STREAM ORDER -- for every pixel the
  * LAST event that hits it wins.  int() truncates toward zero, a negative index wraps once (numpy indexing), anything else

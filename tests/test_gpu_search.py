@@ -206,3 +206,34 @@ def test_grid_cmax_cells(E, C, scene):
     assert np.linalg.norm(params[0] - np.array([60., 0.])) < 6.0
     assert np.linalg.norm(params[1] - np.array([-40., 30.])) < 6.0
     assert all(f < 0 for f in fevals)
+
+
+@pytest.mark.parametrize("shape", [(181, 241), (241, 181), (481, 641), (721, 1281), (7, 300), (64, 64)])
+def test_spectral_norm_kernel_against_numpy(E, shape):
+    """evk_spectral_norm_sq_f32 (Lanczos on the Gram operator, one workgroup, float64): sigma_max^2 of random, smooth,
+    sign-alternating, rank-one, rank-two and zero images against np.linalg.norm(a.astype(float64), 2)^2."""
+    from event_utils_amd import _device as D, _lib, tiled
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    cases = {
+        "noise": rng.normal(size=shape),
+        "positive": rng.poisson(3.0, size=shape).astype(np.float64),
+        "smooth": np.sin(xx / 17.0) * np.cos(yy / 11.0) + 0.3 * rng.normal(size=shape),
+        "checker": ((xx + yy) % 2 * 2.0 - 1.0) * (1.0 + 0.01 * rng.normal(size=shape)),
+        "rank1": np.outer(rng.normal(size=h), rng.normal(size=w)),
+        "rank2": np.outer(rng.normal(size=h), rng.normal(size=w)) + 0.999 * np.outer(rng.normal(size=h), rng.normal(size=w)),
+        "one pixel": np.where((yy == h // 2) & (xx == w // 3), 5.0, 0.0),
+        "zero": np.zeros(shape),
+    }
+    dev = torch.device("cuda", 0)
+    nbytes = int(_lib.lib().evk_spectral_scratch_bytes(h, w))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.zeros(4, dtype=torch.float64, device=dev)
+    for name, a in cases.items():
+        a32 = np.ascontiguousarray(a, dtype=np.float32)
+        img = torch.from_numpy(a32).cuda()
+        _lib.call("evk_spectral_norm_sq_f32", D.ptr(img), h, w, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
+        got = float(out[0].item())
+        want = float(np.linalg.norm(a32.astype(np.float64), 2)) ** 2
+        assert abs(got - want) <= 1e-9 * max(want, 1e-300), (name, shape, got, want)
