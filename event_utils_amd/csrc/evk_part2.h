@@ -756,7 +756,10 @@ struct V2Config {
 #define V2_GEOMETRIES(X) X(1024, 8) X(1024, 12)
 static const V2Config &v2_config(bool share = false, int ntiles = 0) {
     static const V2Config small{1024, 8}, large{1024, 12};
-    return (share || ntiles <= 680) ? small : large;
+#ifndef V2_LARGE_ABOVE
+#define V2_LARGE_ABOVE 680   // (A/B) tile count above which the 12 K-event geometry is taken
+#endif
+    return (share || ntiles <= V2_LARGE_ABOVE) ? small : large;
 }
 #define V2_MIN_SUBCHUNK 8192
 #define V2_LDS_LIMIT (160 * 1024 - 512)   // (the partition kernel also has a few bytes of static LDS)
