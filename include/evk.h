@@ -325,8 +325,9 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  *   index    evk_voxel2_index_len(ntiles, n) uint32, ZEROED ONCE by the caller when it is allocated; the library
  *            leaves its counters at zero after every call (persistent across calls on one stream)
  *   scratch  evk_voxel2_scratch_bytes(...) bytes, 16-byte aligned, uninitialised
- *   host_report  optional: two uint32, 8-byte aligned, in PINNED host memory the device can write (hipHostMalloc).  When the
- *            partition kernel's last workgroup finishes it stores {seq, *oob} there (one 8-byte system-scope store: the pair
+ *   host_report  optional: two uint32, 8-byte aligned, in PINNED host memory the device can write (hipHostMalloc).  As soon as
+ *            every partition workgroup has counted the dropped events of its LAST sub-chunk (round 5: ~8 us before the kernel
+ *            ends; the bilinear image format: when its last workgroup finishes) the kernel stores {seq, *oob} there (one 8-byte system-scope store: the pair
  *            is never seen torn; EVK_EALIGN if the pointer is not 8-byte aligned), so a caller that checks for
  *            dropped events lazily needs neither a device-to-host copy nor an event on the stream: the call numbered
  *            `seq` has counted all its events once host_report[0] == seq (sequence numbers grow by one per call).
