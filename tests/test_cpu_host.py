@@ -32,6 +32,19 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert _lib.lib().evk_error_string(-1) == b"invalid argument"
 
 
+def test_python_flag_constants_equal_the_header():
+    """event_utils_amd/_lib.py restates the flags of include/evk.h: every EVK_* integer constant there must be the header's
+    #define of the same name (the ctypes binding is the reference-side stub of INTEGRATION.md: it may not drift)."""
+    import re
+    from event_utils_amd import _lib
+    text = open(os.path.join(ROOT, "include", "evk.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(EVK_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))[uU]?\b", text, re.M)}
+    names = [k for k, v in vars(_lib).items() if k.startswith("EVK_") and isinstance(v, int)]
+    assert len(names) >= 15
+    for k in names:
+        assert k in defines and defines[k] == getattr(_lib, k), (k, getattr(_lib, k), defines.get(k))
+
+
 def test_argument_errors_need_no_gpu():
     from event_utils_amd import _lib
     L = _lib.lib()
@@ -300,8 +313,8 @@ def test_voxel_kernels_compile_without_register_spills(tmp_path):
     assert asm, os.listdir(tmp_path)
     text = open(tmp_path / asm[0]).read()
     kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
-    seen = {n: (int(v), int(sp)) for n, v, sp in kernels if "k_part_sorted" in n or "k_voxel_tiles2" in n}
-    assert len(seen) >= 12, sorted(seen)
+    seen = {n: (int(v), int(sp)) for n, v, sp in kernels if "k_part_sorted" in n or "k_voxel_tiles2" in n or "k_voxel_live" in n}
+    assert len(seen) >= 14, sorted(seen)
     spilled = {n: vs for n, vs in seen.items() if vs[1]}
     assert not spilled, spilled
     assert "Folded Spill" not in "".join(l for l in text.splitlines(True) if "scratch_" in l)
@@ -310,6 +323,9 @@ def test_voxel_kernels_compile_without_register_spills(tmp_path):
     assert all(v <= 80 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n and "ELi8EEEv" in n)
     assert all(v <= 128 for n, (v, _) in seen.items() if "k_voxel_tiles2" in n)
     assert all(v <= 128 for n, (v, _) in seen.items() if "k_part_sorted" in n)
+    # the live pair must fit one CU together: the partition's 4 waves per SIMD at <= 80 registers leave 192 for the consumer's 2
+    assert all(v <= 80 for n, (v, _) in seen.items() if "k_part_sorted" in n and "Lb1EEEvT2_" in n)   # (LIVE is the last template argument)
+    assert all(v <= 96 for n, (v, _) in seen.items() if "k_voxel_live" in n)
 
 
 def test_evk_bfgs_line_search_logic_on_a_known_function():
