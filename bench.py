@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=7, help="repetitions of the K-step timed loop; the median is reported")
     ap.add_argument("--events", type=int, default=N_PER_GPU)
     ap.add_argument("--impl", default=None, help="kernel variant: direct | tiled | auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -209,9 +210,16 @@ def main():
         exchange_choice = {"overlapped_ms": round(trial[True] / max(args.steps, 20) * 1e3, 4),
                            "serial_ms": round(trial[False] / max(args.steps, 20) * 1e3, 4),
                            "chosen": "overlapped" if overlap else "serial", "share_cu": overlap}
-    elapsed = timed(step, args.steps, args.warmup)
+    # Round 6: the K-step region is ~1.5 ms, and one such region scatters by more than the changes a round makes (boxes differ by
+    # +-6 %, a single region by +-3 %): the K steps are timed REPS times -- each repetition exactly K steps between a barrier +
+    # synchronize on both sides, max over ranks, after its own W warm-up steps -- and the line reports the MEDIAN repetition
+    # (`ms_per_step`, `value`), with every repetition and the spread beside it (`repetitions`).
+    reps_ms = []
+    for _ in range(max(1, args.reps)):
+        reps_ms.append(timed(step, args.steps, args.warmup) / args.steps * 1e3)
     E.check_errors()                     # deferred out-of-range reports of the timed calls (none expected)
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = float(np.median(reps_ms))
+    elapsed = ms_per_step * args.steps * 1e-3
     value = n * world / (elapsed / args.steps) / 1e6
     # device-side time per step, outside the timed region (an event pair around every step of the timed loop would
     # itself cost ~8 us per step): one pair of HIP events around K more steps
@@ -247,6 +255,11 @@ def main():
                                    % (world, ", overlapped with the next step's kernels" if overlap else ""))
                    if use_dist else "single GPU"},
         "device_ms_per_step": round(dev_ms, 4),
+        "repetitions": {"count": len(reps_ms), "steps_each": args.steps, "ms_per_step": [round(v, 4) for v in reps_ms],
+                        "median": round(ms_per_step, 4), "min": round(min(reps_ms), 4), "max": round(max(reps_ms), 4),
+                        "spread_pct": round(100.0 * (max(reps_ms) - min(reps_ms)) / ms_per_step, 2),
+                        "note": "ms_per_step / value are the MEDIAN repetition; every repetition is exactly `steps` steps between "
+                                "barrier + synchronize, after `warmup` warm-up steps"},
         "roofline": roofline,
     }
     if use_dist:
@@ -355,6 +368,10 @@ def main():
             result["c5_share"] = bench_c5_share(tiled, dev, impl)
         except Exception as e:  # noqa: BLE001
             result["c5_share"] = {"error": repr(e)}
+        try:
+            result["prebucketed"] = bench_prebucketed(tiled, sets, n, t_first, t_last, dev, max(8, args.steps))
+        except Exception as e:  # noqa: BLE001
+            result["prebucketed"] = {"error": repr(e)}
         result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
                                                max(5, args.steps))
         for key, fn in (("voxel_structured", bench_structured), ("image_10m", bench_image_10m), ("image_c1", bench_image_c1)):
@@ -436,6 +453,57 @@ def bench_c5_share(tiled, dev, impl):
     del cols
     torch.cuda.empty_cache()
     return res
+
+
+def bench_prebucketed(tiled, sets, n, t_first, t_last, dev, reps):
+    """SURVEY.md 8(d) "with and without the bucketing pre-pass": BASELINE.json's north_star defines its kernel on "events
+    pre-sorted/bucketed by output tile".  The streams of the headline loop are bucketed ONCE (evk_bucket_events_f32: 16-byte
+    records (x, y, t, p), tile-contiguous; not timed as part of the kernel, reported beside it), then evk_voxel_tiled_f32 --
+    LDS tile accumulate, exclusive plain-store flush -- is timed with HIP events on the launch stream, rotating over the
+    bucketed streams (640 MB of records: every launch reads its records from HBM).  Algorithmic bytes = 16 B/event + the grid,
+    exactly what this kernel moves (`traffic`: the committed PMC pass of the same workload)."""
+    from event_utils_amd import _lib, _device as D
+    L = _lib.lib()
+    tw, th = 5, 4        # 32 x 16 pixel tiles: 600 tiles at 640x480 (DESIGN.md section 3, K2)
+    bks = [tiled.bucket_events(*c, 0, H, W, tw, th) for c in sets]
+    nbytes = int(L.evk_voxel_tiled_staging_bytes(bks[0].ntiles, n, B, tw, th))
+    staging = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    it = [0]
+
+    def kernel():
+        it[0] += 1
+        bk = bks[it[0] % len(bks)]
+        _lib.call("evk_voxel_tiled_f32", D.ptr(bk.records), D.ptr(bk.bucket_start), n, H, W, tw, th, t_first, t_last, B,
+                  _lib.EVK_VOXEL_OVERWRITE, D.ptr(out), D.ptr(staging), nbytes, D.stream())
+
+    def bucket():
+        it[0] += 1
+        k = it[0] % len(bks)
+        tiled.bucket_events(*sets[k], 0, H, W, tw, th, into=bks[k])
+    reps = max(reps, len(bks)) // len(bks) * len(bks)
+    k_ms = tiled._time_ms(kernel, reps)
+    # self-check of what was timed: the grid of stream 1 against the one-pass call's (both accumulate float64 in LDS)
+    it[0] = 0
+    kernel()
+    ref = torch.empty_like(out)
+    tiled.voxel_f32(*sets[1 % len(sets)], t_first, t_last, B, H, W, ref, None, impl="tiled", fresh=True)
+    err = float((out - ref).abs().max().item())
+    scale = float(ref.abs().max().item())
+    b_ms = tiled._time_ms(bucket, reps)
+    alg = 16.0 * n + B * H * W * 4.0
+    traffic, src, _ = pmc_traffic("k_voxel_tiled", "prebucketed")
+    return {"workload": "configs[1] with the events ALREADY bucketed by output tile (north_star's own assumption): 10M events, "
+                        "640x480, 5 bins; 16-byte (x, y, t, p) records, tile-contiguous, %d streams rotating (HBM-resident)" % len(bks),
+            "kernel": "k_voxel_tiled (evk_voxel_tiled_f32): one workgroup per 32x16 tile, float64 LDS accumulators, plain-store flush",
+            "kernel_ms": round(k_ms, 4), "Mevents_per_s": round(n / k_ms / 1e3, 1),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                         "algorithmic_bytes": alg},
+            "bucketing_ms": round(b_ms, 4),
+            "bucketing_note": "evk_bucket_events_f32 (histogram + scan + write-combined scatter), paid once per stream; with it "
+                              "the pair takes kernel_ms + bucketing_ms -- the headline's one-pass call does both jobs in ms_per_step",
+            "max_abs_diff_vs_one_pass_call": err, "grid_max": scale, "checked": bool(err <= 1e-5 * max(scale, 1.0))}
 
 
 def bench_native(DeviceEvents, voxel, x, y, t, p, B, H, W, impl, reps):
@@ -624,7 +692,7 @@ def pmc_traffic(kernel, tag):
     (profiles/rNN_pmc_traffic.json, newest round first: separate --pmc passes for reads and writes of this same workload, gfx950 corrections
     applied as MI355X_MICROARCH.md prescribes; tools/profile_round.sh).  PMC counters cannot be collected from inside the
     timed process, so this is the recorded measurement of the workload `tag`; None when the profile is absent."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)
         if not os.path.isfile(path):
             continue
@@ -799,7 +867,55 @@ def bench_cmax(E, DeviceEvents, dev, impl):
         c4[mode]["evk_bfgs"] = {"seconds": round(best, 4), "argmax": [round(float(v), 3) for v in np.asarray(a3, dtype=float)],
                                 "speedup_vs_fmin_bfgs": round(dt / best, 2)}
     out["c4"] = c4
+    del ev
+    torch.cuda.empty_cache()
+    # ---- optimizer='evk_bfgs' WARM and COLD at both cmax configurations (round 6): every real optimize() call
+    #      (events_cmax.py:348-368 on a fresh window of events) is cold -- the bucketing of the events by IWE tile is inside it
+    try:
+        out["evk_bfgs"] = bench_evk_bfgs(E, DeviceEvents, impl)
+    except Exception as e:  # noqa: BLE001
+        out["evk_bfgs"] = {"error": repr(e)}
     return out
+
+
+def bench_evk_bfgs(E, DeviceEvents, impl):
+    """optimize_contrast(..., optimizer='evk_bfgs') with the consistent analytic gradient on the moving-edge scene at configs[2]
+    size (10 M events, 640x480) and configs[3] size (50 M, 1280x720): `warm_seconds` = best of 3 on a DeviceEvents whose events
+    are already bucketed (what rounds 4-5 reported), `cold_seconds` = median of 3 runs each on a FRESH DeviceEvents over the
+    same device columns (bucketing, record compaction and every first-use allocation inside the timed region)."""
+    import warnings
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast
+    res = {}
+    w = E.linvel_warp()
+    for tag, (n, Hs, Ws) in (("c3_10M_640x480", (N_PER_GPU, H, W)), ("c4_50M_1280x720", (50_000_000, 720, 1280))):
+        x, y, t, p = structured_scene(3, n, Hs, Ws)
+        ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+
+        def run(e):
+            o = E.variance_objective()
+            o.sensor_size, o.impl, o.reference_exact = (Hs, Ws), impl, False
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                a = optimize_contrast(e, None, None, None, w, o, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0,
+                                      img_size=(Hs, Ws))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, np.asarray(a, dtype=float)
+        run(ev)                                   # first use of every buffer / code object
+        warm = min(run(ev)[0] for _ in range(3))
+        cold, arg = [], None
+        for _ in range(3):
+            fresh = DeviceEvents(ev.x, ev.y, ev.t, ev.p, t_host=ev._t_host)
+            dt, arg = run(fresh)
+            cold.append(dt)
+            del fresh
+        res[tag] = {"warm_seconds": round(warm, 5), "cold_seconds": round(float(np.median(cold)), 5),
+                    "cold_runs": [round(v, 5) for v in cold], "cold_minus_warm_ms": round((float(np.median(cold)) - warm) * 1e3, 3),
+                    "argmax_cold": [round(float(v), 3) for v in arg], "true_flow": [40.0, -25.0]}
+        del ev
+        torch.cuda.empty_cache()
+    return res
 
 
 def bench_c5(E, DeviceEvents, dist, rank, world, dev, impl):

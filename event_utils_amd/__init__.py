@@ -20,5 +20,6 @@ from .contrast_max.events_cmax import optimize, optimize_contrast  # noqa: F401
 from .util.event_util import events_bounds_mask  # noqa: F401
 from .events import DeviceEvents  # noqa: F401
 from ._device import check_errors, error_mode  # noqa: F401
+from .tiled import release_scratch  # noqa: F401
 
 __version__ = "0.1.0"

@@ -83,6 +83,9 @@ SIGNATURES = {
     "evk_event_image_add_f64": [P, P, P, c_int64, c_int, c_int, P, P, P],
     "evk_dense_rank_f64": [P, c_int64, P, P, c_int64, P],
     "evk_minmax_normalise_f64": [P, c_int64, P, P, P],
+    "evk_polarity_weights_f32": [P, c_int64, P, P, P],
+    "evk_abs_max": [P, c_int, c_int64, P, P],
+    "evk_abs": [P, c_int, c_int64, P, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
     "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P],
     "evk_bucket_events_native_f32": [P, P, c_int, P, c_int, c_double, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,

@@ -100,6 +100,15 @@ def cut_events_to_lifespan(xs, ys, ts, ps, params, pixel_crossings, minimum_even
     return xs[s_idx:-1], ys[s_idx:-1], ts[s_idx:-1], ps[s_idx:-1]
 
 
+def _abs_device(t):
+    """|t| of a float32 / float64 tensor through evk_abs (device tensors stay on the device, host tensors come back)."""
+    dev = D.require_gpu()
+    td = D.to_device(t, t.dtype if t.dtype in (torch.float32, torch.float64) else torch.float64, dev)
+    out = torch.empty_like(td)
+    _lib.call("evk_abs", D.ptr(td), td.element_size(), td.numel(), D.ptr(out), D.stream())
+    return out if t.is_cuda else out.to(t.device)
+
+
 def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, use_polarity=True,
             return_events=False, return_per_event_contrast=False, sensor_size=None):
     """
@@ -120,7 +129,7 @@ def get_iwe(params, xs, ys, ts, ps, warpfunc, img_size, compute_gradient=False, 
         ev = xs
         xs, ys, ts, ps = (c.double() for c in (ev.x, ev.y, ev.t, ev.p * ev.p_scale))
     if not use_polarity:
-        ps = np.abs(ps) if not isinstance(ps, torch.Tensor) else ps.abs()
+        ps = np.abs(ps) if not isinstance(ps, torch.Tensor) else _abs_device(ps)
     t0 = ts[-1] if not isinstance(ts, torch.Tensor) else float(ts[-1].item())
     xw, yw, jx, jy = warpfunc.warp(xs, ys, ts, ps, t0, params, compute_grad=compute_gradient)
     mask = events_bounds_mask(xw, yw, 0, img_size[1], 0, img_size[0])

@@ -1,0 +1,74 @@
+// Small element-wise helpers of the host layer (round 6): the last pieces of arithmetic the Python side still did with torch on
+// the product path -- the polarity weights of events_to_neg_pos_voxel_torch's two-voxelisation route (voxel_grid.py:173-174),
+// max |p| of an event set (the bound of the IWE kernels' fixed-point accumulators), |p| for use_polarity=False
+// (objectives.py:184-185).  Streaming kernels, 16-byte loads where the pointers allow.
+#include "evk_common.h"
+
+namespace evk {
+
+__global__ void __launch_bounds__(EVK_BLOCK) k_polarity_weights(const float *__restrict__ p, int64_t n, float *__restrict__ pos,
+                                                               float *__restrict__ neg) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        if (pos) pos[i] = v > 0.0f ? 1.0f : 0.0f;     // torch.where(ps > 0, 1.0, 0.0): a NaN polarity is in neither grid
+        if (neg) neg[i] = v <= 0.0f ? 1.0f : 0.0f;    // torch.where(ps <= 0, 1.0, 0.0)
+    }
+}
+
+// max |p| as a BIT PATTERN: the patterns of non-negative floats order like the values, and a NaN's pattern lies above every
+// finite one -- so an unsigned atomic max propagates NaN as torch's max() does
+template <typename T>
+__global__ void __launch_bounds__(EVK_BLOCK) k_abs_max(const T *__restrict__ p, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long b;
+        if constexpr (sizeof(T) == 4) b = (unsigned long long)(__float_as_uint((float)p[i]) & 0x7FFFFFFFu);
+        else b = (unsigned long long)__double_as_longlong((double)p[i]) & 0x7FFFFFFFFFFFFFFFull;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_max(out, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(EVK_BLOCK) k_abs(const T *__restrict__ in, int64_t n, T *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] < (T)0 ? -in[i] : (in[i] == (T)0 ? (T)0 : in[i]);   // |x| with -0.0 -> +0.0 (and NaN kept)
+}
+
+}  // namespace evk
+
+using namespace evk;
+
+extern "C" int evk_polarity_weights_f32(const float *p, int64_t n, float *pos, float *neg, void *stream) {
+    if (n < 0 || (n > 0 && (!p || (!pos && !neg)))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_polarity_weights<<<stream_grid(n), EVK_BLOCK, 0, (hipStream_t)stream>>>(p, n, pos, neg);
+    return launch_status();
+}
+
+// out8: 8 bytes of device memory; receives the bit pattern of max |p| (float32 pattern in the low word for elem_bytes 4,
+// float64 pattern for 8), 0 for n == 0
+extern "C" int evk_abs_max(const void *p, int elem_bytes, int64_t n, void *out8, void *stream) {
+    if (n < 0 || !out8 || (n > 0 && !p) || (elem_bytes != 4 && elem_bytes != 8)) return EVK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out8, 0, 8, s);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return EVK_OK;
+    if (elem_bytes == 4) k_abs_max<float><<<stream_grid(n, 4), EVK_BLOCK, 0, s>>>((const float *)p, n, (unsigned long long *)out8);
+    else k_abs_max<double><<<stream_grid(n, 4), EVK_BLOCK, 0, s>>>((const double *)p, n, (unsigned long long *)out8);
+    return launch_status();
+}
+
+extern "C" int evk_abs(const void *in, int elem_bytes, int64_t n, void *out, void *stream) {
+    if (n < 0 || (n > 0 && (!in || !out)) || (elem_bytes != 4 && elem_bytes != 8)) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (elem_bytes == 4) k_abs<float><<<stream_grid(n), EVK_BLOCK, 0, s>>>((const float *)in, n, (float *)out);
+    else k_abs<double><<<stream_grid(n), EVK_BLOCK, 0, s>>>((const double *)in, n, (double *)out);
+    return launch_status();
+}

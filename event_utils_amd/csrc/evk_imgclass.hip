@@ -58,8 +58,11 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_rank_flags(const double *__restri
         flag[i] = (i > 0 && sorted[i] != sorted[i - 1]) ? 1u : 0u;      // (numeric: -0.0 and +0.0 share a rank)
 }
 __global__ void __launch_bounds__(EVK_BLOCK) k_rank_scatter(const uint32_t *__restrict__ rank, const uint32_t *__restrict__ where,
-                                                            int64_t n, double *__restrict__ out) {
-    const double top = (double)rank[n - 1];      // the largest dense rank (0 for a constant image: 0 / 0 = NaN, as upstream)
+                                                            const double *__restrict__ sorted, int64_t n, double *__restrict__ out) {
+    double top = (double)rank[n - 1];      // the largest dense rank (0 for a constant image: 0 / 0 = NaN, as upstream)
+    // A NaN pixel: scipy.stats.rankdata (image.py:371) propagates it to EVERY rank.  The radix sort orders bit patterns, so a
+    // NaN sits at one end of the sorted keys (sign bit clear: behind +inf; set: in front of -inf)
+    if (sorted[0] != sorted[0] || sorted[n - 1] != sorted[n - 1]) top = __builtin_nan("");
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[where[i]] = (double)rank[i] / top;
 }
@@ -156,7 +159,7 @@ extern "C" int evk_dense_rank_f64(const double *image, int64_t npix, double *out
     tb = rank_temp_bytes(npix);
     e = hipcub::DeviceScan::InclusiveSum(temp, tb, (const uint32_t *)flag, iota, (int)npix, s);   // iota now holds the ranks
     if (e != hipSuccess) return (int)e;
-    k_rank_scatter<<<stream_grid(npix), EVK_BLOCK, 0, s>>>(iota, where, npix, out);
+    k_rank_scatter<<<stream_grid(npix), EVK_BLOCK, 0, s>>>(iota, where, keys, npix, out);
     return launch_status();
 }
 

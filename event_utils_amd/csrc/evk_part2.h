@@ -243,8 +243,8 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     auto early_publish = [&]() {
         EVK_HANDOVER_ACQUIRE();
         __hip_atomic_store(index + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (host_report && oob) {
-            const uint32_t cnt = __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_report) {   // (an optional argument of its own: {seq, 0} for a caller that passes no counter)
+            const uint32_t cnt = oob ? __hip_atomic_load(oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(host_report),
                                (unsigned long long)seq | ((unsigned long long)cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -4,12 +4,15 @@
 // full re-orthogonalisation, all in float64 in ONE workgroup (the images are <= 4 MB and L2-resident; two matrix-vector products
 // per step, at most 96 steps), then a bisection on the tridiagonal matrix the iteration leaves.  Round 5: until then the Gram
 // matrix and its eigenvalues came from torch (rocBLAS + rocSOLVER) -- the one place a library routine computed on this path.
+#include <mutex>
+
 #include "evk_common.h"
 
 namespace evk {
 
 #define SPEC_THREADS 1024
 #define SPEC_MAX_STEPS 96
+#define SPEC_MAX_RESTARTS 8    // sweeps of <= SPEC_MAX_STEPS steps, each starting from the previous one's Ritz vector
 #define SPEC_MAX_DIM 4096      // longest image side (the two work vectors live in LDS)
 
 // block-wide sum of one double per thread; every thread gets the total (two barriers)
@@ -62,6 +65,13 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
     for (int i = tid; i < n; i += SPEC_THREADS) v[i] /= nrm;
     __syncthreads();
     const int msteps = n < SPEC_MAX_STEPS ? n : SPEC_MAX_STEPS;
+    __shared__ double lam_sh;
+    // RESTARTS (round 6).  96 steps need not be enough for a slowly converging spectrum, and a Ritz value is a LOWER bound: the
+    // iteration used to return it unchecked.  Now the Ritz vector y is formed, the true residual |op(y) - lambda y| is
+    // measured (|lambda - an eigenvalue| <= that residual, always), and while it exceeds 1e-10 lambda the iteration starts
+    // again FROM y (a thick restart with one vector: every sweep begins where the last one ended), at most SPEC_MAX_RESTARTS
+    // sweeps.  One more operator application per sweep; the usual image converges in the first.
+    for (int sweep_no = 0; sweep_no < SPEC_MAX_RESTARTS; ++sweep_no) {
     int m = 0;
     double scale = 0.0;                       // largest |alpha| so far: what "zero" is measured against
     for (int j = 0; j < msteps; ++j) {
@@ -123,7 +133,47 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
             }
             if (below >= m) hi = x; else lo = x;
         }
-        out[0] = m ? fmax(0.5 * (lo + hi), 0.0) : 0.0;
+        const double lam = m ? fmax(0.5 * (lo + hi), 0.0) : 0.0;
+        lam_sh = lam;
+        out[0] = lam;
+        // its eigenvector of the tridiagonal by the three-term recurrence (only a START for the check below: a poor vector
+        // shows as a large residual and a further sweep, never as a wrong answer)
+        double s0 = 0.0, s1 = 1.0, nn = 1.0;
+        coef[0] = 1.0;
+        for (int k = 0; k + 1 < m; ++k) {
+            const double b = beta[k] != 0.0 ? beta[k] : 1e-300;
+            double s2 = ((lam - alpha[k]) * s1 - (k > 0 ? beta[k - 1] * s0 : 0.0)) / b;
+            if (!(fabs(s2) < 1e150)) s2 = 0.0;
+            coef[k + 1] = s2, nn += s2 * s2, s0 = s1, s1 = s2;
+        }
+        nn = 1.0 / sqrt(nn);
+        for (int k = 0; k < m; ++k) coef[k] *= nn;
+    }
+    __syncthreads();
+    const double lam = lam_sh;
+    if (m == 0) break;
+    // Ritz vector y = sum_k s_k v_k -> v (normalised), true residual of (lam, y)
+    double yn = 0.0;
+    for (int i = tid; i < n; i += SPEC_THREADS) {
+        double y = 0.0;
+        for (int k = 0; k < m; ++k) y += coef[k] * basis[(int64_t)k * n + i];
+        v[i] = y, yn += y * y;
+    }
+    yn = sqrt(spec_block_sum(yn, red));
+    if (!(yn > 0.0)) break;
+    for (int i = tid; i < n; i += SPEC_THREADS) v[i] /= yn;
+    __syncthreads();
+    if (tall) { rows_times(v, u); __syncthreads(); cols_times(u, wv); }
+    else { cols_times(v, u); __syncthreads(); rows_times(u, wv); }
+    __syncthreads();
+    double r2 = 0.0, ry = 0.0;
+    for (int i = tid; i < n; i += SPEC_THREADS) ry += wv[i] * v[i];
+    const double rq = spec_block_sum(ry, red);          // Rayleigh quotient of y: never below lam's sweep, never above the truth
+    for (int i = tid; i < n; i += SPEC_THREADS) { const double d = wv[i] - rq * v[i]; r2 += d * d; }
+    const double rn = sqrt(spec_block_sum(r2, red));
+    if (tid == 0) out[0] = fmax(rq, lam);
+    if (rn <= 1e-10 * rq || !(rq > 0.0)) break;          // converged (or the zero image)
+    __syncthreads();
     }
 }
 
@@ -142,8 +192,12 @@ extern "C" int evk_spectral_norm_sq_f32(const float *img, int h, int w, double *
     if (scratch_bytes < evk_spectral_scratch_bytes(h, w)) return EVK_ESCRATCH;
     const int n = h < w ? h : w, big = h < w ? w : h;
     const size_t lds = (size_t)(2 * n + big + 3 * SPEC_MAX_STEPS + SPEC_THREADS / 64) * sizeof(double);
-    static bool attr = false;
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_spectral_norm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), attr = true;
+    static std::once_flag once[64];   // per DEVICE: the attribute belongs to the code object loaded there (and thread-safe)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [] {
+        (void)hipFuncSetAttribute((const void *)k_spectral_norm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    });
     k_spectral_norm_sq<<<1, SPEC_THREADS, lds, (hipStream_t)stream>>>(img, h, w, (double *)scratch, out);
     return launch_status();
 }

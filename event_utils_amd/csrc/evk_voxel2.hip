@@ -40,8 +40,10 @@ namespace evk {
 // twelve lists then leave room for the counting mode's accumulators of TWO workgroups per CU (VGA, 5 bins: 2 x 78.7 KB)
 #define V2_MAX_CHUNKS(WG) ((WG) == 768 ? 6 : 7)
 #endif
+#ifndef V2_CHUNK_CAP
 #define V2_CHUNK_CAP(WG) (64 * V2_MAX_CHUNKS(WG))  // per wave; 28 KB for 8 waves: with the padded accumulators (21 KB at VGA) three
                                            // workgroups still fit a CU's 160 KB
+#endif
 // FIXED (EVK_VOXEL_DETERMINISTIC): the cells are int64 multiples of 2^-32 instead of float64 -- integer adds commute, so the
 // grid is bit-identical from run to run and for any order of the events.  |contribution| < 2^30 and finite, else it is
 // counted in index[4] and left out (the wrapper raises).
@@ -74,8 +76,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     // segment}: ONE LDS read gives a lane group everything it needs for its load (a 2-byte (segment, chunk) entry followed
     // by a ds_bpermute of the table entry put two dependent LDS round trips, queued behind other waves' atomics, in front
     // of every load)
-    __shared__ uint2 cseg[NW][V2_CHUNK_CAP(WG)];
-    __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP(WG) : 1];   // REC 4: t_norm base of the chunk's sub-chunk
+    // (entry [CAP] of every list is a ZERO entry that is never overwritten: a lane group without a chunk reads it -- one v_min
+    // and an unconditional LDS read instead of a compare, two zero moves and two exec-masked reads per list access)
+    __shared__ uint2 cseg[NW][V2_CHUNK_CAP(WG) + 1];
+    __shared__ uint32_t cbase[REC == 4 ? NW : 1][REC == 4 ? V2_CHUNK_CAP(WG) + 1 : 1];   // REC 4: t_norm base of the chunk's sub-chunk
     const int ntiles = g.tiles_x * g.tiles_y;
     const uint32_t *part_start = index + V2_PART, *item_tile = index + V2_ITEM(ntiles);
     V2_T0();
@@ -150,6 +154,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     int *const s0 = reinterpret_cast<int *>(acc + (B + 1) * ppix);   // unit mode: acc = G[-1 .. B-1], then S0[0 .. B-1]
     V2_U(0);
     unsigned long long *const gq = reinterpret_cast<unsigned long long *>(acc);   // unit mode: G as int64
+    if (threadIdx.x < NW) {
+        cseg[threadIdx.x][V2_CHUNK_CAP(WG)] = make_uint2(0u, 0u);
+        if constexpr (REC == 4) cbase[threadIdx.x][V2_CHUNK_CAP(WG)] = 0u;
+    }
     if (unit) {
         for (int i = threadIdx.x; i < (B + 1) * ppix; i += WG) acc[i] = 0.0;
         for (int i = threadIdx.x; i < B * ppix; i += WG) s0[i] = 0;
@@ -236,6 +244,59 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     };
     auto one = [&](auto unit_tag, uint32_t lo_w, uint32_t hi_w, uint32_t ridx) {
         constexpr int UNIT = decltype(unit_tag)::value;   // 0: float64 / fixed-point cells, 1: S0 + G planes, 2: B int64 planes
+#ifndef V2_ENT_PREFETCH
+#define V2_ENT_PREFETCH 0   // (A/B) measured: 92.3 against 88.6 us at 50 M events / 720p with the prefetch (six more live registers in the rounds)
+#endif
+#ifndef V2_FAST_UNIT
+#define V2_FAST_UNIT 1   // (A/B)
+#endif
+        if constexpr (UNIT >= 1 && V2_FAST_UNIT && V2_ABLATE_B >= 4) {
+            // THE HOT PATH of the counting modes (round 6): a record with polarity +1 or -1 and t_norm in [0, B - 1) -- all but a
+            // handful of a call's records -- in ~24 vector instructions and ONE branch.  The SQ counters say this kernel is bound
+            // by instruction issue (52 M wave-level VALU instructions for 50 M events, profiles/r03_voxel_sq_counters.txt: ~96 us
+            // of a CU's four SIMDs), and the general code below spends ~38 VALU + ~10 scalar instructions and three taken
+            // branches per record on cases that do not occur here: the counting modes run only when EVERY polarity of the call
+            // is a unit (index[7]), so p is a sign -- p (2^31 - fi) and p fi (fi = (int)(f 2^31), f = t_norm - b0) are
+            // conditional negations of 32-bit integers, not float products and 64-bit shifts and subtractions; a record is
+            // never wide; and t_norm == B - 1 exactly (the stream's last time stamp) goes below with everything else that is rare
+            // -- zero polarity, escaped 4-byte records, NaN or out-of-range times --, so bin b0 + 1 always exists and its
+            // address is an addition.  Bit-identical to the general code: p f 2^31 is exact in float32 and truncation is odd.
+            uint32_t tbits, sgn;   // sgn = 0 (p = +1) or 0xFFFFFFFF (p = -1)
+            uint32_t bad;          // bit 31 set: not a unit polarity (or wide / escaped)
+            int cell;
+            if constexpr (REC == 8) {
+                cell = (int)(hi_w & V2_LOCAL_MASK);
+                tbits = lo_w;
+                bad = (hi_w & (0x7FFFFFFFu & ~V2_LOCAL_MASK)) == 0x3F800000u ? 0u : 0x80000000u;   // |p| == 1 and not wide
+                sgn = (uint32_t)((int32_t)hi_w >> 31);
+            } else {
+                cell = (int)(lo_w & V2_LOCAL_MASK);
+                tbits = hi_w + (lo_w >> V2_DELTA_SHIFT);
+                bad = lo_w << (30 - V2_CODE_SHIFT);                              // code 0 / 1 = +1 / -1 (2: zero, 3: escaped): its high bit
+                sgn = (uint32_t)((int32_t)(lo_w << (31 - V2_CODE_SHIFT)) >> 31);
+            }
+            const float tf = __uint_as_float(tbits);
+            // t_norm in [0, B - 1) as ONE unsigned compare of the bit patterns: non-negative floats order like their bits, and a
+            // negative value, -0.0 or a NaN has a pattern above that of B - 1 (they all take the general path below)
+            const bool ok = ((tbits | (bad & 0x80000000u)) < __float_as_uint(bm1));
+            if (__builtin_expect(ok, 1)) {
+                const int b0 = (int)tf;
+                const uint32_t fi = (uint32_t)(int)((tf - (float)b0) * 2147483648.0f);
+                const int off = __mul24(b0, ppix) + cell;
+                const uint32_t lo2 = (fi ^ sgn) - sgn;                           // p fi
+                const unsigned long long v2 = (unsigned long long)lo2 | ((unsigned long long)(uint32_t)((int32_t)lo2 >> 31) << 32);
+                if constexpr (UNIT == 2) {
+                    const uint32_t lo1 = ((0x80000000u - fi) ^ sgn) - sgn;      // p (2^31 - fi): magnitude in [1, 2^31], high word = sign
+                    __hip_atomic_fetch_add(gq + off, (unsigned long long)lo1 | ((unsigned long long)sgn << 32), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(gq + off + ppix, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    __hip_atomic_fetch_add(gq + ppix + off, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(s0 + off, (int)(sgn | 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return;
+            }
+        }
         // REC 8: lo_w = t_norm bits, hi_w = polarity | cell.  REC 4: lo_w = the record word, hi_w = its sub-chunk's base.
         int local;
         float p, tn;
@@ -271,8 +332,13 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 const int b0 = (int)tn;
                 unsigned long long *cell = gq + __mul24(b0, ppix) + local;
                 const int fx = (int)((p * (tn - (float)b0)) * 2147483648.0f);
+                if (V2_ABLATE_B < 3) {   // (timing builds) weights and addresses, no atomics
+                    if (fx == 0x12345677 && cell == gq + 1) acc[0] = 1.0;
+                    return;
+                }
                 __hip_atomic_fetch_add(cell, (unsigned long long)(((long long)(int)p << 31) - (long long)fx), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (V2_ABLATE_B < 4) return;   // (timing builds) one atomic per event
                 // (b0 + 1 == B only for t_norm == B - 1, where fx is 0)
                 __hip_atomic_fetch_add(cell + (b0 + 1 < B ? ppix : 0), (unsigned long long)(long long)fx, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -336,7 +402,14 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
     struct PairU {         // NOT packed: the compiler may assume the natural alignment it does not have (the hardware does not care)
         Pair v;
     };
-    auto load_pair = [&](uint32_t pos) -> Pair { return reinterpret_cast<const PairU *>(static_cast<const Rec1 *>(rec_) + pos)->v; };
+#ifndef V2_ABLATE_LOADS
+#define V2_ABLATE_LOADS 0   // (timing builds, results wrong) 1: every record load lands in the first 1 MB of the runs (L2-resident); 2: in its first 16 KB (L1)
+#endif
+    auto load_pair = [&](uint32_t pos) -> Pair {
+        if (V2_ABLATE_LOADS == 1) pos &= 0x3FFFFu;
+        if (V2_ABLATE_LOADS == 2) pos &= 0xFFFu;
+        return reinterpret_cast<const PairU *>(static_cast<const Rec1 *>(rec_) + pos)->v;
+    };
     auto pair = [&](auto unit_tag, const Pair &v, uint32_t bbits, uint32_t pos, uint32_t end) {  // records pos, pos + 1 of a segment ending at `end`
         if constexpr (REC == 8) {
             one(unit_tag, v.x, v.y, pos);
@@ -354,9 +427,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
         auto meta = [&](uint32_t j0, uint2(&cs)[U], uint32_t(&cb_)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t j = j0 + 16u * u + grp;
-                cs[u] = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
-                if constexpr (REC == 4) cb_[u] = j < total ? cbase[wave][j] : 0u;
+                uint32_t j = j0 + 16u * u + grp;
+                j = j < total ? j : (uint32_t)V2_CHUNK_CAP(WG);   // (the zero entry)
+                cs[u] = cseg[wave][j];
+                if constexpr (REC == 4) cb_[u] = cbase[wave][j];
             }
         };
         auto fire = [&](const uint2(&cs)[U], Pair(&v)[U]) {
@@ -442,13 +516,14 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 if constexpr (REC == 4) bn[e] = have ? bases[my] : 0u;
             }
         };
+        // (round 6: the NEXT batch's entries are fetched ahead of the last pass's rounds -- 4096 uncoalesced 4-byte loads per tile,
+        // ~15 % of the kernel's wave cycles at 50 M events / 720p when every batch began by waiting for them; entries are still
+        // fetched again where a rare path needs them after the rounds)
+        uint32_t ent[E], bb[E];
+        fetch(sc_lo, ent, bb);
         __syncthreads();  // the accumulators are zero before the first adds
         for (int base = sc_lo; base < sc_hi; base += bsz) {
-            // (no prefetch of the next batch's entries, and entries are fetched again where a rare path needs them after
-            // the rounds: their registers are what the hot loop needs)
-            uint32_t ent[E], bb[E];
             uint32_t sum = 0, longs = 0, packed = 0;   // packed: chunks of entry e in bits [4e, 4e + 4)
-            fetch(base, ent, bb);
             auto mych_of = [&](int e) { return (packed >> (4 * e)) & 15u; };
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -489,8 +564,10 @@ __global__ void __launch_bounds__(WG, V2_TILES_WAVES(REC)) k_voxel_tiles2(const 
                 }
                 V2_U(4);
                 V2_U(5);
+                if (V2_ENT_PREFETCH && pass == npass - 1) fetch(base + bsz, ent, bb);   // (beyond sc_hi: zeros)
                 rounds(unit_tag, total);
             }
+            if (!V2_ENT_PREFETCH) fetch(base + bsz, ent, bb);
             V2_U(6);
             // long segments: listed in the (consumed) chunk list, then streamed one after the other
             uint32_t nlong = 0;
@@ -752,7 +829,7 @@ extern "C" int evk_voxel2_num_tiles(int h, int wd, int tile_w, int tile_h) {
 // LDS of a tile workgroup with `planes` float64 accumulator planes: the accumulators + the chunk lists (512 threads, either
 // record size); the limit voxel2() enforces
 static size_t v2_tiles_lds(const TileGridG &g, int planes) {
-    return (size_t)planes * sizeof(acc_t) * g.pitch * g.th + 12 * 8 * V2_CHUNK_CAP(512) + 64;
+    return (size_t)planes * sizeof(acc_t) * g.pitch * g.th + 12 * 8 * (V2_CHUNK_CAP(512) + 1) + 64;
 }
 #define V2_TILES_LDS_LIMIT (150 * 1024)
 
@@ -789,7 +866,7 @@ static void launch_tiles(int items, size_t lds_dyn, hipStream_t s, const void *r
     (void)hipGetDevice(&dev);
     std::call_once(once[dev & 63], [] {
         (void)hipFuncSetAttribute((const void *)k_voxel_tiles2<WG, U, SPLIT, FIXED, REC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * V2_CHUNK_CAP(WG) - 256);
+                                  160 * 1024 - (REC == 4 ? 12 : 8) * (WG / 64) * (V2_CHUNK_CAP(WG) + 1) - 256);
     });
     k_voxel_tiles2<WG, U, SPLIT, FIXED, REC><<<items, WG, lds_dyn, s>>>(rec, pw, bases, table, index, g, q, B, kf, vox, staging, band,
                                                                         live_status, live_epoch);
@@ -810,6 +887,19 @@ static hipStream_t v2_live_stream() {
         (void)hipFuncSetAttribute((const void *)k_voxel_live<V2L_U>, hipFuncAttributeMaxDynamicSharedMemorySize, V2L_LDS_REQUEST);
     });
     return side[dev & 63];
+}
+// the event the caller's stream waits on for the consumer kernel's end (per device; re-recorded by every live call: a wait
+// already enqueued keeps the record it was issued against)
+static hipEvent_t v2_live_event() {
+    static std::once_flag once[64];
+    static hipEvent_t ev[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [dev] {
+        ev[dev & 63] = nullptr;
+        if (hipEventCreateWithFlags(&ev[dev & 63], hipEventDisableTiming) != hipSuccess) ev[dev & 63] = nullptr;
+    });
+    return ev[dev & 63];
 }
 static uint32_t v2_live_epoch() {
     static std::atomic<uint32_t> counter{0};
@@ -866,6 +956,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
     // for (other geometries, split polarities, shared CUs, single stages, a stream that is being captured) run as ever.
     bool live = false;
     hipStream_t s2 = nullptr;
+    hipEvent_t live_done = nullptr;
     uint32_t epoch = 0;
     if constexpr (std::is_same<C, SrcF32>::value) {
         if ((flags & EVK_VOXEL2_LIVE) && band.tile_hi == 0 &&
@@ -887,6 +978,8 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
             LiveArgs la{live_progress, live_status, epoch, (uint32_t)v2_cap(n, ntiles), 400u};
             k_voxel_live<V2L_U><<<(ntiles + 1) / 2, V2L_WG, V2L_LDS_REQUEST - V2L_STATIC_LDS, s2>>>(
                 rec, (uint32_t)((int64_t)q.nsc * q.S * 8), table, g, q, B, flags & EVK_VOXEL_OVERWRITE, vox, la);
+            live_done = v2_live_event();
+            if (!live_done || hipEventRecord(live_done, s2) != hipSuccess) live_done = nullptr, (void)hipGetLastError();
         }
     } else if (!(flags & EVK_VOXEL2_TILES_ONLY)) {
         // (8-byte records in the 8 K-event geometry of a call that has its CUs to itself: the exact polarities are staged in
@@ -921,7 +1014,7 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         // while TWO workgroups still fit a CU -- that is what the 512 tiles of a VGA call need.
         const size_t lds_count = ((size_t)(B + 1) * sizeof(acc_t) + (size_t)B * 4) * g.pitch * g.th;
         auto two_fit = [](size_t acc_bytes, int wg, int rec) {
-            return 2 * (acc_bytes + (size_t)(rec == 4 ? 12 : 8) * (wg / 64) * V2_CHUNK_CAP(wg) + 256) <= (size_t)160 * 1024;
+            return 2 * (acc_bytes + (size_t)(rec == 4 ? 12 : 8) * (wg / 64) * (V2_CHUNK_CAP(wg) + 1) + 256) <= (size_t)160 * 1024;
         };
         const bool may_count = !sp && !(flags & EVK_VOXEL2_NO_COUNT) && n < ((int64_t)1 << 31);   // (int32 counts)
 #ifndef V2_U4
@@ -956,10 +1049,22 @@ static int voxel2(const C &c, int64_t n, int h, int wd, int tile_w, int tile_h, 
         if (count) kf |= EVK_VOXEL2_COUNT;
         else if (may_count && !(flags & EVK_VOXEL2_NO_COUNT2)) kf |= EVK_VOXEL2_COUNT2;   // the same integers in the float64 mode's B planes
         const bool wide_wg = wg == 768;
-        if (recb == 4) V2_TILES(512, 4);
+#ifndef V2_WG4
+#define V2_WG4 512   // (A/B) threads of a tile workgroup with 4-byte records
+#endif
+        if (recb == 4) V2_TILES(V2_WG4, 4);
         else if (wide_wg) V2_TILES(768, 8);
         else V2_TILES(512, 8);
 #undef V2_TILES
+    }
+    // The consumer kernel STARTED unordered (that is the overlap), but it must not outlive the call: a consumer that left its
+    // tiles or lost a take-over keeps polling `progress`, loading `table` / `rec` and finally CASes a word of `status` -- in
+    // buffers whose lifetime evk.h ties to `stream`, not to the library's side stream.  So the caller's stream waits for the
+    // consumer's end behind the tile kernel (bounded: every wait inside the consumer is, LiveArgs.wait_us): whatever follows
+    // on `stream` -- the next call's partition rewriting the records, a free of the scratch -- is ordered behind it.
+    if (live) {
+        if (!live_done) (void)hipStreamSynchronize(s2);   // (no event: the slow, safe form)
+        else if (hipStreamWaitEvent(s, live_done, 0) != hipSuccess) (void)hipGetLastError(), (void)hipStreamSynchronize(s2);
     }
     return launch_status();
 }

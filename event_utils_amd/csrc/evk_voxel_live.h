@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(V2L_WG, 5) k_voxel_live(const void *__restrict
 #endif
         const int local = (int)(hi_w & V2_LOCAL_MASK);
         const uint32_t pb = hi_w & V2_P_MASK;
-        // +1.0, -1.0, +0.0 carried by the record itself; everything else (wide, other values, -0.0) is not for this kernel
-        const bool unit = !(hi_w & V2_WIDE) & (((pb & 0x7FFFFFFFu) == 0x3F800000u) | (pb == 0u));
+        // +1.0, -1.0, +0.0 carried by the record itself; everything else (wide, other values, -0.0) is not for this kernel.
+        // A cell outside the tile's plane cannot come from this call's partition: the word is not a record of this call (a
+        // straggling consumer reading a buffer the NEXT call is rewriting) -- never form an LDS address from it
+        const bool unit = !(hi_w & V2_WIDE) & (((pb & 0x7FFFFFFFu) == 0x3F800000u) | (pb == 0u)) & (local < ppix);
         if (__builtin_expect(!unit, 0)) {
             __hip_atomic_fetch_or(&sh_leave, 1u << tsel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return;

@@ -6,6 +6,19 @@ import numpy as np
 import torch
 
 from . import _device as D
+from . import _lib
+
+
+def _abs_max(col):
+    """max |col| of a float32 / float64 device column as a python float (evk_abs_max: one streaming kernel, the maximum taken on
+    the bit patterns, so a NaN propagates as torch's max() does); one 8-byte read-back."""
+    c = col if col.is_contiguous() else col.contiguous()
+    out = torch.empty(1, dtype=torch.int64, device=c.device)
+    _lib.call("evk_abs_max", D.ptr(c), c.element_size(), c.numel(), D.ptr(out), D.stream())
+    bits = int(out.item())
+    if c.element_size() == 4:
+        return float(np.array([bits & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+    return float(np.array([bits], dtype=np.int64).view(np.float64)[0])
 
 
 def _f32_lossless(a):
@@ -170,7 +183,7 @@ class DeviceEvents:
             if self._cols is None and self.native.p_kind == 0:
                 self._p_absmax = 1.0 if len(self) else 0.0          # {0, 1} -> -1 / +1
             else:
-                self._p_absmax = float(self.p.abs().max().item()) if len(self) else 0.0
+                self._p_absmax = _abs_max(self.p) if len(self) else 0.0
         return self._p_absmax
 
     def slice(self, start, stop):

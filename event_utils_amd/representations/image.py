@@ -300,27 +300,55 @@ def _f64_columns(dev, *cols):
 
 
 class _DeviceImage:
-    """float64 (H, W) image resident on the GPU with the reference's attributes; `.image` is a numpy COPY (assign to it to
-    replace the device image: in-place edits of the copy are not seen)."""
+    """float64 (H, W) image resident on the GPU with the reference's attributes.  Upstream's `.image` is a plain mutable
+    ndarray (image.py:358,380) that callers edit in place (`obj.image[y, x] = v`, `obj.image *= k`) and keep references to; here
+    `.image` hands out a host MIRROR that stays coupled to the device image for as long as the caller holds it: its contents are
+    uploaded before every device-side operation of the object (so in-place edits are seen) and refreshed after every one that
+    changes the image (so a kept reference shows the new events) -- one small copy each way per call, only once `.image` has
+    been touched; the mirror is held weakly, a dropped one costs nothing."""
 
     def __init__(self, sensor_size):
         self.sensor_size = sensor_size
         self.num_pixels = sensor_size[0] * sensor_size[1]
         self._dev = D.require_gpu()
         self._img = torch.ones(tuple(int(v) for v in sensor_size), dtype=torch.float64, device=self._dev)
+        self._mirror = None
+
+    def _host_mirror(self):
+        return self._mirror() if self._mirror is not None else None
+
+    def _sync_in(self):
+        """Before a device-side operation: in-place edits of the handed-out mirror become the device image."""
+        h = self._host_mirror()
+        if h is not None:
+            self._img.copy_(torch.from_numpy(np.ascontiguousarray(h, dtype=np.float64)).reshape(self._img.shape))
+        return h
+
+    def _sync_out(self, h):
+        """After an operation that changed the device image: the mirror a caller still holds shows it."""
+        if h is not None:
+            h[...] = self._img.cpu().numpy()
 
     @property
     def image(self):
-        return self._img.cpu().numpy()
+        h = self._host_mirror()
+        if h is None:
+            import weakref
+            h = self._img.cpu().numpy()
+            self._mirror = weakref.ref(h)
+        return h
 
     @image.setter
     def image(self, value):
         a = np.asarray(value, dtype=np.float64)
         self._img = D.to_device(np.ascontiguousarray(a), torch.float64, self._dev)
+        self._mirror = None
 
     @property
     def device_image(self):
-        """The resident image (a torch float64 tensor; no copy)."""
+        """The resident image (a torch float64 tensor; no copy).  Edits of a host mirror handed out by `.image` are uploaded
+        first; a caller that writes to this tensor directly should re-read `.image` afterwards."""
+        self._sync_in()
         return self._img
 
     def _raise(self, oob):
@@ -336,6 +364,7 @@ class TimestampImage(_DeviceImage):
 
     def set_init(self, value):
         self._img = torch.full_like(self._img, float(value))
+        self._sync_out(self._host_mirror())
 
     def add_event(self, x, y, t, p):
         self.add_events([x], [y], [t], None)
@@ -347,8 +376,10 @@ class TimestampImage(_DeviceImage):
         H, W = self._img.shape
         oob = D.OobCounter(self._dev)
         last = torch.empty(H * W, dtype=torch.int32, device=self._dev)
+        mirror = self._sync_in()
         _lib.call("evk_timestamp_image_add_f64", D.ptr(xd), D.ptr(yd), D.ptr(td), n, H, W, D.ptr(self._img), D.ptr(last),
                   oob.ptr, D.stream())
+        self._sync_out(mirror)
         self._raise(oob)
 
     def get_image(self):
@@ -359,6 +390,7 @@ class TimestampImage(_DeviceImage):
         off = (-scratch.data_ptr()) % 256
         out = torch.empty((H, W), dtype=torch.float64, device=self._dev)
         import ctypes
+        self._sync_in()
         _lib.call("evk_dense_rank_f64", D.ptr(self._img), npix, D.ptr(out), ctypes.c_void_p(scratch.data_ptr() + off), nbytes,
                   D.stream())
         return out.cpu().numpy()
@@ -389,12 +421,15 @@ class EventImage(_DeviceImage):
             return
         H, W = self._img.shape
         oob = D.OobCounter(self._dev)
+        mirror = self._sync_in()
         _lib.call("evk_event_image_add_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), n, H, W, D.ptr(self._img), oob.ptr, D.stream())
+        self._sync_out(mirror)
         self._raise(oob)
 
     def get_image(self):
         H, W = self._img.shape
         out = torch.empty((H, W), dtype=torch.float64, device=self._dev)
         scratch = torch.empty(int(_lib.lib().evk_minmax_scratch_bytes()) // 8, dtype=torch.float64, device=self._dev)
+        self._sync_in()
         _lib.call("evk_minmax_normalise_f64", D.ptr(self._img), H * W, D.ptr(out), D.ptr(scratch), D.stream())
         return out.cpu().numpy()

@@ -141,10 +141,9 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
             return both[0], both[1]
         x, y, t, p = ev.x, ev.y, ev.t, ev.p          # (widened once) -> the two-voxelisation route below
         out_dev = target
-        pos = events_to_voxel_torch(x, y, t, torch.where(p > 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,
-                                    sensor_size=sensor_size)
-        neg = events_to_voxel_torch(x, y, t, torch.where(p <= 0, 1.0, 0.0).to(torch.float32), B, device=out_dev,
-                                    sensor_size=sensor_size)
+        pw, nw = _polarity_weights(p)
+        pos = events_to_voxel_torch(x, y, t, pw, B, device=out_dev, sensor_size=sensor_size)
+        neg = events_to_voxel_torch(x, y, t, nw, B, device=out_dev, sensor_size=sensor_size)
         return pos, neg
     if (temporal_bilinear and all(isinstance(a, torch.Tensor) for a in (xs, ys, ts, ps)) and len(xs)
             and ts.dtype != torch.float64 and ps.dtype != torch.float64):
@@ -160,13 +159,27 @@ def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(1
             oob.raise_if_set(IndexError, "index out of range for voxel grid of size %s" % ((B, H, W),), deferrable=resident)
             both = both.to(xs.device if device is None else device)
             return both[0], both[1]
-    pos_weights = torch.where(ps > 0, 1.0, 0.0).to(torch.float32)
-    neg_weights = torch.where(ps <= 0, 1.0, 0.0).to(torch.float32)
+    pos_weights, neg_weights = _polarity_weights(ps)
     voxel_pos = events_to_voxel_torch(xs, ys, ts, pos_weights, B, device=device, sensor_size=sensor_size,
                                       temporal_bilinear=temporal_bilinear)
     voxel_neg = events_to_voxel_torch(xs, ys, ts, neg_weights, B, device=device, sensor_size=sensor_size,
                                       temporal_bilinear=temporal_bilinear)
     return voxel_pos, voxel_neg
+
+
+def _polarity_weights(ps):
+    """The two weight columns of voxel_grid.py:173-174 -- torch.where(ps > 0, 1.0, 0.0), torch.where(ps <= 0, 1.0, 0.0) as
+    float32 -- from one kernel (evk_polarity_weights_f32), returned where `ps` lives."""
+    dev = D.require_gpu()
+    if isinstance(ps, torch.Tensor) and ps.dtype == torch.float64:      # (upstream's dtype error is raised by the voxelisation)
+        pd = D.to_device(ps, torch.float64, dev).to(torch.float32)
+    else:
+        pd = D.to_device(ps, torch.float32, dev)
+    pos, neg = torch.empty_like(pd), torch.empty_like(pd)
+    _lib.call("evk_polarity_weights_f32", D.ptr(pd), pd.numel(), D.ptr(pos), D.ptr(neg), D.stream())
+    if isinstance(ps, torch.Tensor) and not ps.is_cuda:
+        return pos.to(ps.device), neg.to(ps.device)
+    return pos, neg
 
 
 def events_to_neg_pos_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear=True):

@@ -92,6 +92,45 @@ def _zbuf(key, nwords, device):
     return b
 
 
+def release_scratch(device=None, stream=None):
+    """Drop the library's persistent per-stream scratch -- the grow-only record / table / staging buffers of the one-pass and
+    bucketed paths (80 MB after one 10 M-event call, tens of GB after a 2 G-event one), the zeroed indices, the spill pairs of
+    the fused objective evaluation and the small reduction slots -- for `device` (default: every device) and `stream` (a
+    torch.cuda.Stream or its id; default: every stream).  The memory returns to torch's caching allocator
+    (torch.cuda.empty_cache() hands it back to the driver); the next call on the stream allocates what it needs again, with a
+    freshly zeroed index.  Safe at any time on the owning stream: the buffers are torch tensors, freed in stream order.
+    Returns the number of bytes released."""
+    dev_index = None if device is None else __import__("torch").device(device).index
+    if stream is not None and not isinstance(stream, int):
+        stream = stream.cuda_stream
+    freed = 0
+
+    def match(di, sid):
+        return (dev_index is None or di == dev_index) and (stream is None or sid == stream)
+
+    for store, pos in ((_persist, (1, 2)), (_zpersist, (1, 2)), (_spill, (0, 1)), (D._scratch, (0, 1))):
+        for k in [k for k in store if match(k[pos[0]], k[pos[1]])]:
+            v = store.pop(k)
+            for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                if hasattr(t, "numel"):
+                    freed += t.numel() * t.element_size()
+    return freed
+
+
+def _rezero_on_failure(index, call):
+    """The one-pass paths keep self-resetting counters (tickets, per-tile totals, hand-over words) in `index`: a call that
+    fails between its launches could leave them mid-count.  Any failure therefore zeroes the index before it propagates -- the
+    next call starts from the state a freshly allocated index has (the IWE path's spill pair has the same rule, _spill_call)."""
+    try:
+        call()
+    except BaseException:
+        try:
+            index.zero_()
+        except Exception:   # noqa: BLE001  (a dead context: the original error is the one to report)
+            pass
+        raise
+
+
 class Buckets:
     """Events partitioned by tile: `records` (n_kept, 4) float32 (x, y, t, p), `bucket_start` (ntiles+1) offsets.
     After compact(): `records` is the 8-byte compact record buffer (include/evk.h, EVK_IWE_COMPACT) and `iwe_flag`
@@ -300,16 +339,17 @@ def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
     rows = voxel2_band_rows(H, W, B, nbands)
     report, seq = oob.report_args() if oob is not None else (None, 0)
     dummy = torch.empty(1, dtype=torch.float32, device=dev)      # (the partition does not touch the grid)
-    _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, H, W, tw, th, t_first, t_last, B,
-              flags | _lib.EVK_VOXEL2_PARTITION_ONLY, D.ptr(dummy), D.ptr(index), D.ptr(scratch), nbytes,
-              oob.ptr if oob is not None else None, report, seq, D.stream())
+    _rezero_on_failure(index, lambda: _lib.call(
+        "evk_voxel2_f32", *(D.ptr(c) for c in cols), n, H, W, tw, th, t_first, t_last, B,
+        flags | _lib.EVK_VOXEL2_PARTITION_ONLY, D.ptr(dummy), D.ptr(index), D.ptr(scratch), nbytes,
+        oob.ptr if oob is not None else None, report, seq, D.stream()))
 
     def gen():
         for y0, y1 in rows:
             r0, r1 = y0 // th, -(-y1 // th)
             band = torch.empty((B, y1 - y0, W), dtype=torch.float32, device=dev)
-            _lib.call("evk_voxel2_band_f32", n, H, W, tw, th, B, flags, r0, r1, D.ptr(band), D.ptr(index), D.ptr(scratch), nbytes,
-                      D.stream())
+            _rezero_on_failure(index, lambda: _lib.call("evk_voxel2_band_f32", n, H, W, tw, th, B, flags, r0, r1, D.ptr(band),
+                                                        D.ptr(index), D.ptr(scratch), nbytes, D.stream()))
             yield y0, y1, band
     return gen()
 
@@ -329,9 +369,9 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
             oob.ptr if oob is not None else None, report, seq, D.stream())
     if native is None:
-        _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail)
+        _rezero_on_failure(index, lambda: _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail))
     else:
-        _lib.call("evk_%s_native_f32" % ver, *native.head(), *tail)
+        _rezero_on_failure(index, lambda: _lib.call("evk_%s_native_f32" % ver, *native.head(), *tail))
     if det and not (stage & _lib.EVK_VOXEL2_PARTITION_ONLY):
         bad = int(index[4].item())          # synchronises: the deterministic mode is a debugging / verification mode
         if bad:
@@ -378,10 +418,10 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     tail = (tw, th, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None,
             report, seq, D.stream())
     if kind == "i32":
-        _lib.call("evk_image2_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, *tail)
+        _rezero_on_failure(index, lambda: _lib.call("evk_image2_nearest_i32", D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, *tail))
     else:
-        _lib.call("evk_image2_%s_f32" % ("bilinear" if kind == "bilinear" else "nearest"), D.ptr(xd), D.ptr(yd), D.ptr(wd_), n,
-                  H, W, clipx, clipy, *tail)
+        _rezero_on_failure(index, lambda: _lib.call("evk_image2_%s_f32" % ("bilinear" if kind == "bilinear" else "nearest"),
+                                                    D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, clipx, clipy, *tail))
     return True
 
 
@@ -684,14 +724,27 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
     return True
 
 
+WARM_MS = 40.0
+
+
 def _time_ms(fn, reps):
     """Average duration of fn's launches: `reps` back-to-back calls between ONE pair of HIP events on the launch
     stream.  (An event pair around every single launch adds the ~7-10 us the command processor needs between the
     event's timestamp write and the dispatch, which made a 62 us kernel read as 72 us against rocprofv3's
     kernel-trace; back to back the GPU stays fed, the host enqueue being shorter than the kernels timed here.)"""
+    import time
     import torch
+    # Round 6: the device's clocks ramp for tens of milliseconds after an idle phase (a 50 M-event stream generated on the host
+    # is seconds of idleness): the first ~10 launches of a fresh burst ran 15-20 % slower than the steady state (tile kernel at
+    # 50 M events / 720p: 128 us in the first 3 ms, 105-107 us from the third burst on; tools/warm_probe.py).  What a loop of
+    # such calls sustains is the steady state, so every timing is preceded by WARM_MS of the same launches.
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < WARM_MS:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

@@ -331,6 +331,7 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  *            is never seen torn; EVK_EALIGN if the pointer is not 8-byte aligned), so a caller that checks for
  *            dropped events lazily needs neither a device-to-host copy nor an event on the stream: the call numbered
  *            `seq` has counted all its events once host_report[0] == seq (sequence numbers grow by one per call).
+ *            Independent of `oob`: without a counter the report is {seq, 0}.
  *   flags    EVK_VOXEL_OVERWRITE, EVK_VOXEL_SPLIT_POLARITY as evk_voxel_tiled_f32;
  *            EVK_VOXEL_T_FROM_EVENTS: t_first / t_last are read on the device from t[0] / t[n-1] (voxel_grid.py:133-134
  *            takes them from the same column), so the caller needs no device-to-host transfer before the launch;
@@ -363,7 +364,9 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  * library's own (one per device, created on first use) takes every run as soon as it is written, two tiles per workgroup, one
  * workgroup beside the partition's on every CU; the tile kernel proper still follows on `stream` and accumulates only what
  * the consumers leave (polarities other than +1 / -1 / +0, hot tiles, rounds that did not arrive in time), so the call is
- * complete in `stream`'s order exactly as without the flag, and the grid is bit-identical to the counting mode's.  A request:
+ * complete in `stream`'s order exactly as without the flag (round 6: `stream` also WAITS for the consumer kernel's end behind
+ * the tile kernel -- an event on the side stream -- so index / scratch / the columns may be freed or rewritten by anything
+ * ordered after the call on `stream`, as for every other entry point), and the grid is bit-identical to the counting mode's.  A request:
  * calls the consumer kernel is not written for (more than 512 tiles, accumulators beyond 52 KB per pair of tiles, fewer than
  * two sub-chunks per partition workgroup, 4-byte records, split polarities, EVK_VOXEL2_SHARE_CU, single stages, a stream that
  * is being captured into a graph) run as without it.  evk_voxel2_f32 only. */
@@ -538,6 +541,16 @@ int evk_dense_rank_f64(const double *image, int64_t npix, double *out, void *scr
  * scratch: evk_minmax_scratch_bytes() bytes. */
 int64_t evk_minmax_scratch_bytes(void);
 int evk_minmax_normalise_f64(const double *image, int64_t npix, double *out, double *scratch, void *stream);
+
+/* ---- element-wise helpers of the host layer (evk_elem.hip, round 6) ---------------------------------------------
+ * evk_polarity_weights_f32: pos[i] = p[i] > 0 ? 1 : 0, neg[i] = p[i] <= 0 ? 1 : 0 -- the two weight columns of
+ *   events_to_neg_pos_voxel_torch (voxel_grid.py:173-174); either output may be NULL.
+ * evk_abs_max: the BIT PATTERN of max |p| over a float32 (elem_bytes 4) or float64 (8) column into 8 bytes of device memory
+ *   (a NaN anywhere gives a NaN pattern, as torch's max()); 0 for n == 0.
+ * evk_abs: out[i] = |in[i]| (get_iwe's use_polarity=False, objectives.py:184-185); float32 or float64. */
+int evk_polarity_weights_f32(const float *p, int64_t n, float *pos, float *neg, void *stream);
+int evk_abs_max(const void *p, int elem_bytes, int64_t n, void *out8, void *stream);
+int evk_abs(const void *in, int elem_bytes, int64_t n, void *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Event-sharded data parallelism: the path's only exchange step

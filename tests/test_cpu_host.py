@@ -306,7 +306,7 @@ def test_voxel_kernels_compile_without_register_spills(tmp_path):
         pytest.skip("no hipcc")
     from event_utils_amd.csrc import build as B
     src = os.path.join(B.HERE, "evk_voxel2.hip")
-    flags = [f for f in B.FLAGS if f not in ("-shared", "-ldl")]
+    flags = list(B.CFLAGS)
     subprocess.run([hipcc] + flags + ["-c", src, "-o", str(tmp_path / "v2.o"), "-save-temps=obj"], check=True, cwd=B.HERE,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
