@@ -34,6 +34,7 @@ EVK_IMAGE2_NO_FIXED = 512
 EVK_VOXEL2_REC4, EVK_VOXEL2_REC8, EVK_VOXEL2_NO_COUNT, EVK_VOXEL2_WG512 = 1024, 2048, 4096, 8192
 EVK_VOXEL2_LIVE = 16384
 EVK_VOXEL2_NO_COUNT2 = 32768
+EVK_STAGE_STATS, EVK_STAGE_COMPACT, EVK_STAGE_LEGACY_SCATTER = 16, 32, 64
 
 P = c_void_p  # every device / host pointer crosses as void*
 

@@ -66,6 +66,8 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
     __syncthreads();
     const int msteps = n < SPEC_MAX_STEPS ? n : SPEC_MAX_STEPS;
     __shared__ double lam_sh;
+    __shared__ double tdd[SPEC_MAX_STEPS], tdu[SPEC_MAX_STEPS], tdl[SPEC_MAX_STEPS], tdu2[SPEC_MAX_STEPS];
+    __shared__ int tpiv[SPEC_MAX_STEPS];
     // RESTARTS (round 6).  96 steps need not be enough for a slowly converging spectrum, and a Ritz value is a LOWER bound: the
     // iteration used to return it unchecked.  Now the Ritz vector y is formed, the true residual |op(y) - lambda y| is
     // measured (|lambda - an eigenvalue| <= that residual, always), and while it exceeds 1e-10 lambda the iteration starts
@@ -121,6 +123,7 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
             hi = fmax(hi, r);
         }
         lo = -hi;
+        const double hi0 = hi;   // (the Gershgorin bound: the scale of the tridiagonal)
         for (int it = 0; it < 200 && hi - lo > 1e-15 * fmax(fabs(hi), fabs(lo)); ++it) {
             const double x = 0.5 * (lo + hi);
             int below = 0;                    // eigenvalues < x
@@ -135,19 +138,52 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
         }
         const double lam = m ? fmax(0.5 * (lo + hi), 0.0) : 0.0;
         lam_sh = lam;
-        out[0] = lam;
-        // its eigenvector of the tridiagonal by the three-term recurrence (only a START for the check below: a poor vector
-        // shows as a large residual and a further sweep, never as a wrong answer)
-        double s0 = 0.0, s1 = 1.0, nn = 1.0;
-        coef[0] = 1.0;
-        for (int k = 0; k + 1 < m; ++k) {
-            const double b = beta[k] != 0.0 ? beta[k] : 1e-300;
-            double s2 = ((lam - alpha[k]) * s1 - (k > 0 ? beta[k - 1] * s0 : 0.0)) / b;
-            if (!(fabs(s2) < 1e150)) s2 = 0.0;
-            coef[k + 1] = s2, nn += s2 * s2, s0 = s1, s1 = s2;
+        out[0] = lam, out[1] = 0.0;
+        // its eigenvector of the tridiagonal by INVERSE ITERATION (a tridiagonal LU with partial pivoting, three solves): the
+        // three-term recurrence breaks down exactly where the Lanczos iteration does -- an invariant subspace, beta ~ 0 (images
+        // of a handful of events) -- and a poor vector would show as a large residual of a VALUE that is exact there
+        {
+            const double sig = lam + 1e-13 * fmax(hi0, 1e-300);   // (just above the eigenvalue: T - sig I is non-singular)
+            for (int k = 0; k < m; ++k) {
+                tdd[k] = alpha[k] - sig;
+                tdu[k] = tdl[k] = k + 1 < m ? beta[k] : 0.0;
+                tdu2[k] = 0.0, tpiv[k] = 0, coef[k] = 1.0 + 0.01 * k;
+            }
+            const double tiny = 1e-30 * fmax(hi0, 1e-300);
+            for (int k = 0; k + 1 < m; ++k) {
+                if (fabs(tdd[k]) >= fabs(tdl[k])) {
+                    if (tdd[k] == 0.0) tdd[k] = tiny;
+                    const double f = tdl[k] / tdd[k];
+                    tdl[k] = f, tdd[k + 1] -= f * tdu[k], tpiv[k] = 0;
+                } else {
+                    const double f = tdd[k] / tdl[k];
+                    tdd[k] = tdl[k], tdl[k] = f;
+                    const double t2 = tdd[k + 1];
+                    tdd[k + 1] = tdu[k] - f * t2;
+                    if (k + 2 < m) tdu2[k] = tdu[k + 1], tdu[k + 1] = -f * tdu2[k];
+                    tdu[k] = t2, tpiv[k] = 1;
+                }
+            }
+            if (m && tdd[m - 1] == 0.0) tdd[m - 1] = tiny;
+            for (int it = 0; it < 3; ++it) {
+                for (int k = 0; k + 1 < m; ++k) {
+                    if (tpiv[k]) { const double t2 = coef[k]; coef[k] = coef[k + 1], coef[k + 1] = t2; }
+                    coef[k + 1] -= tdl[k] * coef[k];
+                }
+                for (int k = m - 1; k >= 0; --k) {
+                    double r = coef[k];
+                    if (k + 1 < m) r -= tdu[k] * coef[k + 1];
+                    if (k + 2 < m) r -= tdu2[k] * coef[k + 2];
+                    coef[k] = r / tdd[k];
+                }
+                double nn = 0.0, big = 0.0;
+                for (int k = 0; k < m; ++k) big = fmax(big, fabs(coef[k]));
+                if (!(big > 0.0) || !(big < 1e300)) { for (int k = 0; k < m; ++k) coef[k] = k == 0 ? 1.0 : 0.0; break; }
+                for (int k = 0; k < m; ++k) coef[k] /= big, nn += coef[k] * coef[k];
+                nn = 1.0 / sqrt(nn);
+                for (int k = 0; k < m; ++k) coef[k] *= nn;
+            }
         }
-        nn = 1.0 / sqrt(nn);
-        for (int k = 0; k < m; ++k) coef[k] *= nn;
     }
     __syncthreads();
     const double lam = lam_sh;
@@ -171,7 +207,7 @@ __global__ void __launch_bounds__(SPEC_THREADS) k_spectral_norm_sq(const float *
     const double rq = spec_block_sum(ry, red);          // Rayleigh quotient of y: never below lam's sweep, never above the truth
     for (int i = tid; i < n; i += SPEC_THREADS) { const double d = wv[i] - rq * v[i]; r2 += d * d; }
     const double rn = sqrt(spec_block_sum(r2, red));
-    if (tid == 0) out[0] = fmax(rq, lam);
+    if (tid == 0) out[0] = fmax(rq, lam), out[1] = rq > 0.0 ? rn / rq : 0.0;   // the value and its relative error bound
     if (rn <= 1e-10 * rq || !(rq > 0.0)) break;          // converged (or the zero image)
     __syncthreads();
     }

@@ -9,6 +9,9 @@
 //   3. the tile is flushed with plain, coalesced stores: voxel tiles are owned exclusively; IWE windows (tile + halo,
 //      shifted by the flow) go to a staging area and a gather kernel sums the (<= a few) windows covering each pixel.
 // No global atomics remain on the hot path (only the rare event that lands outside its block's window uses one).
+#include <mutex>
+#include <type_traits>
+
 #include "evk_img.h"
 #include "evk_tiles.h"
 
@@ -25,10 +28,25 @@ namespace evk {
 #endif
 
 // Block b owns the contiguous event range [b*chunk, (b+1)*chunk) (chunk % 4 == 0); table[b][tile] = its count.
-template <typename C>
+// COMPACT records (8 bytes, see below): the bits of a record's second word
+#define EVK_REC_LOCAL_MASK 0x3FFu
+#define EVK_REC_P_MASK 0xFFFFF800u
+// is (x, y, p) representable as a compact record?  Integer pixel coordinates inside the domain, a polarity whose low 11
+// mantissa bits are zero (the rule of k_compact_records)
+__device__ __forceinline__ bool rec_compactable(float x, float y, float p, const TileGrid &g) {
+    const float fx = floorf(x), fy = floorf(y);
+    return fx == x && fy == y && fx >= 0.0f && fy >= 0.0f && fx <= (float)(g.dom_w - 1) && fy <= (float)(g.dom_h - 1) &&
+           !(__float_as_uint(p) & ~EVK_REC_P_MASK);
+}
+
+// STATS (round 6, EVK_STAGE_STATS): the pass also reads the polarity column (12 instead of 8 B/event) and delivers, into
+// the last two words of the bucket index, (0) whether SOME event has no compact 8-byte record (0 = every event has one) and
+// (1) the bit pattern of max |p| -- what the host needed a separate pass over the 16-byte records (evk_compact_records_f32,
+// 352 us at 50 M events whether or not it succeeded) and a reduction over p with a synchronisation of its own for.
+template <typename C, bool STATS>
 __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const C c, int64_t n, int64_t chunk, TileGrid g,
                                                                   int mode, int ntiles, uint32_t *__restrict__ table,
-                                                                  uint32_t *oob) {
+                                                                  uint32_t *oob, uint32_t *__restrict__ stats) {
     extern __shared__ uint32_t hist[];
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) hist[i] = 0;
     __syncthreads();
@@ -36,8 +54,9 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const C c, int
     int64_t hi = lo + chunk;
     if (hi > n) hi = n;
     uint32_t dropped = 0;
+    bool bad = false;
     const int64_t nq = (hi > lo) ? ((hi - lo) >> 2) : 0;
-    auto count4 = [&](const Vec4<float> &xv, const Vec4<float> &yv) {
+    auto count4 = [&](const Vec4<float> &xv, const Vec4<float> &yv, const Vec4<float> &pv) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int key = tile_key(xv.v[k], yv.v[k], g, mode);
@@ -45,28 +64,51 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_hist(const C c, int
                 atomicAdd(&hist[key], 1u);
             else
                 ++dropped;
+            if constexpr (STATS) bad |= !rec_compactable(xv.v[k], yv.v[k], pv.v[k], g);
         }
     };
     int64_t q = threadIdx.x;
-    Vec4<float> xa, ya, xb, yb;
-    for (; q + blockDim.x < nq; q += 2 * blockDim.x) {  // 4 independent 16-byte loads in flight per lane
+    Vec4<float> xa, ya, xb, yb, pa = {}, pb = {};
+    // (STATS: the polarities are read only while this lane's verdict is still open -- a stream of sub-pixel coordinates
+    // fails on its first events and the pass reads 8 B/event like the plain one)
+    for (; q + blockDim.x < nq; q += 2 * blockDim.x) {  // 4 (6) independent 16-byte loads in flight per lane
         c.xy4(lo, q, xa, ya);
         c.xy4(lo, q + blockDim.x, xb, yb);
-        count4(xa, ya);
-        count4(xb, yb);
+        if constexpr (STATS) {
+            if (!bad) c.p4(lo, q, pa), c.p4(lo, q + blockDim.x, pb);
+        }
+        count4(xa, ya, pa);
+        count4(xb, yb, pb);
     }
     for (; q < nq; q += blockDim.x) {
         c.xy4(lo, q, xa, ya);
-        count4(xa, ya);
+        if constexpr (STATS) {
+            if (!bad) c.p4(lo, q, pa);
+        }
+        count4(xa, ya, pa);
     }
     for (int64_t i = lo + (nq << 2) + threadIdx.x; i < hi; i += blockDim.x) {  // ragged tail of the last block
-        const int key = tile_key(c.x1(i), c.y1(i), g, mode);
+        const float xs = c.x1(i), ys = c.y1(i);
+        const int key = tile_key(xs, ys, g, mode);
         if (key >= 0)
             atomicAdd(&hist[key], 1u);
         else
             ++dropped;
+        if constexpr (STATS) bad |= !rec_compactable(xs, ys, c.p1(i), g);
     }
     if (dropped && oob) atomicAdd(oob, dropped);
+    if constexpr (STATS) {
+        // per BLOCK "some event has no compact record" -> stats[block]: no global atomics, nothing to zero (a memset node in
+        // front of the kernel cost ~90 us on this stack); k_tile_scan_totals folds the 256 words into the index and zeroes the
+        // max |p| word, which the scatter (it reads the polarities anyway) fills
+        __shared__ uint32_t sbad;
+        if (threadIdx.x == 0) sbad = 0u;
+        __syncthreads();
+        const bool anybad = __any(bad);
+        if ((threadIdx.x & 63) == 0 && anybad) atomicOr(&sbad, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) stats[blockIdx.x] = sbad;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < ntiles; i += blockDim.x) table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x] = hist[i];
 }
@@ -123,8 +165,16 @@ __global__ void __launch_bounds__(256) k_tile_scan_blocks(uint32_t *__restrict__
 
 __global__ void __launch_bounds__(1024) k_tile_scan_totals(const uint32_t *__restrict__ totals, int ntiles,
                                                            uint32_t cap, uint32_t budget, uint32_t *__restrict__ index,
-                                                           uint32_t *__restrict__ scene) {
+                                                           uint32_t *__restrict__ scene,
+                                                           const uint32_t *__restrict__ block_stats = nullptr) {
     __shared__ uint32_t part[1024];
+    if (block_stats && threadIdx.x < 64) {   // EVK_STAGE_STATS: the histogram blocks' verdicts -> scene[1]; scene[2] = 0 for the scatter
+        uint32_t bad = 0;
+        for (int b = threadIdx.x; b < EVK_BUCKET_BLOCKS; b += 64) bad |= block_stats[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off, 64);
+        if (threadIdx.x == 0) scene[1] = bad, scene[2] = 0u;
+    }
     uint32_t *bucket_start = index, *part_start = index + IDX_PART(ntiles), *counters = index + IDX_COUNTER(ntiles),
              *item_tile = index + IDX_ITEM(ntiles);
     const int per = (ntiles + 1023) / 1024;
@@ -351,6 +401,193 @@ __global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_wc(const C 
     }
 }
 
+// Scatter by LDS sort (round 6; the default where its LDS fits).  The write-combining scatter above is INSTRUCTION-bound:
+// every phase of 4096 events scans all tiles for complete granules and runs three workgroup barriers -- 634 us for the
+// 1.6 GB it moves at 50 M events (2.5 TB/s), with the histogram and the scans 750 us of a cold optimize() (1.1 ms with the
+// separate compaction pass).  Here every workgroup sorts SUB-CHUNKS of 1024 x EPT consecutive events by tile entirely in LDS
+// -- histogram, scan, a returning atomic per event on its tile's cursor: the passes of k_part_sorted (evk_part2.h) -- and writes
+// each sorted sub-chunk out with consecutive lanes on consecutive records: a tile's ~9 records (142 bytes) leave as one
+// contiguous piece to   bucket_start[tile] + (this block's prefix) + (what its earlier sub-chunks put there),   so the
+// records end up exactly where the other scatters put them (tile-contiguous, time order preserved), and the piece that
+// follows it in memory is the same tile's piece of the NEXT sub-chunk of the same workgroup, ~10 us later.
+// FMT 1 (EVK_STAGE_COMPACT, when the histogram pass found every event compactable): the sorted buffer holds, and the
+// kernel writes, the 8-byte COMPACT records directly -- {t, polarity bits [31:11] | pixel in tile [9:0]}, exactly
+// evk_compact_records_f32's -- 16 B/event read + 8 written instead of 16 + 16 and then 16 + 8 again.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define SCATTER_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+template <int EPT, int FMT, typename C>
+__device__ __forceinline__ void scatter_sorted_body(const C &c, int64_t n, int64_t chunk, const TileGrid &g, int mode, int ntiles,
+                                                    const uint32_t *__restrict__ table,
+                                                    const uint32_t *__restrict__ bucket_start, void *__restrict__ rec_,
+                                                    unsigned char *smem, uint32_t *pmax_out) {
+    constexpr int T = EVK_BUCKET_THREADS, S = T * EPT, NQ = EPT / 4, NWV = T / 64;
+    static_assert(EPT % 4 == 0, "whole quads of events per thread");
+    typedef typename std::conditional<FMT == 1, uint2, float4>::type Rec;
+    Rec *sorted = reinterpret_cast<Rec *>(smem);                                         // [S] the sorted sub-chunk
+    unsigned short *tileof = reinterpret_cast<unsigned short *>(smem + (size_t)S * sizeof(Rec));   // [S] its records' tiles
+    const int npad = (ntiles + 3) & ~3;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + (size_t)S * (sizeof(Rec) + 2));  // [ntiles] counts of the pass (zero between passes)
+    uint32_t *cur = cnt + npad;                                                          // [ntiles] cursors: start -> end of the tile's piece in `sorted`
+    uint32_t *gend = cur + npad;                                                         // [ntiles] where the tile's piece ENDS in the record array
+    uint32_t *tmp = gend + npad;                                                         // [NWV + 1] scan scratch
+    Rec *rec = static_cast<Rec *>(rec_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ntiles; i += T) {
+        cnt[i] = 0;
+        gend[i] = bucket_start[i] + table[(int64_t)i * EVK_BUCKET_BLOCKS + blockIdx.x];
+    }
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    int64_t hi = lo + chunk;
+    if (hi > n) hi = n;
+    const int64_t nq = (hi > lo) ? ((hi - lo + 3) >> 2) : 0;   // quads, the last one may be ragged
+    const int64_t npass = (nq + (int64_t)T * NQ - 1) / ((int64_t)T * NQ);
+    Vec4<float> xv[NQ], yv[NQ], tv[NQ], pv[NQ], xn[NQ], yn[NQ], tn[NQ], pn[NQ];
+    auto fetch = [&](int64_t pass, Vec4<float>(&X)[NQ], Vec4<float>(&Y)[NQ], Vec4<float>(&Tt)[NQ], Vec4<float>(&P)[NQ]) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int64_t q = (pass * NQ + k) * T + tid;
+            if (pass < npass && q < nq) {
+                const int64_t base = lo + (q << 2);
+                if (base + 4 <= hi) {
+                    c.xy4(lo, q, X[k], Y[k]);
+                    c.tp4(lo, q, Tt[k], P[k]);
+                } else {   // the stream's ragged last quad
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int64_t i = base + e < hi ? base + e : hi - 1;
+                        X[k].v[e] = c.x1(i), Y[k].v[e] = c.y1(i), Tt[k].v[e] = c.t1(i), P[k].v[e] = c.p1(i);
+                    }
+                }
+            }
+        }
+    };
+    auto valid = [&](int64_t pass, int k) -> int {   // events of quad k of this thread that exist (0 .. 4)
+        const int64_t q = (pass * NQ + k) * T + tid;
+        if (q >= nq) return 0;
+        const int64_t left = hi - (lo + (q << 2));
+        return left >= 4 ? 4 : (int)left;
+    };
+    uint32_t pmax = 0;
+    fetch(0, xv, yv, tv, pv);
+    __syncthreads();
+    for (int64_t pass = 0; pass < npass; ++pass) {
+        // ---- keys, histogram
+        int key[EPT];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int nv = valid(pass, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = e < nv ? tile_key(xv[k].v[e], yv[k].v[e], g, mode) : -1;
+                key[4 * k + e] = kk;
+                if (kk >= 0) __hip_atomic_fetch_add(&cnt[kk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        lds_only_barrier();   // histogram complete (and: every wave has written the previous sub-chunk out)
+        fetch(pass + 1, xn, yn, tn, pn);   // in flight during the scan and the placement
+        // ---- exclusive scan of the counts -> cursors; the global end of every tile's piece
+        uint32_t kept = 0;
+        for (int base = 0; base < ntiles; base += T) {
+            const int i = base + tid;
+            const uint32_t cn = i < ntiles ? cnt[i] : 0u;
+            uint32_t incl = cn;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) tmp[wave] = incl;
+            lds_only_barrier();
+            const uint32_t wt = lane < NWV ? tmp[lane] : 0u;
+            uint32_t wi = wt;
+#pragma unroll
+            for (int off = 1; off < NWV; off <<= 1) {
+                const uint32_t v = __shfl_up(wi, off, 64);
+                if (lane >= off) wi += v;
+            }
+            const uint32_t start = kept + __shfl(wi - wt, wave, 64) + incl - cn;
+            if (i < ntiles) {
+                cur[i] = start;
+                gend[i] += cn;
+                cnt[i] = 0;
+            }
+            kept += __shfl(wi, NWV - 1, 64);
+            if (base + T < ntiles) lds_only_barrier();   // tmp is reused by the next round
+        }
+        lds_only_barrier();   // cursors complete
+        // ---- placement: a returning LDS atomic on the tile's cursor hands every event its slot
+        uint32_t slot[EPT];
+#pragma unroll
+        for (int s2 = 0; s2 < EPT; ++s2) {
+            slot[s2] = 0;
+            if (key[s2] >= 0) {
+                slot[s2] = atomicAdd(&cur[key[s2]], 1u);
+                const uint32_t a = __float_as_uint(pv[s2 / 4].v[s2 % 4]) & 0x7FFFFFFFu;   // max |p| of the bucketed events
+                pmax = a > pmax ? a : pmax;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < EPT; ++s2) {
+            if (key[s2] >= 0) {
+                const float x = xv[s2 / 4].v[s2 % 4], y = yv[s2 / 4].v[s2 % 4], t = tv[s2 / 4].v[s2 % 4], p = pv[s2 / 4].v[s2 % 4];
+                if constexpr (FMT == 1) {
+                    const int xi = (int)x, yi = (int)y;   // (integers inside the domain: the histogram pass's verdict)
+                    const uint32_t local = (uint32_t)(((yi & ((1 << g.th_log2) - 1)) << g.tw_log2) | (xi & ((1 << g.tw_log2) - 1)));
+                    sorted[slot[s2]] = make_uint2(__float_as_uint(t), (__float_as_uint(p) & EVK_REC_P_MASK) | (local & EVK_REC_LOCAL_MASK));
+                } else {
+                    sorted[slot[s2]] = make_float4(x, y, t, p);
+                }
+                tileof[slot[s2]] = (unsigned short)key[s2];
+            }
+        }
+        lds_only_barrier();   // the sorted sub-chunk is complete
+        SCATTER_WAIT_VM0();   // the next pass's columns have landed: the stores below never sit between a load and its use
+        // ---- write-out: record i of the sorted sub-chunk -> gend[tile] - (cur[tile] - i)   (cur is the piece's END now)
+#ifndef SCATTER_ABL_LINEAR
+#define SCATTER_ABL_LINEAR 0   // (timing builds, results wrong) 1: every sub-chunk leaves as ONE contiguous run (what would streaming writes cost?)
+#endif
+        for (uint32_t i = tid; i < kept; i += T) {
+            const uint32_t tl = tileof[i];
+            if (SCATTER_ABL_LINEAR) rec[(lo + pass * S + i) % (uint64_t)(n > 0 ? n : 1)] = sorted[i];
+            else rec[gend[tl] - (cur[tl] - i)] = sorted[i];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) xv[k] = xn[k], yv[k] = yn[k], tv[k] = tn[k], pv[k] = pn[k];
+    }
+    if (pmax_out) {   // ONE global atomic per workgroup (the word was zeroed by k_tile_scan_totals; 4096 same-address atomics --
+                      // one per wave -- cost 30 us at the end of the kernel)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t o = __shfl_xor(pmax, off, 64);
+            pmax = o > pmax ? o : pmax;
+        }
+        lds_only_barrier();              // (tmp is free: every wave is past its last scan)
+        if (tid == 0) tmp[0] = 0u;
+        lds_only_barrier();
+        if (lane == 0 && pmax) atomicMax(&tmp[0], pmax);
+        lds_only_barrier();
+        if (tid == 0 && tmp[0]) atomicMax(pmax_out, tmp[0]);
+    }
+}
+
+template <int EPT, typename C>
+__global__ void __launch_bounds__(EVK_BUCKET_THREADS) k_tile_scatter_sorted(const C c, int64_t n, int64_t chunk, TileGrid g, int mode,
+                                                                            int ntiles, const uint32_t *__restrict__ table,
+                                                                            const uint32_t *__restrict__ bucket_start,
+                                                                            void *__restrict__ rec,
+                                                                            uint32_t *__restrict__ stats, int try_compact) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char scatter_smem[];
+    // (uniform over the launch: the histogram pass and the scans ended before this kernel began)
+    if (try_compact && stats && stats[0] == 0u)
+        scatter_sorted_body<EPT, 1>(c, n, chunk, g, mode, ntiles, table, bucket_start, rec, scatter_smem, stats ? stats + 1 : nullptr);
+    else
+        scatter_sorted_body<EPT, 0>(c, n, chunk, g, mode, ntiles, table, bucket_start, rec, scatter_smem, stats ? stats + 1 : nullptr);
+}
+static size_t scatter_sorted_lds(int ept, int ntiles) {   // (sized for the 16-byte format: one launch serves either)
+    return (size_t)EVK_BUCKET_THREADS * ept * (16 + 2) + 3 * (size_t)((ntiles + 3) & ~3) * 4 + (EVK_BUCKET_THREADS / 64 + 1) * 4;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // voxel grid: one workgroup per tile, LDS accumulators (B x th x tw), exclusive plain-store flush
 // ---------------------------------------------------------------------------------------------------------
@@ -380,8 +617,6 @@ __device__ __forceinline__ void stream_records(const float4 *__restrict__ rec, u
 // COMPACT records (8 bytes, evk_compact_records_f32): {t (float32 bits), polarity bits [31:11] | pixel in tile [9:0]}.
 // Events whose x, y are integers inside the domain (sensor pixels) and whose polarity has its low 11 mantissa bits zero
 // (+-1, 0, small integers, halves ...) lose nothing: x, y come back from the tile origin, which the work item knows.
-#define EVK_REC_LOCAL_MASK 0x3FFu
-#define EVK_REC_P_MASK 0xFFFFF800u
 // Streams compact records [lo, hi): a lane takes PAIRS (one 16-byte load = records 2j, 2j + 1), 4 loads in flight; the
 // pair straddling lo / hi is loaded whole (the buffer is padded to an even count) and the outsiders skipped.
 template <typename F>
@@ -940,14 +1175,14 @@ extern "C" int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_lo
 
 extern "C" int64_t evk_bucket_index_len(int ntiles, int64_t n) {
     if (ntiles <= 0 || n < 0) return 0;
-    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles) + 1;  // + the scene word
+    return (int64_t)IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles) + 3;  // + the scene word and the two stats words
 }
 
 extern "C" int evk_bucket_max_items(int ntiles, int64_t n) { return ntiles > 0 && n >= 0 ? bucket_max_items_balanced(n, ntiles) : 0; }
 
 extern "C" int64_t evk_bucket_scratch_bytes(int ntiles) {
-    if (ntiles <= 0) return 0;
-    return ((int64_t)EVK_BUCKET_BLOCKS * ntiles + ntiles) * (int64_t)sizeof(uint32_t);
+    if (ntiles <= 0) return 0;   // the [tile][block] table, the tile totals, the blocks' stats pairs (EVK_STAGE_STATS)
+    return ((int64_t)EVK_BUCKET_BLOCKS * ntiles + ntiles + EVK_BUCKET_BLOCKS) * (int64_t)sizeof(uint32_t);
 }
 
 template <int RR, typename C>
@@ -964,6 +1199,22 @@ static void launch_scatter_wc(const C &c, int64_t n, int64_t chunk, const TileGr
     }
     k_tile_scatter_wc<RR, C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds_wc, s>>>(c, n, chunk, g, key_mode, ntiles, table,
                                                                                 bucket_start, (float4 *)records);
+}
+
+__global__ void k_set_word(uint32_t *w, uint32_t v) { *w = v; }
+
+template <int EPT, typename C>
+static void launch_scatter_sorted(const C &c, int64_t n, int64_t chunk, const TileGrid &g, int key_mode, int ntiles,
+                                  const uint32_t *table, const uint32_t *bucket_start, float *records, uint32_t *stats,
+                                  int try_compact, hipStream_t s) {
+    static std::once_flag once[64];   // per device and instantiation
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [] {
+        (void)hipFuncSetAttribute((const void *)k_tile_scatter_sorted<EPT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    });
+    k_tile_scatter_sorted<EPT, C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, scatter_sorted_lds(EPT, ntiles), s>>>(
+        c, n, chunk, g, key_mode, ntiles, table, bucket_start, (void *)records, stats, try_compact);
 }
 
 template <typename C>
@@ -984,15 +1235,38 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
     chunk = (chunk + 3) & ~(int64_t)3;
     if (chunk == 0) chunk = 4;
     const size_t lds = (size_t)ntiles * sizeof(uint32_t);
-    if (stages & EVK_STAGE_HIST)
-        k_tile_hist<C><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob);
+    uint32_t *const scene = bucket_start + IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles), *const stats = scene + 1;
+    // compact records need tiles of <= 1024 pixels (10-bit pixel field) and the IWE key (every event inside a tile)
+    const bool compact_ok = (1 << (tw_log2 + th_log2)) <= (int)EVK_REC_LOCAL_MASK + 1 && key_mode == EVK_KEY_FLOOR_CLAMP;
+    if ((stages & EVK_STAGE_COMPACT) && !(stages & EVK_STAGE_STATS)) return EVK_EINVAL;
+    uint32_t *const block_stats = totals + ntiles;   // [EVK_BUCKET_BLOCKS]
+    if (stages & EVK_STAGE_HIST) {
+        if (stages & EVK_STAGE_STATS)
+            k_tile_hist<C, true><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob, block_stats);
+        else
+            k_tile_hist<C, false><<<EVK_BUCKET_BLOCKS, EVK_BUCKET_THREADS, lds, s>>>(c, n, chunk, g, key_mode, ntiles, table, oob, nullptr);
+    }
     if (stages & EVK_STAGE_SCAN) {
         k_tile_scan_blocks<<<(ntiles + 3) / 4, 256, 0, s>>>(table, ntiles, totals);
         k_tile_scan_totals<<<1, 1024, 0, s>>>(totals, ntiles, (uint32_t)bucket_cap(n, ntiles),
-                                              (uint32_t)bucket_item_budget(ntiles), bucket_start,
-                                              bucket_start + IDX_ITEM(ntiles) + bucket_max_items_balanced(n, ntiles));
+                                              (uint32_t)bucket_item_budget(ntiles), bucket_start, scene,
+                                              (stages & EVK_STAGE_STATS) ? block_stats : nullptr);
     }
     if (!(stages & EVK_STAGE_SCATTER)) return launch_status();
+    // the LDS-sorting scatter (round 6) where its buffers fit the budget below: sub-chunks of 8 K events, or of 4 K
+    const size_t lds_cap = (stages & EVK_STAGE_SHARE_CU) ? (size_t)96 * 1024 : (size_t)160 * 1024 - 512;
+    const int try_compact = (stages & EVK_STAGE_COMPACT) && compact_ok ? 1 : 0;
+    if (!(stages & EVK_STAGE_LEGACY_SCATTER)) {
+        for (int ept : {8, 4}) {
+            if (scatter_sorted_lds(ept, ntiles) > lds_cap) continue;
+            uint32_t *const st = (stages & EVK_STAGE_STATS) ? stats : nullptr;
+            if (ept == 8) launch_scatter_sorted<8>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, st, try_compact, s);
+            else launch_scatter_sorted<4>(c, n, chunk, g, key_mode, ntiles, table, bucket_start, records, st, try_compact, s);
+            return launch_status();
+        }
+    }
+    if (try_compact) return EVK_EINVAL;   // (only the sorting scatter writes compact records: the caller asked for what this tiling cannot give)
+    if (stages & EVK_STAGE_STATS) k_set_word<<<1, 1, 0, s>>>(stats + 1, 0xFFFFFFFFu);   // max |p| is NOT delivered by the ring scatter
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
     // all partition blocks co-resident, one per CU.  With EVK_STAGE_SHARE_CU the rings take at most 96 KB so that a
     // workgroup of ANOTHER kernel (an overlapped RCCL collective) still fits on every CU: a scatter workgroup that

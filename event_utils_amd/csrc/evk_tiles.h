@@ -56,6 +56,7 @@ struct ColsF32 {  // four float32 SoA columns, 16 B / event
     __device__ __forceinline__ void tp4n(int64_t lo, int64_t qb, uint32_t ql, int, Vec4<float> &tv, Vec4<float> &pv) const {
         tv = load4(t + lo + 4 * qb, ql), pv = load4(p + lo + 4 * qb, ql);
     }
+    __device__ __forceinline__ void p4(int64_t lo, int64_t q, Vec4<float> &pv) const { pv = load4(p + lo, q); }
     __device__ __forceinline__ float x1(int64_t i) const { return x[i]; }
     __device__ __forceinline__ float y1(int64_t i) const { return y[i]; }
     __device__ __forceinline__ float t1(int64_t i) const { return t[i]; }
@@ -126,6 +127,11 @@ struct ColsNative {
 #pragma unroll
             for (int k = 0; k < 4; ++k) tv.v[k] = (float)((double)f.v[k] - t_offset);
         }
+        const uint32_t w = reinterpret_cast<const uint32_t *>(p + lo)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv.v[k] = pol((w >> (8 * k)) & 0xffu);
+    }
+    __device__ __forceinline__ void p4(int64_t lo, int64_t q, Vec4<float> &pv) const {
         const uint32_t w = reinterpret_cast<const uint32_t *>(p + lo)[q];
 #pragma unroll
         for (int k = 0; k < 4; ++k) pv.v[k] = pol((w >> (8 * k)) & 0xffu);

@@ -305,7 +305,7 @@ class _DeviceImage:
     `.image` hands out a host MIRROR that stays coupled to the device image for as long as the caller holds it: its contents are
     uploaded before every device-side operation of the object (so in-place edits are seen) and refreshed after every one that
     changes the image (so a kept reference shows the new events) -- one small copy each way per call, only once `.image` has
-    been touched; the mirror is held weakly, a dropped one costs nothing."""
+    been touched; a mirror the caller no longer references is dropped at the next call."""
 
     def __init__(self, sensor_size):
         self.sensor_size = sensor_size
@@ -315,13 +315,18 @@ class _DeviceImage:
         self._mirror = None
 
     def _host_mirror(self):
-        return self._mirror() if self._mirror is not None else None
+        return self._mirror
 
     def _sync_in(self):
-        """Before a device-side operation: in-place edits of the handed-out mirror become the device image."""
-        h = self._host_mirror()
+        """Before a device-side operation: in-place edits of the handed-out mirror become the device image.  The mirror is held
+        strongly until here (`obj.image[y, x] = v` edits a temporary that nobody else references); once uploaded it is kept
+        only while the caller still holds a reference of their own."""
+        h = self._mirror
         if h is not None:
+            import sys
             self._img.copy_(torch.from_numpy(np.ascontiguousarray(h, dtype=np.float64)).reshape(self._img.shape))
+            if sys.getrefcount(h) <= 3:          # self._mirror, h, getrefcount's argument: the caller dropped theirs
+                self._mirror = h = None
         return h
 
     def _sync_out(self, h):
@@ -331,12 +336,9 @@ class _DeviceImage:
 
     @property
     def image(self):
-        h = self._host_mirror()
-        if h is None:
-            import weakref
-            h = self._img.cpu().numpy()
-            self._mirror = weakref.ref(h)
-        return h
+        if self._mirror is None:
+            self._mirror = self._img.cpu().numpy()
+        return self._mirror
 
     @image.setter
     def image(self, value):

@@ -26,8 +26,10 @@ def default_impl():
 #   image_fixed  True | False       fixed-point windows of the bilinear image tile kernel for unit weights
 #   live         None | True | False   the voxel tiles accumulated while the partition sorts (EVK_VOXEL2_LIVE; None: only
 #                                   with EVK_VOXEL_LIVE=1 -- measured SLOWER than the two launches)
+#   legacy_scatter  False | True    the write-combining ring scatter of rounds 1-5 (and the separate compaction pass) instead of
+#                                   the LDS-sorting scatter (EVK_STAGE_LEGACY_SCATTER)
 FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu": None, "iwe_records": "auto",
-         "iwe_fixed": True, "image_fixed": True, "live": None, "count2": True}
+         "iwe_fixed": True, "image_fixed": True, "live": None, "count2": True, "legacy_scatter": False}
 
 
 # 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, profiles/r04_small_calls.txt; tools/crossover.py,
@@ -133,37 +135,68 @@ def _rezero_on_failure(index, call):
 
 class Buckets:
     """Events partitioned by tile: `records` (n_kept, 4) float32 (x, y, t, p), `bucket_start` (ntiles+1) offsets.
-    After compact(): `records` is the 8-byte compact record buffer (include/evk.h, EVK_IWE_COMPACT) and `iwe_flag`
-    carries that flag for the IWE entry points."""
+    With compact records -- written by the bucketing itself when every event allows it (EVK_STAGE_COMPACT), or by compact() --
+    `records` is the 8-byte compact record buffer (include/evk.h, EVK_IWE_COMPACT) and `iwe_flag` carries that flag for the IWE
+    entry points.  `stats`: the bucketing also delivered the compact verdict and max |p| (EVK_STAGE_STATS)."""
 
-    def __init__(self, records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n):
+    def __init__(self, records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n, stats=False, compact=False):
         self.records, self.bucket_start, self.n = records, bucket_start, n   # bucket_start = the whole bucket index
         self.key_mode, self.dom_h, self.dom_w = key_mode, dom_h, dom_w
         self.tw_log2, self.th_log2, self.ntiles = tw_log2, th_log2, ntiles
         self.iwe_flag = 0
         self._structured = None
+        self._stats, self._try_compact = stats, compact
+        self._p_absmax = None
+
+    def _tail(self):
+        """The last three words of the index in ONE 12-byte copy: scene | compact verdict | bit pattern of max |p|."""
+        import numpy as np
+        w = self.bucket_start[-3:].cpu().numpy().view(np.uint32)
+        self._structured = bool(w[0])
+        if self._stats:
+            # (0xFFFFFFFF: the scatter that ran does not deliver it -- the caller reduces the column itself)
+            self._p_absmax = float(w[2:3].view(np.float32)[0]) if w[2] != 0xFFFFFFFF else None
+            self._stats_pmax_known = w[2] != 0xFFFFFFFF
+            if self._try_compact and w[1] == 0 and self.n:
+                # the scatter wrote 8-byte compact records into the first half of the buffer
+                self.records = self.records.view(-1).view(__import__("torch").int64)[: self.n + (self.n & 1)]
+                self.iwe_flag = _lib.EVK_IWE_COMPACT
+            self._try_compact = False
 
     @property
     def structured(self):
-        """The bucketing's verdict on the scene (last word of the index): True when the fullest tile holds more than 1.25 x
-        the mean tile population.  Read once (one 4-byte copy) and kept."""
+        """The bucketing's verdict on the scene: True when the fullest tile holds more than 1.25 x the mean tile population.
+        Read once (with the other tail words, one 12-byte copy) and kept."""
         if self._structured is None:
-            self._structured = bool(int(self.bucket_start[-1].item()))
+            self._tail()
         return self._structured
 
+    @property
+    def p_absmax(self):
+        """max |p| of the bucketed events when the bucketing computed it (EVK_STAGE_STATS), else None."""
+        if self._stats and self._p_absmax is None and getattr(self, "_stats_pmax_known", True):
+            self._tail()
+        return self._p_absmax
+
+    def settle(self):
+        """Read what the bucketing decided on the device (record format, scene, max |p|): one small copy, one synchronisation."""
+        if self._structured is None:
+            self._tail()
+        return self
+
     def compact(self):
-        """Rewrite the records as 8-byte compact records when that is exact (integer pixel coordinates inside the
+        """Rewrite 16-byte records as 8-byte compact records when that is exact (integer pixel coordinates inside the
         domain, polarities without low mantissa bits: sensor events) and drop the 16-byte ones: every later evaluation
-        streams half the bytes.  One extra pass over the records and ONE host synchronisation (the verdict), paid once
-        per bucketing, i.e. once per optimisation.  FORCE["iwe_records"]: "auto" (default) compacts when the 16-byte records
-        do not fit the 256 MB Infinity Cache (> 16 M events) -- measured on MI355X (tools/iwe_kernel_time.py): 50 M
-        events / 720p, function evaluation kernel 0.225 -> 0.211 ms; 10 M events / VGA (cache-resident, bound by
-        arithmetic and LDS atomics, where the decode costs instructions) 0.039 -> 0.041 ms; "compact" always tries,
-        "full" never does."""
+        streams half the bytes.  Since round 6 the bucketing does this itself (bucket_events(..., compact=True): the histogram
+        pass delivers the verdict, the scatter writes compact records directly); this separate pass over the records remains for
+        buckets built without it.  FORCE["iwe_records"]: "auto" (default) compacts when the 16-byte records do not fit the
+        256 MB Infinity Cache (> 16 M events) -- measured on MI355X (tools/iwe_kernel_time.py): 50 M events / 720p, function
+        evaluation kernel 0.225 -> 0.211 ms; 10 M events / VGA (cache-resident, bound by arithmetic and LDS atomics, where the
+        decode costs instructions) 0.039 -> 0.041 ms; "compact" always tries, "full" never does."""
         import torch
-        mode = FORCE["iwe_records"]
-        if self.iwe_flag or self.key_mode != 1 or self.n == 0 or (1 << (self.tw_log2 + self.th_log2)) > 1024 \
-                or mode == "full" or (mode != "compact" and self.n * 16 <= (256 << 20)):
+        if self._stats:
+            return self.settle()
+        if self.iwe_flag or not want_compact(self.key_mode, self.n, self.tw_log2, self.th_log2):
             return self
         dev = self.records.device
         out = torch.empty(int(_lib.lib().evk_compact_records_bytes(self.n)) // 8, dtype=torch.int64, device=dev)
@@ -173,6 +206,14 @@ class Buckets:
         if int(verdict.item()) == 0:
             self.records, self.iwe_flag = out, _lib.EVK_IWE_COMPACT
         return self
+
+
+def want_compact(key_mode, n, tw_log2, th_log2):
+    """Whether a bucketing of n events should try compact records (the FORCE["iwe_records"] policy, see Buckets.compact)."""
+    mode = FORCE["iwe_records"]
+    if key_mode != 1 or n == 0 or (1 << (tw_log2 + th_log2)) > 1024 or mode == "full":
+        return False
+    return mode == "compact" or n * 16 > (256 << 20)
 
 
 def can_tile(cols, impl, min_events=None):
@@ -196,10 +237,13 @@ def share_cu():
     return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
-def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None, native=None):
+def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=None, stages=7, into=None, native=None,
+                  stats=False, compact=False):
     """evk_bucket_events_f32: counting sort of the SoA columns by output tile (one histogram + one scatter pass).
     native = events.NativeColumns: the same sort reading the on-disk dtypes (evk_bucket_events_native_f32; the four
-    column arguments are then ignored)."""
+    column arguments are then ignored).  stats: the histogram pass also delivers the compact verdict and max |p|
+    (EVK_STAGE_STATS); compact (implies stats): the scatter writes 8-byte compact records when every event allows it
+    (EVK_STAGE_COMPACT) -- Buckets.settle() / .structured / .p_absmax read the outcome."""
     import torch
     L = _lib.lib()
     ntiles = L.evk_bucket_num_tiles(dom_h, dom_w, tw_log2, th_log2)
@@ -214,13 +258,18 @@ def bucket_events(xd, yd, td, pd, key_mode, dom_h, dom_w, tw_log2, th_log2, oob=
         bucket_start = torch.empty(int(L.evk_bucket_index_len(ntiles, n)), dtype=torch.int32, device=dev)
     nbytes = int(L.evk_bucket_scratch_bytes(ntiles))
     scratch = _buf("bucket", nbytes, dev)
+    stats = bool(stats or compact)
+    if FORCE.get("legacy_scatter"):
+        stages |= _lib.EVK_STAGE_LEGACY_SCATTER
+        compact = False
+    stages |= (_lib.EVK_STAGE_STATS if stats else 0) | (_lib.EVK_STAGE_COMPACT if compact else 0)
     tail = (key_mode, dom_h, dom_w, tw_log2, th_log2, D.ptr(records), D.ptr(bucket_start), D.ptr(scratch), nbytes,
             oob.ptr if oob is not None else None, stages | (8 if share_cu() else 0), D.stream())
     if native is None:
         _lib.call("evk_bucket_events_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, *tail)
     else:
         _lib.call("evk_bucket_events_native_f32", *native.head(), *tail)
-    return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n)
+    return Buckets(records, bucket_start, key_mode, dom_h, dom_w, tw_log2, th_log2, ntiles, n, stats=stats, compact=compact)
 
 
 def voxel_deterministic():
@@ -558,11 +607,17 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     key = (1, dom_h, dom_w, tw, th, FORCE["iwe_records"])
     bk = ev._buckets.get(key)
     if bk is None:
+        # (round 6) ONE bucketing call also decides the record format and delivers max |p|: the histogram pass reads the
+        # polarities too, the scatter writes compact records directly when every event allows it
+        legacy = bool(FORCE.get("legacy_scatter"))      # (A/B: rounds 1-5's three kernels + the separate compaction pass)
+        wc = want_compact(1, len(ev), tw, th) and not legacy
         if native is not None:
-            bk = bucket_events(None, None, None, None, 1, dom_h, dom_w, tw, th, native=native)
+            bk = bucket_events(None, None, None, None, 1, dom_h, dom_w, tw, th, native=native, stats=not legacy, compact=wc)
         else:
-            bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th)
+            bk = bucket_events(ev.x, ev.y, ev.t, ev.p, 1, dom_h, dom_w, tw, th, stats=not legacy, compact=wc)
         ev._buckets[key] = bk.compact()
+        if ev._p_absmax is None and bk.p_absmax is not None:
+            ev._p_absmax = bk.p_absmax
     skey = (bk.ntiles, bk.n, S, planes, win_w, win_h)
     nbytes = _staging_bytes.get(skey)
     if nbytes is None:

@@ -244,7 +244,8 @@ int64_t evk_reduce_scratch_bytes(void);
 int evk_bucket_num_tiles(int dom_h, int dom_w, int tw_log2, int th_log2);
 int64_t evk_bucket_scratch_bytes(int ntiles);
 /* length (uint32 entries) of the bucket index for n events: tile offsets (ntiles+1), work-item offsets (ntiles+1),
- * per-tile arrival counters (ntiles), the item -> tile map (evk_bucket_max_items entries) and, LAST, the `scene` word.
+ * per-tile arrival counters (ntiles), the item -> tile map (evk_bucket_max_items entries), the `scene` word and, LAST, the
+ * two words of EVK_STAGE_STATS (below); scene = index[len - 3].
  * A tile holding more than max(32768, 4n/ntiles) events is split into several work items, so clustered event data cannot
  * serialise on one CU.  When the fullest tile holds more than 1.25 x the mean tile population the scene word is 1 (a
  * structured scene; 0 otherwise) and the plan is BALANCED: the split threshold is lowered, not below
@@ -259,6 +260,18 @@ int evk_bucket_max_items(int ntiles, int64_t n);
 #define EVK_STAGE_ALL 7
 #define EVK_STAGE_SHARE_CU 8 /* modifier of the scatter stage: keep its LDS rings <= 96 KB so that workgroups of another,
                                 concurrently running kernel (an overlapped RCCL collective) still fit on every CU    */
+/* Round 6.  EVK_STAGE_STATS: the histogram pass also reads the polarity column and leaves, in the LAST TWO words of the
+ * bucket index, [len - 2] = 0 when every event has a compact 8-byte record (integer pixel coordinates inside the domain, a
+ * polarity without low mantissa bits), else 1, and -- filled by the scatter stage (the LDS-sorting one) -- [len - 1] = the
+ * float32 bit pattern of max |p| over the bucketed events (0xFFFFFFFF when the ring scatter ran instead): what callers needed a pass over the records
+ * (evk_compact_records_f32) and a reduction over p for.  EVK_STAGE_COMPACT (with STATS, IWE key,
+ * tiles of <= 1024 pixels): when that verdict is 0 the scatter writes the COMPACT records (see evk_compact_records_f32:
+ * same records, same order) into the first 8 n bytes of `records` instead of the 16-byte ones -- the caller learns which
+ * from index[len - 2].  EVK_STAGE_LEGACY_SCATTER: the write-combining ring scatter of rounds 1-5 instead of the LDS-sorting
+ * one (A/B, tests; both produce identical records). */
+#define EVK_STAGE_STATS 16
+#define EVK_STAGE_COMPACT 32
+#define EVK_STAGE_LEGACY_SCATTER 64
 
 /* Counting sort of the SoA columns by tile: records = n x (x, y, t, p) float4 (16 B, contiguous per tile, time order
  * preserved across the 256 partition blocks), bucket_index = evk_bucket_index_len(ntiles, n) uint32 (see above).
@@ -518,7 +531,11 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
 
 /* Largest singular value SQUARED of a float32 (h, w) image, float64 -> out[0]: what the "rms" objective needs
  * (objectives.py:282: np.linalg.norm(iwe, 2) of a 2-D array is the spectral norm).  Lanczos on the Gram operator with full
- * re-orthogonalisation in one workgroup, then a bisection; h, w <= 4096.  scratch: evk_spectral_scratch_bytes(h, w). */
+ * re-orthogonalisation in one workgroup, then a bisection; h, w <= 4096.  scratch: evk_spectral_scratch_bytes(h, w).
+ * Round 6: `out` holds TWO doubles.  The Ritz pair's true residual is measured after every sweep of <= 96 steps and the
+ * iteration restarts from the Ritz vector until it is below 1e-10 of the value (at most 8 sweeps); out[1] = the final relative
+ * residual, a bound on the relative distance of out[0] (a lower bound of sigma_max^2) from an eigenvalue -- a caller that needs
+ * more than that checks it. */
 int64_t evk_spectral_scratch_bytes(int h, int w);
 int evk_spectral_norm_sq_f32(const float *img, int h, int w, double *out, void *scratch, int64_t scratch_bytes, void *stream);
 

@@ -1,0 +1,292 @@
+"""GPU (-m gpu): round-6 hardening -- release_scratch(), the one-pass index re-zeroed after a failed call, the element-wise
+helper kernels that replaced the last torch arithmetic on the product path (evk_elem.hip), host_report without a counter,
+the coupled `.image` mirror and NaN propagation of the stateful image classes."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+from event_utils_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _events(seed, n, H, W):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    return x, y, t, p
+
+
+def _close(a, ref, tol=1e-5):
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape and np.max(np.abs(a - ref)) <= tol * max(np.max(np.abs(ref)), 1e-30)
+
+
+def test_release_scratch_frees_the_persistent_buffers_and_calls_go_on():
+    """event_utils_amd.release_scratch(): the grow-only record / staging buffers, zeroed indices, spill pairs and reduction
+    slots of the current stream are dropped (tens of MB after one 1 M-event call) and the next calls rebuild what they need:
+    same grid, same image, same objective value."""
+    import event_utils_amd as E
+    from event_utils_amd import tiled
+    n, H, W, B = 1_000_000, 480, 640, 5
+    x, y, t, p = _events(11, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    xr = torch.from_numpy(np.random.default_rng(3).uniform(1, W - 1, n).astype(np.float32)).cuda()
+    yr = torch.from_numpy(np.random.default_rng(4).uniform(1, H - 1, n).astype(np.float32)).cuda()
+
+    def work():
+        vox = E.events_to_voxel_torch(*cols, B, sensor_size=(H, W)).cpu().numpy()
+        img = E.events_to_image_torch(cols[0], cols[1], cols[3], sensor_size=(H, W), interpolation='bilinear', padding=False).cpu().numpy()
+        ev = E.DeviceEvents(xr, yr, cols[2], cols[3])
+        obj = E.variance_objective(); obj.sensor_size = (H, W)
+        f = float(obj.evaluate_function(np.array([30., -20.]), ev, None, None, None, E.linvel_warp(), (H, W), 1.0))
+        return vox, img, f
+    a = work()
+    held = sum(b.numel() * b.element_size() for b in list(tiled._persist.values()) + list(tiled._zpersist.values()))
+    assert held > 8 * n                                   # at least the 8-byte records of the voxel call
+    freed = E.release_scratch()
+    assert freed >= held and not tiled._persist and not tiled._zpersist and not tiled._spill
+    b = work()
+    assert np.array_equal(a[0], b[0]) and abs(a[2] - b[2]) <= 1e-6 * abs(a[2])
+    _close(b[1], a[1], 1e-6)
+    # per device / per stream selection: another stream's buffers are left alone
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        E.events_to_voxel_torch(*cols, B, sensor_size=(H, W))
+    side.synchronize()
+    keys = set(tiled._persist)
+    assert E.release_scratch(stream=side) > 0
+    assert set(tiled._persist) < keys and any(k[2] != side.cuda_stream for k in tiled._persist)
+
+
+def test_one_pass_index_is_zeroed_again_after_a_failed_call():
+    """The one-pass paths keep self-resetting counters in a persistent index that is zeroed ONCE.  A call that fails (here: an
+    argument the library refuses -- after the index has been dirtied by hand, as a launch failing between the two kernels
+    would leave it) zeroes the index before the error propagates, and the next call is correct."""
+    import event_utils_amd as E
+    from event_utils_amd import tiled
+    n, H, W, B = 600_000, 480, 640, 5
+    x, y, t, p = _events(12, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    ref = R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64")
+    out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    shape = tiled.voxel2_shape(H, W, B)
+    tiled.voxel2(cols, None, n, float(t[0]), float(t[-1]), B, H, W, *shape, out, None, True)
+    index = tiled._zbuf("voxel2_index", 1, out.device)
+    index[2] = 7; index[16:40] = 12345; index[8] = 3            # ticket, per-tile totals, early-report ticket mid-count
+    with pytest.raises(_lib.EvkError):
+        tiled.voxel2(cols, None, n, float(t[0]), float(t[-1]), B, H, W, *shape, out, None, True, stage=1 << 30)   # unknown flag
+    assert int(index.abs().sum().item()) == 0
+    tiled.voxel2(cols, None, n, float(t[0]), float(t[-1]), B, H, W, *shape, out, None, True)
+    _close(out.cpu().numpy(), ref)
+    # the event images share the rule
+    img = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    iidx = None
+    assert tiled.image2("f32", cols[0], cols[1], cols[3], n, H, W, float("inf"), float("inf"), img, None, fresh=True)
+    iidx = tiled._zbuf("image2_index", 1, img.device)
+    iidx[2] = 5
+    with pytest.raises(_lib.EvkError):
+        tiled.image2("f32", cols[0], cols[1], cols[3], n, H, W, float("inf"), float("inf"), img, None, fresh=True, stage=1 << 30)
+    assert int(iidx.abs().sum().item()) == 0
+    assert tiled.image2("f32", cols[0], cols[1], cols[3], n, H, W, float("inf"), float("inf"), img, None, fresh=True)
+    want = np.zeros((H, W)); np.add.at(want, (y.astype(int), x.astype(int)), p.astype(np.float64))
+    _close(img.cpu().numpy(), want)
+
+
+def test_elementwise_helpers_match_torch_and_numpy(monkeypatch):
+    """evk_polarity_weights_f32 / evk_abs_max / evk_abs against the torch / numpy expressions they replace, NaN and signed zeros
+    included; and the paths that use them: the two-voxelisation route of events_to_neg_pos_voxel_torch (forced with
+    EVK_IMPL=direct) against the oracle, DeviceEvents.p_absmax()."""
+    import event_utils_amd as E
+    from event_utils_amd import _device as D
+    from event_utils_amd.events import _abs_max
+    from event_utils_amd.contrast_max.objectives import _abs_device
+    from event_utils_amd.representations.voxel_grid import _polarity_weights
+    rng = np.random.default_rng(5)
+    p = rng.normal(size=100_003).astype(np.float32)
+    p[:6] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-45]
+    pt = torch.from_numpy(p)
+    pos, neg = _polarity_weights(pt.cuda())
+    assert torch.equal(pos.cpu(), torch.where(pt > 0, 1.0, 0.0).to(torch.float32))
+    assert torch.equal(neg.cpu(), torch.where(pt <= 0, 1.0, 0.0).to(torch.float32))
+    hp, hn = _polarity_weights(pt)                                  # host tensor in -> host tensors out
+    assert not hp.is_cuda and torch.equal(hp, pos.cpu()) and torch.equal(hn, neg.cpu())
+    for arr in (p[6:], p[6:].astype(np.float64), np.zeros(5, np.float32), np.array([-3.5, 2.0], np.float64)):
+        assert _abs_max(torch.from_numpy(arr).cuda()) == float(np.abs(arr).max())
+    assert np.isnan(_abs_max(pt.cuda()))                            # a NaN propagates, as torch's max()
+    for dt in (np.float32, np.float64):
+        a = torch.from_numpy(p.astype(dt))
+        got = _abs_device(a.cuda()).cpu()
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(a.abs(), nan=-1.0))
+        assert not torch.signbit(got[:2]).any()                     # |-0.0| = +0.0
+    # the fallback route of events_to_neg_pos_voxel_torch
+    n, H, W, B = 80_000, 60, 80, 3
+    x, y, t, _ = _events(21, n, H, W)
+    ps = rng.integers(-1, 2, n).astype(np.float32)                  # -1, 0, +1
+    monkeypatch.setenv("EVK_IMPL", "direct")
+    vp, vn = E.events_to_neg_pos_voxel_torch(*(torch.from_numpy(a).cuda() for a in (x, y, t, ps)), B, sensor_size=(H, W))
+    rp = R.events_to_voxel_torch(x, y, t, (ps > 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
+    rn = R.events_to_voxel_torch(x, y, t, (ps <= 0).astype(np.float32), B, sensor_size=(H, W), accum="f64")
+    _close(vp.cpu().numpy(), rp); _close(vn.cpu().numpy(), rn)
+    ev = E.DeviceEvents.from_arrays(x, y, t, ps * 2.5, precision="f32")
+    assert ev.p_absmax() == 2.5
+
+
+def test_host_report_is_written_without_a_counter():
+    """include/evk.h: host_report is an optional argument of its own -- a C caller that passes it WITHOUT a dropped-event counter
+    gets {seq, 0} (round 5 wrote the report only when oob was given too, and such a caller waited for ever)."""
+    from event_utils_amd import tiled, _device as D
+    n, H, W, B = 400_000, 480, 640, 5
+    x, y, t, p = _events(13, n, H, W)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    out = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    tw, th = tiled.voxel2_shape(H, W, B)
+    index, scratch, nbytes, flags = tiled._voxel2_env(out.device, n, B, H, W, tw, th)
+    report = torch.zeros(2, dtype=torch.int32).pin_memory()
+    seq = 0x1234
+    _lib.call("evk_voxel2_f32", *(D.ptr(c) for c in cols), n, H, W, tw, th, float(t[0]), float(t[-1]), B,
+              flags | _lib.EVK_VOXEL_OVERWRITE, D.ptr(out), D.ptr(index), D.ptr(scratch), nbytes, None,
+              ctypes.c_void_p(report.data_ptr()), seq, D.stream())
+    torch.cuda.synchronize()
+    assert int(report[0]) == seq and int(report[1]) == 0
+    _close(out.cpu().numpy(), R.events_to_voxel_torch(x, y, t, p, B, sensor_size=(H, W), accum="f64"))
+
+
+def test_image_classes_mirror_and_nan_rank():
+    """Upstream's TimestampImage / EventImage expose `.image` as THE ndarray (image.py:358,380): in-place edits are seen by the
+    next call and a kept reference follows add_events.  Here `.image` is a host mirror coupled to the device image.  And a NaN
+    pixel makes every rank NaN, as scipy.stats.rankdata does (image.py:371; checked against the real reference in round 6)."""
+    import event_utils_amd as E
+    for cls, rcls in ((E.EventImage, R.EventImage), (E.TimestampImage, R.TimestampImage)):
+        a, b = cls((6, 7)), rcls((6, 7))
+        views = []
+        for o in (a, b):
+            img = o.image
+            img[1, 2] = 7.0
+            img *= 2.0
+            views.append(img)
+            if cls is E.EventImage:
+                o.add_event(2.2, 1.9, 0.0, 3.0)
+            else:
+                o.add_events(np.array([3.0, 2.0]), np.array([4.0, 1.0]), np.array([0.25, 0.5]), None)
+        assert np.array_equal(a.image, b.image)
+        assert np.array_equal(views[0], views[1])          # the reference handed out BEFORE the events shows them
+        assert np.array_equal(a.get_image(), b.get_image(), equal_nan=True)
+        a.image = np.arange(42.0).reshape(6, 7)            # assignment replaces the image (and drops the old mirror)
+        assert a.image[5, 6] == 41.0 and views[0][5, 6] != 41.0
+    t1, t2 = E.TimestampImage((5, 4)), R.TimestampImage((5, 4))
+    for o in (t1, t2):
+        o.add_events(np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2, 0.3]), None)
+        o.image[4, 0] = np.nan
+    g1, g2 = t1.get_image(), t2.get_image()
+    assert np.all(np.isnan(g1)) and np.array_equal(g1, g2, equal_nan=True)
+    t1.image[4, 0] = -np.nan                              # (sign bit set: sorts to the front of the radix sort)
+    assert np.all(np.isnan(t1.get_image()))
+
+
+def _per_tile_sets(bk):
+    """Records of a Buckets object sorted within every tile (the order inside one block's share of a tile is the order of
+    LDS atomics in either scatter; the SET per tile is what the tile kernels sum)."""
+    T = bk.ntiles
+    starts = bk.bucket_start[: T + 1].cpu().numpy().astype(np.int64)
+    tile_of = np.repeat(np.arange(T), np.diff(starts))
+    kept = int(starts[-1])
+    if bk.iwe_flag:
+        r = bk.records[:kept].cpu().numpy().view(np.uint32).reshape(-1, 2)
+        return r[np.lexsort((r[:, 1], r[:, 0], tile_of))], starts
+    r = bk.records.cpu().numpy().reshape(-1, 4).view(np.uint32)[:kept]
+    return r[np.lexsort((r[:, 3], r[:, 1], r[:, 0], r[:, 2], tile_of))], starts
+
+
+@pytest.mark.parametrize("case", ["iwe 32x32", "iwe 16x16 (4 K-event sub-chunks)", "voxel key, dropped events", "ring fallback"])
+def test_lds_sorting_scatter_equals_the_ring_scatter(case, monkeypatch):
+    """Round 6: evk_bucket_events_f32 scatters by LDS sort (k_tile_scatter_sorted: sub-chunks of 8 K / 4 K events sorted by tile
+    in LDS, every tile's piece written to its final place).  Same bucket index bit for bit and the same records per tile as the
+    write-combining ring scatter of rounds 1-5 (EVK_STAGE_LEGACY_SCATTER) -- on a structured scene with a ragged event count, on
+    a tiling that needs the smaller sub-chunks, with the nearest-pixel key and out-of-domain events (dropped, counted), and on
+    a tiling whose counters no longer fit beside the sort buffer (the library then takes the old scatter by itself)."""
+    import bench
+    from event_utils_amd import tiled, _device as D
+    n, H, W = 1_300_003, 720, 1280
+    x, y, t, p = bench.structured_scene(9, n, H, W)
+    key_mode, dom_h, dom_w, tw, th = 1, H + 1, W + 1, 5, 5
+    if case.startswith("iwe 16x16"):
+        tw, th = 4, 4                                   # 81 x 46 = 3726 tiles
+    elif case.startswith("voxel"):
+        key_mode, dom_h, dom_w, tw, th = 0, H, W, 5, 4
+        x, y = np.floor(x), np.floor(y)
+        x[::1000] = W + 3.0                             # out of the domain: dropped and counted
+    elif case.startswith("ring"):
+        dom_h, dom_w, tw, th = 704, 720, 3, 3           # 90 x 88 = 7920 tiles of 8 x 8
+        x, y = x % 719.0, y % 703.0
+    cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (x, y, t, p)]
+    got = {}
+    for legacy in (True, False):
+        monkeypatch.setitem(tiled.FORCE, "legacy_scatter", legacy)
+        oob = D.OobCounter(cols[0].device)
+        bk = tiled.bucket_events(*cols, key_mode, dom_h, dom_w, tw, th, oob=oob, stats=not legacy)
+        torch.cuda.synchronize()
+        if case.startswith("voxel"):                    # the dropped events were counted: exactly the ones put out of the domain
+            with pytest.raises(IndexError, match="%d offending" % len(x[::1000])):
+                oob.raise_if_set(IndexError, "out of range")
+        else:
+            oob.raise_if_set(IndexError, "out of range")
+        got[legacy] = (bk, _per_tile_sets(bk))
+    (a, (ra, sa)), (b, (rb, sb)) = got[True], got[False]
+    T = a.ntiles                                        # (offsets, work-item offsets, counters, then the USED item -> tile entries)
+    ia, ib = a.bucket_start.cpu().numpy(), b.bucket_start.cpu().numpy()
+    nitems = int(ia[2 * T + 1])
+    assert np.array_equal(ia[: 3 * T + 2 + nitems], ib[: 3 * T + 2 + nitems]) and np.array_equal(sa, sb)
+    assert np.array_equal(ra, rb) and len(ra) == int(sa[-1])
+    if case.startswith("voxel"):
+        assert int(sa[-1]) == n - len(x[::1000])
+    if case.startswith("ring"):
+        assert b.p_absmax is None                      # the ring scatter does not deliver max |p|: the caller reduces the column
+    else:
+        assert b.p_absmax == 1.0 and b.structured == a.structured
+
+
+def test_bucketing_delivers_compact_records_and_stats_in_one_call(monkeypatch):
+    """EVK_STAGE_STATS | EVK_STAGE_COMPACT: the histogram pass delivers the verdict (every event has an 8-byte compact record),
+    the scatter then writes compact records DIRECTLY -- the very records evk_compact_records_f32 makes from the 16-byte ones --
+    and max |p| arrives with the scene word in one 12-byte copy.  Sub-pixel coordinates or a polarity with low mantissa bits
+    keep the 16-byte records.  Objective and gradient on either kind of bucket agree bit for bit (integer LDS accumulation)."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd import tiled
+    n, H, W = 900_001, 480, 640
+    x, y, t, p = bench.structured_scene(4, n, H, W)
+    xi, yi = np.floor(x), np.floor(y)
+    p3 = (p * 3.0).astype(np.float32)
+    dom_h, dom_w = H + 1, W + 1
+    tw, th = tiled.iwe_tile_shape(dom_h, dom_w)
+    monkeypatch.setitem(tiled.FORCE, "iwe_records", "compact")
+
+    def bucket(xs, ys, ps, legacy):
+        monkeypatch.setitem(tiled.FORCE, "legacy_scatter", legacy)
+        cols = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (xs, ys, t, ps)]
+        bk = tiled.bucket_events(*cols, 1, dom_h, dom_w, tw, th, stats=not legacy, compact=not legacy)
+        return bk.compact()
+    new, old = bucket(xi, yi, p3, False), bucket(xi, yi, p3, True)
+    assert new.iwe_flag == old.iwe_flag == _lib.EVK_IWE_COMPACT and new.p_absmax == 3.0
+    (rn, sn), (ro, so) = _per_tile_sets(new), _per_tile_sets(old)
+    assert np.array_equal(sn, so) and np.array_equal(rn, ro)
+    assert bucket(x, yi, p3, False).iwe_flag == 0                                   # a sub-pixel coordinate
+    assert bucket(xi, yi, (p * 1.0001).astype(np.float32), False).iwe_flag == 0     # a polarity with low mantissa bits
+    far = xi.copy(); far[5] = dom_w + 10.0
+    assert bucket(far, yi, p3, False).iwe_flag == 0                                 # a coordinate outside the domain
+    # the objective through both routes
+    vals = {}
+    for legacy in (False, True):
+        monkeypatch.setitem(tiled.FORCE, "legacy_scatter", legacy)
+        ev = E.DeviceEvents.from_arrays(xi, yi, t, p3, precision="f32")
+        obj = E.variance_objective(); obj.sensor_size, obj.impl = (H, W), "tiled"
+        prm = np.array([35.0, -22.0])
+        vals[legacy] = (float(obj.evaluate_function(prm, ev, None, None, None, E.linvel_warp(), (H, W), 1.0)),
+                        obj.evaluate_gradient(prm, ev, None, None, None, E.linvel_warp(), (H, W), 1.0).copy())
+        assert list(ev._buckets.values())[0].iwe_flag == _lib.EVK_IWE_COMPACT and ev.p_absmax() == 3.0
+    assert vals[False][0] == vals[True][0] and np.array_equal(vals[False][1], vals[True][1])

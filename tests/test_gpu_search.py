@@ -226,6 +226,14 @@ def test_spectral_norm_kernel_against_numpy(E, shape):
         "one pixel": np.where((yy == h // 2) & (xx == w // 3), 5.0, 0.0),
         "zero": np.zeros(shape),
     }
+    if min(shape) >= 181:
+        # a SLOWLY converging spectrum (round 6): 150 singular values within 3e-3 of the largest -- one sweep of 96 Lanczos steps
+        # stops short of 1e-9 here; the kernel measures the Ritz pair's true residual and restarts from the Ritz vector
+        k = min(shape)
+        sv = np.concatenate([1.0 - 2e-5 * np.arange(150), rng.uniform(0.0, 0.5, k - 150)])
+        qa, _ = np.linalg.qr(rng.normal(size=(h, k)))
+        qb, _ = np.linalg.qr(rng.normal(size=(w, k)))
+        cases["clustered top"] = (qa * sv) @ qb.T
     dev = torch.device("cuda", 0)
     nbytes = int(_lib.lib().evk_spectral_scratch_bytes(h, w))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -234,6 +242,11 @@ def test_spectral_norm_kernel_against_numpy(E, shape):
         a32 = np.ascontiguousarray(a, dtype=np.float32)
         img = torch.from_numpy(a32).cuda()
         _lib.call("evk_spectral_norm_sq_f32", D.ptr(img), h, w, D.ptr(out), D.ptr(scratch), nbytes, D.stream())
-        got = float(out[0].item())
+        got, resid = (float(v) for v in out[:2].cpu().numpy())
         want = float(np.linalg.norm(a32.astype(np.float64), 2)) ** 2
-        assert abs(got - want) <= 1e-9 * max(want, 1e-300), (name, shape, got, want)
+        assert got <= want * (1.0 + 1e-12), (name, shape, got, want)                # a Ritz value never exceeds the truth
+        assert abs(got - want) <= max(1e-9, 1.01 * resid) * max(want, 1e-300), (name, shape, got, want, resid)
+        if name != "clustered top":
+            assert resid <= 1e-9 and abs(got - want) <= 1e-9 * max(want, 1e-300), (name, shape, got, want, resid)
+        else:
+            assert abs(got - want) <= 2e-6 * want, (name, shape, got, want, resid)  # (the reported bound is what a caller checks)

@@ -62,3 +62,19 @@ def test_fixtures_reproduce_bit_for_bit_from_the_reference(regenerated):
             assert same, (name, k)
             checked += 1
     assert checked > 250
+
+
+def test_timestamp_image_with_a_nan_pixel_matches_the_reference():
+    """Round 6: scipy.stats.rankdata (image.py:371) propagates a NaN pixel to every rank; the oracle's dense rank (np.unique)
+    is pinned to that behaviour directly against the real class (no fixture: two 12-pixel images)."""
+    from oracle import ref_loader, reference_np as R
+    ref = ref_loader.load()
+    for nanpix in (True, False):
+        a, b = ref.image.TimestampImage((3, 4)), R.TimestampImage((3, 4))
+        for o in (a, b):
+            o.image[0, 0] = 5.0
+            o.image[2, 1] = -1.0
+            if nanpix:
+                o.image[1, 2] = np.nan
+        ga, gb = a.get_image(), b.get_image()
+        assert np.array_equal(ga, gb, equal_nan=True) and bool(np.isnan(ga).all()) == nanpix
