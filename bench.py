@@ -267,6 +267,7 @@ def main():
         result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], sets[(args.steps - 1) % COLUMN_SETS][3], n, world))
         if exchange_choice:
             result["exchange"] = exchange_choice
+        result["oracle_self_check"] = oracle_self_check(dist, dev, _voxel_f32_device, sets[0], t_first, t_last, impl)
         # ---- what the step is made of, so that a 1 -> N curve can be read without re-running: the kernels alone, the grid
         #      collective alone (same buffer shape, both forms), the two back to back, and the N = 1 entry point on this rank
         from event_utils_amd import distributed as DD
@@ -297,8 +298,18 @@ def main():
                 DD.banded_exchange(tiled.voxel2_bands(c, n, t_first, t_last, B, H, W, K), outs[0])
             return run
         ms = lambda fn: round(timed(fn, args.steps, args.warmup) / args.steps * 1e3, 4)   # noqa: E731
+
+        def with_share_cu(flag, fn):      # the kernels in the geometry that leaves LDS for a collective's workgroups, or not
+            prev = tiled.FORCE["share_cu"]
+            tiled.FORCE["share_cu"] = flag
+            try:
+                return ms(fn)
+            finally:
+                tiled.FORCE["share_cu"] = prev
         result["breakdown"] = {
-            "headline_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only), "allreduce_ms": ms(allreduce_only),
+            "headline_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only),
+            "compute_share_cu_on_ms": with_share_cu(True, compute_only), "compute_share_cu_off_ms": with_share_cu(False, compute_only),
+            "allreduce_ms": ms(allreduce_only),
             "reduce_scatter_all_gather_ms": ms(rsag_only), "serial_ms": ms(serial), "serial_rsag_ms": ms(serial_rsag),
             "banded_ms": {str(K): ms(banded(K)) for K in (2, 4)},
             "n1_equivalent_ms": ms(step_public), "grid_bytes": int(zgrid.numel() * 4),
@@ -310,7 +321,9 @@ def main():
                     "kernel runs in K row bands, band k all-reduced while band k + 1 accumulates (EVK_VOXEL_COLLECTIVE=bandsK: "
                     "the exchange overlapped inside a single call); n1_equivalent_ms = the public "
                     "events_to_voxel_torch call BENCH's N = 1 `value` times, here on every rank at once without a "
-                    "collective (it allocates the grid and reads ts[0]/ts[-1] on the device: ~1 % above compute_ms)"}
+                    "collective (it allocates the grid and reads ts[0]/ts[-1] on the device: ~1 % above compute_ms); "
+                    "compute_share_cu_on / _off_ms = compute_ms with the partition geometry that leaves LDS for a collective's "
+                    "workgroups forced on / off (tiled.FORCE['share_cu']; default: on in a multi-rank job)"}
     else:
         # the same work through the internal entry point (resident output, host-supplied ts[0]/ts[-1], no out-of-range
         # check) and through the public call with per-call synchronous error reporting
@@ -432,6 +445,28 @@ def check_sharded(dist, dev, grid, pd, n, world):
                          "min %r max %r over ranks" % (gsum, float(psum.item()), tol, float(cmin.item()), float(cmax.item())))
     return {"checked": True, "check": {"grid_sum": gsum, "polarity_sum_all_ranks": float(psum.item()), "tolerance": tol,
                                         "grid_checksum_identical_on_all_ranks": True}}
+
+
+def oracle_self_check(dist, dev, voxel, cols, t_first, t_last, impl, m=200_000):
+    """Per-rank self-check of the N > 1 line against the ORACLE (the checker, outside every timed region): the first m events of
+    this rank's shard voxelised by the product path -- with the GLOBAL ts[0] / ts[-1], as the sharded step does -- against
+    oracle/reference_np.events_to_voxel_torch(t_range=...) on the host; bar 1e-5 of the grid's maximum (north_star).  Every rank
+    checks its own shard; the line carries the worst rank's error and fails loudly if any rank is off."""
+    from oracle import reference_np as R
+    x, y, t, p = (c[:m].contiguous() for c in cols)
+    out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    voxel(x, y, t, p, B, (H, W), t_first, t_last, out=out, check=False, impl=impl, fresh=True)
+    ref = R.events_to_voxel_torch(*(c.cpu().numpy() for c in (x, y, t, p)), B, sensor_size=(H, W), accum="f64",
+                                  t_range=(t_first, t_last))
+    err = float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max())
+    scale = float(np.abs(ref).max())
+    rel = torch.tensor([err / max(scale, 1e-30)], device=dev, dtype=torch.float64)
+    dist.all_reduce(rel, op=dist.ReduceOp.MAX)
+    worst = float(rel.item())
+    if not worst <= 1e-5:
+        raise SystemExit("sharded voxel path failed its oracle self-check: worst rank's max error %.3e of the grid maximum" % worst)
+    return {"events_per_rank": int(x.numel()), "max_err_over_grid_max_worst_rank": worst, "bar": 1e-5, "ok": True,
+            "oracle": "oracle/reference_np.events_to_voxel_torch (float64 accumulation, global ts[0]/ts[-1])"}
 
 
 def bench_c5_share(tiled, dev, impl):

@@ -11,7 +11,8 @@ import re
 import sys
 
 ALG = {"c2": 16 * 10_000_000 + 5 * 480 * 640 * 4, "c5_share": 16 * 50_000_000 + 5 * 720 * 1280 * 4,
-       "img_nearest": 12 * 10_000_000 + 480 * 640 * 4, "img_bilinear": 12 * 10_000_000 + 480 * 640 * 4}
+       "img_nearest": 12 * 10_000_000 + 480 * 640 * 4, "img_bilinear": 12 * 10_000_000 + 480 * 640 * 4,
+       "prebucketed": 16 * 10_000_000 + 5 * 480 * 640 * 4}
 
 
 def collect(d, counter):
@@ -35,7 +36,7 @@ def main():
                    "FETCH_SIZE reports half of a wide coalesced streaming read, MI355X_MICROARCH.md HBM section; WRITE_SIZE "
                    "as reported).  whole_call_bytes = sum over the kernels of one call; algorithmic_bytes = 16 B/event + "
                    "the grid, 12 B/event + the image for img_* (SURVEY.md 8(d)).  Summarised by tools/pmc_summary.py."}
-    for tag in ("c2", "c5_share", "img_nearest", "img_bilinear"):
+    for tag in ("c2", "c5_share", "img_nearest", "img_bilinear", "prebucketed"):
         if not os.path.isdir(os.path.join(root, "pmc_fetch_" + tag)):
             continue
         fetch = collect(os.path.join(root, "pmc_fetch_" + tag), "FETCH_SIZE")
@@ -50,6 +51,9 @@ def main():
             ks[name] = {"FETCH_SIZE_KB_avg": round(fa, 1), "WRITE_SIZE_KB_avg": round(wa, 1), "calls": max(f[1], w[1]),
                         "hbm_bytes_per_launch_corrected": b}
             total += b
+        if tag == "prebucketed":   # the bucketing ran once, outside the timed kernel: the call is k_voxel_tiled alone
+            ks = {k: v for k, v in ks.items() if "k_voxel_tiled" in k}
+            total = sum(v["hbm_bytes_per_launch_corrected"] for v in ks.values())
         out[tag] = {"kernels": ks, "whole_call_bytes": total, "algorithmic_bytes": ALG[tag],
                     "amplification": round(total / ALG[tag], 3) if total else None}
     json.dump(out, sys.stdout, indent=1)

@@ -5,17 +5,19 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r06}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 timeout -s KILL 500 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --no-cpu > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_bench_kernel_stats.csv \;
 rm -rf $OUT/stats
-for tag in c2 c5_share img_nearest img_bilinear; do
+for tag in c2 c5_share img_nearest img_bilinear prebucketed; do
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_fetch_$tag.log 2>&1
   timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_write_$tag.log 2>&1
-  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$tag -- python tools/pmc_workload.py $tag > $OUT/st_$tag.log 2>&1
+  # (kernel durations at steady clocks: a few hundred calls -- the first milliseconds of a burst run 15-20 % slower)
+  calls=400; [ $tag = c5_share ] && calls=150
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$tag -- python tools/pmc_workload.py $tag $calls > $OUT/st_$tag.log 2>&1
   find $OUT/st_$tag -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_${tag}_kernel_stats.csv \;
 done
 python tools/pmc_summary.py $OUT > $OUT/${R}_pmc_traffic.json
