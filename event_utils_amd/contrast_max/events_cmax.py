@@ -173,7 +173,7 @@ def segmentation_mask_from_d_iwe(d_iwe, th=None):
 
 
 def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3, gtol=1e-5, ftol=1e-6, maxiter=100, trace=None,
-             unit_first=True):
+             unit_first=True, fast=True):
     """
     BFGS with a line search made for this objective: every quantity it asks for is ONE pass over the resident events and it
     asks for as few as it can.  scipy's fmin_bfgs (the reference's optimiser, events_cmax.py:343-345) runs a strong-Wolfe
@@ -189,47 +189,73 @@ def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3,
     that keeps following them never ends), or no candidate improves it at all.
     Returns the minimiser (numpy float64).  trace: optional list that receives (x, f, g) of every accepted point.
     """
-    x = np.asarray(x0, dtype=np.float64).copy()
+    # (round 6) The iteration's own arithmetic is a handful of operations on dims-vectors (dims = 2 for the linear flow): as
+    # numpy calls -- norm, dot, outer, eye, a dozen temporaries per iteration -- they cost ~25 us per event pass, a sixth of a
+    # pass at 10 M events and a third at 1 M (tools/bfgs_profile.py).  Plain Python floats, same operations in the same order.
+    n = len(x0)
+    x = [float(v) for v in x0]
     fg_fn = objective.evaluate_function_and_numeric_gradient if numeric_grads else objective.evaluate_function_and_gradient
+    rng = range(n)
+
+    def dot(a, b):
+        s = 0.0
+        for i in rng:
+            s += a[i] * b[i]
+        return s
+
+    def norm(a):
+        return dot(a, a) ** 0.5
+
+    def axpy(al, d, base):
+        return [base[i] + al * d[i] for i in rng]
 
     def fg(q):
-        fv, gv = fg_fn(q, *args)
-        return float(fv), np.asarray(gv, dtype=np.float64)
+        fv, gv = fg_fn(np.array(q, dtype=np.float64), *args)
+        return float(fv), [float(v) for v in gv]
 
     def f3(points):
-        return [float(v) for v in objective.evaluate_function_batch(points, *args)]
+        return [float(v) for v in objective.evaluate_function_batch([np.array(q, dtype=np.float64) for q in points], *args)]
+    # an objective that can bind itself to these events (variance_objective.bind_fast) evaluates through closures that resolve
+    # everything but the flow once: same library calls, same numbers, ~20 us less host work between two passes
+    bound = objective.bind_fast(*args) if (fast and n == 2 and not numeric_grads and hasattr(objective, "bind_fast")) else None
+    if bound is not None:
+        fg, f3 = bound
+
+    def identity():
+        return [[1.0 if i == j else 0.0 for j in rng] for i in rng]
     f, g = fg(x)
     if trace is not None:
-        trace.append((x.copy(), f, g.copy()))
-    Hm = np.eye(x.size)
+        trace.append((np.array(x), f, np.array(g)))
+    Hm = identity()
     have_curvature = False                              # the inverse Hessian carries at least one update
-    scale = 1.0 / max(np.linalg.norm(g), 1e-12)        # first step: a unit-length move along -g (as scipy's first trial)
+    scale = 1.0 / max(norm(g), 1e-12)                   # first step: a unit-length move along -g (as scipy's first trial)
     for _ in range(maxiter):
-        if np.max(np.abs(g)) <= gtol:
+        if max(abs(v) for v in g) <= gtol:
             break
-        d = -Hm.dot(g)
-        slope = float(g.dot(d))
+        d = [-dot(Hm[i], g) for i in rng]
+        slope = dot(g, d)
         if not slope < 0.0:                              # not a descent direction: restart from steepest descent
-            Hm = np.eye(x.size)
+            Hm = identity()
             have_curvature = False
-            d, slope = -g, -float(g.dot(g))
+            d, slope = [-v for v in g], -dot(g, g)
         # Once the inverse Hessian has been updated the quasi-Newton step itself (length 1) is the natural candidate: value
         # AND gradient there are one pass (what an accepted point needs anyway), so an iteration whose unit step satisfies the
         # Armijo condition costs ONE event pass instead of two (round 5: 18 -> ~12 passes at configs[2]).  Only when it does
         # not is the three-lengths search run, below the unit step.
         best, a, grown = None, scale, 0
         fg_new = None
+        dn = norm(d)
         if unit_first and have_curvature:
-            f1, g1 = fg(x + d)
+            f1, g1 = fg(axpy(1.0, d, x))
             if f1 <= f + 1e-4 * slope:
                 best, fg_new = (f1, 1.0), (f1, g1)
             else:
                 a, grown = 1.0 / 9.0, 4          # the three lengths below the unit step: 1/27, 1/9, 1/3 -- and no growing back
         # line search: three step lengths per pass; while the longest one is the best, the next pass looks further out
         # (the first direction is -g with an unknown scale), while none satisfies the Armijo condition, closer in
-        while fg_new is None and a * np.linalg.norm(d) >= 0.5 * xtol:
+        while fg_new is None and a * dn >= 0.5 * xtol:
             alphas = (a / 3.0, a, 3.0 * a)
-            fs = f3([x + al * d for al in alphas])
+            fs = f3([axpy(al, d, x) for al in alphas])
             ok = [(fv, al) for fv, al in zip(fs, alphas) if fv <= f + 1e-4 * al * slope]
             if ok:
                 if best is None or min(ok)[0] < best[0]:
@@ -244,24 +270,27 @@ def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3,
         if best is None:
             break
         step = best[1]
-        x_new = x + step * d
+        x_new = axpy(step, d, x)
         f_new, g_new = fg_new if fg_new is not None else fg(x_new)
-        s_vec, y_vec = x_new - x, g_new - g
-        sy = float(y_vec.dot(s_vec))
+        s_vec = [x_new[i] - x[i] for i in rng]
+        y_vec = [g_new[i] - g[i] for i in rng]
+        sy = dot(y_vec, s_vec)
         if sy > 1e-12:
+            # H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T
             have_curvature = True
             rho = 1.0 / sy
-            I = np.eye(x.size)
-            Hm = (I - rho * np.outer(s_vec, y_vec)).dot(Hm).dot(I - rho * np.outer(y_vec, s_vec)) + rho * np.outer(s_vec, s_vec)
+            A = [[(1.0 if i == j else 0.0) - rho * s_vec[i] * y_vec[j] for j in rng] for i in rng]
+            AH = [[sum(A[i][k] * Hm[k][j] for k in rng) for j in rng] for i in rng]
+            Hm = [[sum(AH[i][k] * A[j][k] for k in rng) + rho * s_vec[i] * s_vec[j] for j in rng] for i in rng]
         gain = f - f_new
         x, f, g, scale = x_new, f_new, g_new, 1.0
         if trace is not None:
-            trace.append((x.copy(), f, g.copy()))
+            trace.append((np.array(x), f, np.array(g)))
         if callback is not None:
-            callback(x)
-        if np.linalg.norm(s_vec) < xtol or gain <= ftol * abs(f):
+            callback(np.array(x))
+        if norm(s_vec) < xtol or gain <= ftol * abs(f):
             break
-    return x
+    return np.array(x, dtype=np.float64)
 
 
 def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fmin_bfgs, x0=None, numeric_grads=False,

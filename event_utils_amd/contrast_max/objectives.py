@@ -357,6 +357,50 @@ class variance_objective(objective_function):
                                               out12, scratch, nbytes, impl=self.impl, host_out=host_out)
         return ev, float(t_ref), launch
 
+    def bind_fast(self, xs, ys, ts, ps, warpfunc, img_size, blur_sigma):
+        """(fg, f3) closures for a loop that evaluates THIS objective on THESE events many times (events_cmax.evk_bfgs):
+        fg(q) -> (f, [g0, g1]) = evaluate_function_and_gradient, f3([q0, q1, q2]) -> [f0, f1, f2] = evaluate_function_batch,
+        same library calls, same numbers -- with everything that does not depend on q resolved ONCE (device, buffers, blur
+        weights, the marshalled arguments of the calls: tiled.cmax_variance's cache entry is patched directly).  The gap
+        between two passes of an optimisation -- result read, Python, next enqueue -- was 41-43 us on the kernel timeline
+        (tools/bfgs_timeline.sh), a third of a pass at 10 M events.  None when the one-call path does not apply (plugin warp,
+        sharded run, adaptive lifespan, direct-kernel regime): the caller then uses the public methods."""
+        if (not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None or self.adaptive_lifespan
+                or getattr(self, "enqueue_only", False)):
+            return None
+        ev = _as_device_events(xs, ys, ts, ps)
+        if len(ev) == 0:
+            return None
+        blur = self.default_blur if blur_sigma is None else blur_sigma
+        post = (_lib.EVK_POST_MIX if self.reference_exact else _lib.EVK_POST_BLUR_IWE) | _lib.EVK_POST_VALUE
+        f32 = np.float32
+
+        def fg(q):
+            # (the first call, and any call whose flow the tiled kernels cannot take, goes through the public method)
+            c = cfg[0]
+            if c is not None:
+                r = tiled.cmax_variance_again(c, float(q[0]), float(q[1]))
+                if r is not None:
+                    return float(f32(-r[3])), [float(f32(-r[0])), float(f32(-r[1]))]
+            fv, gv = self.evaluate_function_and_gradient(np.asarray(q, dtype=np.float64), ev, None, None, None, warpfunc, img_size, blur)
+            if c is None:
+                cfg[0] = tiled.cmax_variance_entry(ev, post | 0, True, self)
+            return float(fv), [float(v) for v in gv]
+
+        def f3(points):
+            c = cf3[0]
+            if c is not None:
+                r = tiled.cmax_variance_batch3_again(c, [float(p_[0]) for p_ in points], [float(p_[1]) for p_ in points])
+                if r is not None:
+                    return [float(f32(-r[4 * k + 1])) for k in range(3)]
+            vals = self.evaluate_function_batch([np.asarray(p_, dtype=np.float64) for p_ in points], ev, None, None, None,
+                                                warpfunc, img_size, blur)
+            if c is None:
+                cf3[0] = tiled.cmax_variance_entry(ev, None, False, self)
+            return [float(v) for v in vals]
+        cfg, cf3 = [None], [None]
+        return fg, f3
+
     def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                                   blur_sigma=None, epsilon=1.0, with_value=False):
         """Forward-difference gradient of evaluate_function with absolute step `epsilon` -- exactly what

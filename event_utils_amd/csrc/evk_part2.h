@@ -323,12 +323,24 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 __builtin_amdgcn_raw_buffer_store_b128(u4v{v.x, v.y, v.z, v.w}, rs, i * 16, 0, /* sc1 */ 16);
             }
         } else {
-            // 4-byte records = HBM-resident calls: streaming stores (write-through ones cost the partition 5 % there:
-            // 219 against 209 us at 50 M events, and the boundary is 1 % of that call)
+            // 4-byte records = HBM-resident calls (write-through stores cost the partition 5 % there: 219 against 209 us at
+            // 50 M events, and the boundary is 1 % of that call)
+#ifndef V2_REC4_PLAIN_STORES
+// Round 6: PLAIN 16-byte stores for the runs of 4-byte records.  Streaming ("nt") stores had been measured against plain ones
+// on the partition kernel alone (-5 % at 50 M events) with the tile kernel timed BEHIND it on records that were still in the
+// Infinity Cache either way; in the call itself (rocprofv3 over 300 back-to-back calls, tools/c5_loop.py) the streamed runs
+// are gone from the cache when the tile kernel asks for them: k_voxel_tiles2 104.7 us behind streaming stores, 92.2 us behind
+// plain ones, the partition 200 us either way (the columns keep their nontemporal loads: with plain loads both kernels lose).
+#define V2_REC4_PLAIN_STORES 1
+#endif
             for (int i = tid; i < n16; i += THREADS) {
                 const uint4 v = src[i];
-                __builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
-                __builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+                if (V2_REC4_PLAIN_STORES) {
+                    dst[i] = v;
+                } else {
+                    __builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
+                    __builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+                }
             }
         }
     };

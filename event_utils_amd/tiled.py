@@ -686,6 +686,29 @@ def _spill_call(st, call):
         st[1] ^= 1
 
 
+def _retarget(c, S, win_w, win_h, Dx, Dy, device):
+    """A cached evaluation call whose flow needs another window (time slices S, LDS window win_w x win_h) than the one it was
+    marshalled for: patch the three geometry arguments and the staging buffer IN PLACE instead of building the plan and its
+    ~36 ctypes arguments again.  A BFGS run walks through a handful of window sizes (the flow grows from 0 to the optimum), so
+    almost every pass of a cold run used to take the slow path (12 of 14 at configs[2]: tools/bfgs_profile.py).  False when the
+    tiled kernels cannot take this flow at all (the caller then goes through iwe_plan, which falls back to the direct kernel)."""
+    import math
+    tw, th = c["tile"]
+    cand = (math.ceil((Dx + win_w) / (1 << tw)) + 1) * (math.ceil((Dy + win_h) / (1 << th)) + 1) * S
+    if S > 64 or cand > 128:
+        return False
+    skey = c["skey_head"] + (S, c["planes"], win_w, win_h)
+    nbytes = _staging_bytes.get(skey)
+    if nbytes is None:
+        nbytes = _staging_bytes[skey] = int(_lib.lib().evk_iwe_tiled_staging_bytes(*skey))
+    staging = _buf("iwe_staging", nbytes, device)
+    args, i = c["args"], c["i_staging"]
+    args[7], args[8], args[9] = S, win_w, win_h
+    args[i], args[i + 1] = D.ptr(staging), nbytes
+    c["win"], c["staging"], c["staging_bytes"] = (S, win_w, win_h), staging, nbytes
+    return True
+
+
 def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights, radius, post_flags, buf, out, scratch,
                   scratch_bytes, impl=None, host_out=None):
     """One-call objective evaluation (evk_cmax_variance_tiled_f32) into `out` (4 doubles); returns False when the
@@ -703,7 +726,8 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
             and c["host_out"] is host_out and math.isfinite(vx) and math.isfinite(vy):
         span, tw, th, planes = c["geo"]
         S, win_w, win_h = _iwe_window(0.0, 1.0, abs(vx) * span, abs(vy) * span, 1 << tw, 1 << th, planes)
-        if (S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]:
+        if ((S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]) or \
+                _retarget(c, S, win_w, win_h, abs(vx) * span, abs(vy) * span, buf.device):
             args = c["args"]
             args[12], args[13] = vx, vy
             st = c["spill"]
@@ -711,6 +735,7 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
                 args[c["i_parity"]] = st[1] ^ 1
             args[-1] = D.stream()
             _spill_call(st, lambda: _lib.check(c["fn"](*args), "evk_cmax_variance_tiled_f32"))
+            ev.__dict__["_cmax_last_single"] = c
             return True
     plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
     if plan is None:
@@ -728,8 +753,10 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
     cache[ckey] = {"fn": fn, "args": args, "buf": buf, "out": out, "scratch": scratch, "weights": weights,
                    "host_out": host_out, "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
                    "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6], planes),
-                   "spill": sp_state,
+                   "spill": sp_state, "tile": (head[5], head[6]), "planes": planes, "skey_head": (plan["buckets"].ntiles, plan["buckets"].n),
+                   "i_staging": len(head) + 3, "ckey": ckey,
                    "i_parity": len(args) - 3, "keep": (plan, spill)}
+    ev.__dict__["_cmax_last_single"] = cache[ckey]
     return True
 
 
@@ -749,8 +776,10 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
     if c is not None and c["buf"] is buf and c["scratch"] is scratch and c["weights"] is weights \
             and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys)):
         span, tw, th = c["geo"]
-        S, win_w, win_h = _iwe_window(0.0, 1.0, max(abs(v) for v in vxs) * span, max(abs(v) for v in vys) * span, 1 << tw, 1 << th, 3)
-        if (S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]:
+        Dx, Dy = max(abs(v) for v in vxs) * span, max(abs(v) for v in vys) * span
+        S, win_w, win_h = _iwe_window(0.0, 1.0, Dx, Dy, 1 << tw, 1 << th, 3)
+        if ((S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], buf.device) is c["staging"]) or \
+                _retarget(c, S, win_w, win_h, Dx, Dy, buf.device):
             c["vx"][:] = vxs
             c["vy"][:] = vys
             args, st = c["args"], c["spill"]
@@ -758,8 +787,10 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
                 args[c["i_parity"]] = st[1] ^ 1
             args[-7] = D.ptr(out12)          # (the samplers hand in a different slice of their result buffer per trio)
             args[-2] = D.host_ptr(host_out) if host_out is not None else None
+            c["host_res"] = host_out
             args[-1] = D.stream()
             _spill_call(st, lambda: _lib.check(c["fn"](*args), "evk_cmax_variance_batch3_tiled_f32"))
+            ev.__dict__["_cmax_last_b3"] = c
             return True
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
@@ -775,8 +806,67 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
     cache[ckey] = {"fn": fn, "args": args, "buf": buf, "scratch": scratch, "weights": weights,
                    "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
                    "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6]),
-                   "spill": st, "i_parity": len(args) - 3, "vx": plan["keep"][0], "vy": plan["keep"][1], "keep": (plan, spill)}
+                   "spill": st, "i_parity": len(args) - 3, "vx": plan["keep"][0], "vy": plan["keep"][1], "keep": (plan, spill),
+                   "tile": (head[5], head[6]), "planes": 3, "skey_head": (plan["buckets"].ntiles, plan["buckets"].n),
+                   "i_staging": len(head) + 2, "host_res": host_out, "ckey": ckey}
+    ev.__dict__["_cmax_last_b3"] = cache[ckey]
     return True
+
+
+def cmax_variance_entry(ev, post_flags, single, obj):
+    """The cached call of the LAST cmax_variance (single=True: it must be the one with `post_flags`) / cmax_variance_batch3 on
+    `ev`, for a loop that repeats it with other flows (objectives.bind_fast); None when there is none, or when it does not
+    bring its results to the host itself."""
+    c = ev.__dict__.get("_cmax_last_single" if single else "_cmax_last_b3")
+    if c is None:
+        return None
+    if single:
+        return c if (c["ckey"][7] == post_flags and c.get("host_out") is not None) else None
+    return c if c.get("host_res") is not None else None
+
+
+def _again(c, name):
+    args, st = c["args"], c["spill"]
+    if st is not None:
+        args[c["i_parity"]] = st[1] ^ 1
+    args[-1] = D.stream()
+    _spill_call(st, lambda: _lib.check(c["fn"](*args), name))
+
+
+def cmax_variance_again(c, vx, vy):
+    """Repeat the cached evaluation `c` at another flow -> its host result array (4 doubles, filled when the call returns), or
+    None when the tiled kernels cannot take this flow or the persistent buffers have been replaced."""
+    import math
+    if not (math.isfinite(vx) and math.isfinite(vy)):
+        return None
+    span, tw, th, planes = c["geo"]
+    Dx, Dy = abs(vx) * span, abs(vy) * span
+    S, win_w, win_h = _iwe_window(0.0, 1.0, Dx, Dy, 1 << tw, 1 << th, planes)
+    dev = c["buf"].device
+    if not (((S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], dev) is c["staging"]) or
+            _retarget(c, S, win_w, win_h, Dx, Dy, dev)):
+        return None
+    c["args"][12], c["args"][13] = vx, vy
+    _again(c, "evk_cmax_variance_tiled_f32")
+    return c["host_out"]
+
+
+def cmax_variance_batch3_again(c, vxs, vys):
+    """The same for the three-flow call -> its host result array (12 doubles)."""
+    import math
+    if not all(math.isfinite(v) for v in vxs + vys):
+        return None
+    span, tw, th = c["geo"]
+    Dx, Dy = max(abs(v) for v in vxs) * span, max(abs(v) for v in vys) * span
+    S, win_w, win_h = _iwe_window(0.0, 1.0, Dx, Dy, 1 << tw, 1 << th, 3)
+    dev = c["buf"].device
+    if not (((S, win_w, win_h) == c["win"] and _buf("iwe_staging", c["staging_bytes"], dev) is c["staging"]) or
+            _retarget(c, S, win_w, win_h, Dx, Dy, dev)):
+        return None
+    c["vx"][:] = vxs
+    c["vy"][:] = vys
+    _again(c, "evk_cmax_variance_batch3_tiled_f32")
+    return c["host_res"]
 
 
 WARM_MS = 40.0
