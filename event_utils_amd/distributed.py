@@ -177,17 +177,25 @@ def all_reduce_sum_(grid, group=None, force=False, form=None):
     return grid
 
 
-def _raise_everywhere(oob_state, exc_type, msg, group):
+def _raise_everywhere(oob_state, exc_type, msg, group, local_error=None):
     """A data-dependent error must surface on EVERY rank (a rank that raised alone would leave the others waiting in the
-    next collective): the per-rank counts of dropped events are summed over the ranks and all of them raise."""
+    next collective): the per-rank counts of dropped events are summed over the ranks and all of them raise.
+    local_error: an exception THIS rank's shard raised before its kernels ran (a shard the library refuses, float64 columns:
+    round 6) -- the rank has joined every collective with a zero contribution; here every rank learns of it and raises: the
+    failing ranks their own exception, the others a RuntimeError that says so."""
     # (earlier DEFERRED reports of this stream are folded in here, quietly: polling them in OobCounter's constructor could
     # raise on this rank alone, between two collectives, and leave the other ranks waiting in the all-reduce)
     local = oob_state.drain() + oob_state._advance(int(oob_state.counter.item()) & 0xFFFFFFFF)
-    cnt = torch.tensor([local], dtype=torch.int64, device=oob_state.counter.device)
+    cnt = torch.tensor([local, 1 if local_error is not None else 0], dtype=torch.int64, device=oob_state.counter.device)
     total = cnt.to(_collective_device(group)) if is_distributed(group) else cnt
     if is_distributed(group):
         _dist().all_reduce(total, op=_dist().ReduceOp.SUM, group=group)
-    total = int(total.item())
+    total, failed = (int(v) for v in total.tolist())
+    if local_error is not None:
+        raise local_error
+    if failed:
+        raise RuntimeError("the sharded call failed on %d other rank(s) before their kernels ran (their shards were refused); "
+                           "the collectives were completed with zero contributions from them" % failed)
     if total:
         raise exc_type("%s (%d offending events over all ranks, %d on this one)" % (msg, total, local))
 
@@ -263,21 +271,41 @@ def events_to_voxel_torch_sharded(xs, ys, ts, ps, B, sensor_size=(180, 240), gro
     # library's tiling only, never on this rank's events.  A rank with an empty shard contributes zero bands with the same
     # edges; columns the one-pass path cannot read in place (views that are not 16-byte aligned, other dtypes) are copied.
     edges = tiled.voxel2_band_rows(H, W, B, K) if (K >= 2 and tiled.default_impl() != "direct") else None
-    if edges is not None:
-        dev = D.require_gpu()
-        if n:
-            cols = [D.to_device(a, torch.float32, dev).contiguous() for a in (xs, ys, ts, ps)]
-            cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]
-            bands = tiled.voxel2_bands(cols, n, float(t_first), float(t_last), B, H, W, K, oob)
+    # Everything that can fail on THIS rank alone -- columns the single-process call refuses (float64 time stamps / polarities:
+    # voxel_grid.py's dtype error), a shard the library does not take (more than 4e9 events, a geometry it refuses) -- happens
+    # BEFORE the first collective, inside a try: the rank then joins every collective with a zero contribution (the peers must
+    # not be left waiting in an all-reduce) and the error surfaces on all ranks afterwards (_raise_everywhere).
+    local_error = None
+    dev = D.require_gpu()
+
+    def zero_bands():
+        return ((y0, y1, torch.zeros((B, y1 - y0, W), dtype=torch.float32, device=dev)) for y0, y1 in edges)
+    try:
+        for name, col in (("ts", ts), ("ps", ps)):
+            if getattr(col, "dtype", None) in (torch.float64, np.float64, np.dtype(np.float64)):
+                raise RuntimeError("Index put requires the source and destination dtypes match, got Float for the destination "
+                                   "and Double for the source. (%s is float64; events_to_voxel_torch raises the same)" % name)
+        if edges is not None:
+            if n:
+                cols = [D.to_device(a, torch.float32, dev).contiguous() for a in (xs, ys, ts, ps)]
+                cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]
+                bands = tiled.voxel2_bands(cols, n, float(t_first), float(t_last), B, H, W, K, oob)
+            else:
+                bands = zero_bands()
         else:
-            bands = ((y0, y1, torch.zeros((B, y1 - y0, W), dtype=torch.float32, device=dev)) for y0, y1 in edges)
+            part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
+    except Exception as e:  # noqa: BLE001
+        local_error = e
+        if edges is not None:
+            bands = zero_bands()
+        else:
+            part = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
     if bands is not None:
         out = banded_exchange(bands, torch.empty((B, H, W), dtype=torch.float32, device=dev), group)
     else:
-        part = _local_voxel(xs, ys, ts, ps, B, sensor_size, t_first, t_last, oob)
         out = all_reduce_sum_(part, group, form="rsag" if voxel_collective() == "rsag" else None)
     _raise_everywhere(oob.state, IndexError, "index out of range for voxel grid of size %s"
-                      % ((B, int(sensor_size[0]), int(sensor_size[1])),), group)
+                      % ((B, int(sensor_size[0]), int(sensor_size[1])),), group, local_error)
     return out
 
 

@@ -93,6 +93,15 @@ def _run(rank, world, port):
         os.environ["EVK_VOXEL_COLLECTIVE"] = form
         with pytest.raises(IndexError):
             DD.events_to_voxel_torch_sharded(*bad, B, (H, W))
+    # a shard that is REFUSED on rank 1 only -- float64 time stamps, the dtype error events_to_voxel_torch raises -- before
+    # its kernels run: rank 1 still joins every collective (zero bands / a zero grid), then BOTH ranks raise (round 6)
+    f64 = [c.clone() for c in cols]
+    if rank == 1:
+        f64[2] = f64[2].double()
+    for form in ("allreduce", "bands2"):
+        os.environ["EVK_VOXEL_COLLECTIVE"] = form
+        with pytest.raises(RuntimeError, match="Double for the source" if rank == 1 else "other rank"):
+            DD.events_to_voxel_torch_sharded(*f64, B, (H, W))
     os.environ.pop("EVK_VOXEL_COLLECTIVE")
     DD.events_to_voxel_torch_sharded(*cols, B, (H, W))        # ... and the next call is clean
     E.check_errors()
