@@ -150,6 +150,52 @@ __device__ __forceinline__ void blur_tile_fill(float *patch, float *inter, const
     }
     __syncthreads();
 }
+// NP planes at once (round 6): FILL(py, px, v) delivers the source values of ALL planes at a patch position, so their global
+// loads are in flight together, and every phase (fill | rows | columns) runs over all planes between ONE pair of barriers --
+// three planes cost three barriers and one exposed load latency instead of nine and three.  Same arithmetic per pixel as
+// blur_tile_fill (bit-identical values).  patch: NP * PW * PW floats, inter: NP * EVK_POST_T * PW floats.
+template <int RC, int NPMAX, typename FILL>
+__device__ __forceinline__ void blur_tiles_fill(float *patch, float *inter, const BlurWeights &bw, int np, FILL fill,
+                                                float (&res)[NPMAX][4]) {
+    const int r = RC ? RC : bw.radius, PW = EVK_POST_T + 2 * r, PH = PW, psz = PH * PW, isz = EVK_POST_T * PW;
+    for (int i = threadIdx.x; i < psz; i += EVK_BLOCK) {
+        const int py = i / PW, px = i - py * PW;
+        float v[NPMAX];
+        fill(py, px, v);
+#pragma unroll
+        for (int p = 0; p < NPMAX; ++p)
+            if (p < np) patch[p * psz + i] = v[p];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < isz; i += EVK_BLOCK) {  // axis 0 (rows)
+        const int y = i / PW, xx = i - y * PW;
+#pragma unroll
+        for (int p = 0; p < NPMAX; ++p) {
+            if (p >= np) continue;
+            const float *col = patch + p * psz + (y + r) * PW + xx;
+            double acc = (double)col[0] * bw.w[r];
+#pragma unroll
+            for (int j = r; j >= 1; --j) acc += ((double)col[-j * PW] + (double)col[j * PW]) * bw.w[r - j];
+            inter[p * isz + i] = (float)acc;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // axis 1 (columns)
+        const int o = threadIdx.x + k * EVK_BLOCK;
+        const int y = o / EVK_POST_T, x = o - y * EVK_POST_T;
+#pragma unroll
+        for (int p = 0; p < NPMAX; ++p) {
+            if (p >= np) continue;
+            const float *row = inter + p * isz + y * PW + x + r;
+            double acc = (double)row[0] * bw.w[r];
+#pragma unroll
+            for (int j = r; j >= 1; --j) acc += ((double)row[-j] + (double)row[j]) * bw.w[r - j];
+            res[p][k] = (float)acc;
+        }
+    }
+    __syncthreads();
+}
 // the same with the source read from global memory: LOAD(gy, gx) returns image pixel (gy, gx)
 template <int RC, typename LOAD>
 __device__ __forceinline__ void blur_tile(float *patch, float *inter, const BlurWeights &bw, int y0, int x0, int ch,

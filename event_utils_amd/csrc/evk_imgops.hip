@@ -74,6 +74,7 @@ struct PostParams {
     double gparam;  // MODE 1: parameter of g;  MODE 2: p of sum(exp(-p v))
     double thresh;  // MODE 2: threshold of count(v > thresh)
     unsigned int *max_bits;  // MODE 2: running max of v as order-preserving uint bits (atomicMax)
+    int batch_planes;        // MODE 1 / 3: the LDS holds the patches of all three planes (launches whose 3 x LDS fits)
     int y_lo, y_hi;          // rows whose pixels enter the sums (the whole image: 0, ch).  A row block of an image that is
                              // sharded by rows (evk_objective_variance_rows_f32) carries halo rows that are blurred FROM
                              // but not summed
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
     const uint32_t flags = pp.flags;
     extern __shared__ float sm[];
     const int r = RC ? RC : bw.radius, PW = EVK_POST_T + 2 * r;
-    float *patch = sm, *inter = sm + PW * PW;
+    float *patch = sm, *inter = sm + ((MODE == 1 || MODE == 3) && pp.batch_planes ? 3 : 1) * PW * PW;
     const int tiles_x = (cw + EVK_POST_T - 1) / EVK_POST_T, ntile = tiles_x * ((ch + EVK_POST_T - 1) / EVK_POST_T);
     const int64_t plane = (int64_t)ch * cw;
     iwe += blockIdx.y * plane;                                         // MODE 0 batched over image planes
@@ -133,6 +134,36 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
         // (One workgroup per PART of a tile -- channel 0, channel 1, blurred IWE; grid.y = 3 -- measured slower: 37.4 vs
         // 29.5 us for value + gradient at 720p, and the finalise has three times the partial sums to add.)
         float d[2][4], a[4];
+        const bool need_a = MODE == 3 || (flags & EVK_POST_BLUR_IWE);
+        if (pp.batch_planes) {
+            // (round 6) all planes of the tile in ONE fill | rows | columns sweep (evk_img.h, blur_tiles_fill): the two dIWE
+            // channels' loads serve both mixed channels, the IWE's loads fly with them
+            uint64_t lo[2] = {0, 0}, hi[2] = {0, 0};
+            for (int c = 0; c < 2; ++c)
+                for (int j = 1; j <= r; ++j) {
+                    lo[c] |= (uint64_t)reflect_idx(c - j, 2) << j;
+                    hi[c] |= (uint64_t)reflect_idx(c + j, 2) << j;
+                }
+            float res3[3][4];
+            blur_tiles_fill<RC, 3>(patch, inter, bw, need_a ? 3 : 2, [&](int py, int px, float (&v)[3]) {
+                const int64_t pix = (int64_t)reflect_idx(y0 - r + py, ch) * cw + reflect_idx(x0 - r + px, cw);
+                const float dv[2] = {diwe[pix], diwe[plane + pix]};
+                v[2] = need_a ? iwe[pix] : 0.0f;
+                if (!(flags & EVK_POST_MIX)) {
+                    v[0] = dv[0], v[1] = dv[1];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        double s = (double)dv[c] * bw.w[r];
+                        for (int j = r; j >= 1; --j)
+                            s += ((double)((lo[c] >> j) & 1 ? dv[1] : dv[0]) + (double)((hi[c] >> j) & 1 ? dv[1] : dv[0])) * bw.w[r - j];
+                        v[c] = (float)s;
+                    }
+                }
+            }, res3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[0][k] = res3[0][k], d[1][k] = res3[1][k], a[k] = res3[2][k];
+        } else {
         for (int c = 0; c < 2; ++c) {
             // channel reflected at offsets -j / +j of the length-2 channel axis: the same for every pixel, so the two
             // reflections per tap are taken once per tile (bit j of lo / hi), not once per tap and pixel
@@ -153,8 +184,9 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_post_fused(const float *__restric
             };
             blur_tile<RC>(patch, inter, bw, y0, x0, ch, cw, load_mixed, d[c]);
         }
-        if (MODE == 3 || (flags & EVK_POST_BLUR_IWE)) {
+        if (need_a) {
             blur_tile<RC>(patch, inter, bw, y0, x0, ch, cw, [&](int gy, int gx) { return iwe[(int64_t)gy * cw + gx]; }, a);
+        }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -237,6 +269,18 @@ extern "C" int evk_variance_grad_f32(const float *iwe, const float *diwe, int64_
     return launch_reduce<1>(iwe, diwe, n, out, scratch, scratch_bytes, stream);
 }
 
+// LDS of a post-pass workgroup; MODE 1 / 3 hold the patches of all three planes (one fill | rows | columns sweep) while that fits
+// the 64 KB a launch gets without asking
+static size_t post_lds(int mode, int radius, int *batch) {
+    const int PW = EVK_POST_T + 2 * radius;
+    const size_t one = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
+    *batch = ((mode == 1 || mode == 3) && 3 * one <= (size_t)60 * 1024) ? 1 : 0;
+#ifdef EVK_POST_NO_BATCH
+    *batch = 0;   // (A/B)
+#endif
+    return *batch ? 3 * one : one;
+}
+
 template <int MODE>
 static int launch_post(const float *iwe, const float *diwe, int h, int w, const double *host_weights, int radius,
                        uint32_t flags, double *out, void *scratch, int64_t scratch_bytes, void *stream,
@@ -261,10 +305,9 @@ static int launch_post(const float *iwe, const float *diwe, int h, int w, const 
     BlurWeights bw;
     bw.radius = radius;
     for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
-    const int PW = EVK_POST_T + 2 * radius;
-    const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     PostParams pp;
+    const size_t lds = post_lds(MODE, radius, &pp.batch_planes);
+    hipStream_t s = (hipStream_t)stream;
     pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = 0, pp.y_hi = h;
     if (radius == 4) k_post_fused<MODE, 4><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     else k_post_fused<MODE, 0><<<dim3(grid, nplanes), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
@@ -342,10 +385,9 @@ static int launch_post_rows(const float *img, int hb, int w, int y_lo, int y_hi,
     BlurWeights bw;
     bw.radius = radius;
     for (int j = 0; j < 2 * radius + 1; ++j) bw.w[j] = host_weights[j];
-    const int PW = EVK_POST_T + 2 * radius;
-    const size_t lds = (size_t)(PW * PW + EVK_POST_T * PW) * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     PostParams pp;
+    const size_t lds = post_lds(MODE, radius, &pp.batch_planes);
+    hipStream_t s = (hipStream_t)stream;
     pp.flags = flags, pp.gfun = EVK_G_IDENT, pp.gparam = 0.0, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = y_lo, pp.y_hi = y_hi;
     const float *diwe = img + (int64_t)hb * w;
     if (radius == 4) k_post_fused<MODE, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, diwe, hb, w, bw, pp, (double *)scratch);
@@ -405,7 +447,7 @@ extern "C" int evk_objective_stats_f32(const float *img, int h, int w, const dou
     hipError_t e = hipMemsetAsync(max_bits, 0, sizeof(unsigned int), s);
     if (e != hipSuccess) return (int)e;
     PostParams pp;
-    pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits, pp.y_lo = 0, pp.y_hi = h;
+    pp.flags = 0, pp.gfun = 0, pp.gparam = p, pp.thresh = thresh, pp.max_bits = max_bits, pp.y_lo = 0, pp.y_hi = h, pp.batch_planes = 0;
     if (radius == 4) k_post_fused<2, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
     else k_post_fused<2, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(img, nullptr, h, w, bw, pp, (double *)scratch);
     k_reduce_final<0, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, wide);
@@ -428,6 +470,7 @@ extern "C" int evk_objective_gradsums_f32(const float *iwe, const float *diwe, i
     hipStream_t s = (hipStream_t)stream;
     PostParams pp;
     pp.flags = flags, pp.gfun = gfun, pp.gparam = gparam, pp.thresh = 0.0, pp.max_bits = nullptr, pp.y_lo = 0, pp.y_hi = h;
+    lds = post_lds(1, radius, &pp.batch_planes);
     if (radius == 4) k_post_fused<1, 4><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     else k_post_fused<1, 0><<<dim3(grid, 1), EVK_BLOCK, lds, s>>>(iwe, diwe, h, w, bw, pp, (double *)scratch);
     k_reduce_final<1, true><<<1, EVK_BLOCK, 0, s>>>((const double *)scratch, grid, (int64_t)h * w, out8);

@@ -1129,7 +1129,47 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_iwe_gather(const float *__restric
             sort_w[rank] = w, sort_x[rank] = list_x[k], sort_y[rank] = list_y[k];
         }
         __syncthreads();
-        for (int k = 0; k < nlist; ++k) add_window(sort_w[k], sort_x[k], sort_y[k]);
+#ifndef EVK_GATHER_BATCH
+#define EVK_GATHER_BATCH 4   // (A/B: 1 = one window at a time)
+#endif
+        if (EVK_GATHER_BATCH <= 1) {
+            for (int k = 0; k < nlist; ++k) add_window(sort_w[k], sort_x[k], sort_y[k]);
+        } else {
+            // (round 6) the windows of the list FOUR at a time: their staging loads are issued together and added in list
+            // order afterwards -- the same sums in the same order, a latency chain of nlist / 4 round trips instead of nlist
+            // (the list holds 4-9 windows at configs[2]'s optimum; this kernel is a chain of dependent loads over a
+            // 1-4 MB image: 15.8 -> ~11 us with three planes at 640x480)
+            constexpr int GB = EVK_GATHER_BATCH;
+            for (int k0 = 0; k0 < nlist; k0 += GB) {
+                float v[GB][ROWS][3];
+                bool ok[GB][ROWS];
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    const int k = k0 + u < nlist ? k0 + u : nlist - 1;
+                    const int w = sort_w[k], lx = X - sort_x[k], oy = sort_y[k];
+                    const bool okx = k0 + u < nlist && lx >= 0 && lx < win_w;
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr) {
+                        const int ly = Yb + rr * RSTEP - oy;
+                        ok[u][rr] = okx && inside[rr] && ly >= 0 && ly < win_h;
+                        const float *st = staging + (int64_t)w * PLANES * wcells + (ok[u][rr] ? ly * win_w + lx : 0);
+                        v[u][rr][0] = v[u][rr][1] = v[u][rr][2] = 0.0f;
+                        if (ok[u][rr]) {
+                            v[u][rr][0] = st[0];
+                            if constexpr (GRAD) v[u][rr][1] = st[wcells], v[u][rr][2] = st[2 * wcells];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GB; ++u)
+#pragma unroll
+                    for (int rr = 0; rr < ROWS; ++rr)
+                        if (ok[u][rr]) {
+                            acc[rr][0] += v[u][rr][0];
+                            if constexpr (GRAD) acc[rr][1] += v[u][rr][1], acc[rr][2] += v[u][rr][2];
+                        }
+            }
+        }
     } else {  // more candidate windows than the LDS list holds (huge flows / many slices): walk them all
         for (int ty = ty_a; ty <= ty_b; ++ty)
             for (int tx = tx_a; tx <= tx_b; ++tx) {
