@@ -290,3 +290,49 @@ def test_bucketing_delivers_compact_records_and_stats_in_one_call(monkeypatch):
                         obj.evaluate_gradient(prm, ev, None, None, None, E.linvel_warp(), (H, W), 1.0).copy())
         assert list(ev._buckets.values())[0].iwe_flag == _lib.EVK_IWE_COMPACT and ev.p_absmax() == 3.0
     assert vals[False][0] == vals[True][0] and np.array_equal(vals[False][1], vals[True][1])
+
+
+def test_bound_evaluators_and_retargeted_calls_give_the_public_methods_numbers():
+    """Round 6: variance_objective.bind_fast -- the closures evk_bfgs evaluates through -- and the in-place re-targeting of a
+    cached evaluation call when the flow needs another LDS window (tiled._retarget) are plumbing only: value + gradient and
+    the three-flow values equal the public methods' bit for bit over flows from 0 to 400 px/s (several window sizes and time
+    slices, in both directions), a flow the tiled kernels cannot take falls back to the public path, and evk_bfgs follows the
+    same trajectory with and without them."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import evk_bfgs
+    n, H, W = 400_000, 240, 320
+    x, y, t, p = bench.structured_scene(7, n, H, W)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    w = E.linvel_warp()
+
+    def objective():
+        o = E.variance_objective()
+        o.sensor_size, o.reference_exact = (H, W), False
+        return o
+    args = (ev, None, None, None, w, (H, W), 1.0)
+    fast, ref = objective(), objective()
+    fg, f3 = fast.bind_fast(*args)
+    flows = [(0.0, 0.0), (3.0, -2.0), (40.0, -25.0), (120.0, 90.0), (400.0, -380.0), (41.0, -25.5), (1.0, 1.0), (2500.0, 10.0)]
+    for q in flows + flows[::-1]:
+        fv, gv = fg(list(q))
+        rf, rg = ref.evaluate_function_and_gradient(np.array(q), *args)
+        if abs(q[0]) > 1000.0:      # (beyond the LDS windows: both go through the direct kernels, whose float atomics add in any order)
+            assert abs(fv - float(rf)) <= 1e-5 * abs(float(rf)) and np.allclose(gv, rg, rtol=1e-3, atol=1e-7), q
+        else:
+            assert fv == float(rf) and gv == [float(v) for v in rg], q
+    trios = [[(0.0, 0.0), (1.0, 0.0), (0.0, 1.0)], [(40.0, -25.0), (13.0, -8.0), (120.0, -75.0)], [(300.0, 300.0)] * 3,
+             [(1.0, 2.0), (2.0, 1.0), (0.5, 0.5)]]
+    for trio in trios + trios[::-1]:
+        got = f3([list(q) for q in trio])
+        want = [float(v) for v in ref.evaluate_function_batch([np.array(q) for q in trio], *args)]
+        assert got == want, trio
+    runs = {}
+    for use_fast in (True, False):
+        o, tr = objective(), []
+        xs = evk_bfgs(o, np.array([0.0, 0.0]), args, trace=tr, fast=use_fast)
+        runs[use_fast] = (xs, tr)
+    assert np.array_equal(runs[True][0], runs[False][0]) and len(runs[True][1]) == len(runs[False][1])
+    for (xa, fa, ga), (xb, fb, gb) in zip(runs[True][1], runs[False][1]):
+        assert np.array_equal(xa, xb) and fa == fb and np.array_equal(ga, gb)
+    assert np.linalg.norm(runs[True][0] - np.array([40.0, -25.0])) < 3.0
