@@ -499,7 +499,8 @@ def bench_prebucketed(tiled, sets, n, t_first, t_last, dev, reps):
     exactly what this kernel moves (`traffic`: the committed PMC pass of the same workload)."""
     from event_utils_amd import _lib, _device as D
     L = _lib.lib()
-    tw, th = 5, 4        # 32 x 16 pixel tiles: 600 tiles at 640x480 (DESIGN.md section 3, K2)
+    tw, th = 4, 4        # 16 x 16 pixel tiles: 1200 tiles at 640x480 -- 4.7 per CU (600 tiles of 32 x 16 are 3 workgroups on 88 CUs
+                         # and 2 on the rest: 41.7 against 35.6 us, tools/prebucketed_sweep.py)
     bks = [tiled.bucket_events(*c, 0, H, W, tw, th) for c in sets]
     nbytes = int(L.evk_voxel_tiled_staging_bytes(bks[0].ntiles, n, B, tw, th))
     staging = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -530,7 +531,7 @@ def bench_prebucketed(tiled, sets, n, t_first, t_last, dev, reps):
     traffic, src, _ = pmc_traffic("k_voxel_tiled", "prebucketed")
     return {"workload": "configs[1] with the events ALREADY bucketed by output tile (north_star's own assumption): 10M events, "
                         "640x480, 5 bins; 16-byte (x, y, t, p) records, tile-contiguous, %d streams rotating (HBM-resident)" % len(bks),
-            "kernel": "k_voxel_tiled (evk_voxel_tiled_f32): one workgroup per 32x16 tile, float64 LDS accumulators, plain-store flush",
+            "kernel": "k_voxel_tiled (evk_voxel_tiled_f32): one workgroup per 16x16 tile, float64 LDS accumulators, plain-store flush",
             "kernel_ms": round(k_ms, 4), "Mevents_per_s": round(n / k_ms / 1e3, 1),
             "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,

@@ -60,8 +60,14 @@ class NativeColumns:
         return out
 
 
+import weakref
+
+_LIVE = weakref.WeakSet()      # every DeviceEvents alive: release_scratch() drops the call caches they hold on the scratch
+
+
 class DeviceEvents:
     def __init__(self, x, y, t, p, t_host=None, native=None):
+        _LIVE.add(self)
         if native is None:
             assert x.shape == y.shape == t.shape == p.shape and x.dim() == 1
             assert x.dtype == y.dtype == t.dtype == p.dtype and x.dtype in (torch.float32, torch.float64)

@@ -110,6 +110,12 @@ def release_scratch(device=None, stream=None):
     def match(di, sid):
         return (dev_index is None or di == dev_index) and (stream is None or sid == stream)
 
+    # (the marshalled calls cached on live DeviceEvents point into these buffers: dropped with them -- the bucketed records of a
+    # DeviceEvents are its own and stay)
+    from . import events as _events
+    for ev in list(_events._LIVE):
+        for k in ("_cmax_calls", "_cmax_last_single", "_cmax_last_b3"):
+            ev.__dict__.pop(k, None)
     for store, pos in ((_persist, (1, 2)), (_zpersist, (1, 2)), (_spill, (0, 1)), (D._scratch, (0, 1))):
         for k in [k for k in store if match(k[pos[0]], k[pos[1]])]:
             v = store.pop(k)

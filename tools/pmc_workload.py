@@ -35,7 +35,7 @@ if tag.startswith("img_"):     # the event images of bench.py's image_10m block:
     sys.exit(0)
 if tag == "prebucketed":   # bench.py's `prebucketed` block: the north_star kernel on records bucketed once (k_voxel_tiled, 16 B/event)
     from event_utils_amd import tiled, _lib, _device as D  # noqa: E402
-    n, H, W, B, tw, th = 10_000_000, 480, 640, 5, 5, 4
+    n, H, W, B, tw, th = 10_000_000, 480, 640, 5, 4, 4
     rng = np.random.default_rng(1)
     x = rng.integers(0, W, n).astype(np.float32); y = rng.integers(0, H, n).astype(np.float32)
     t = np.sort(rng.uniform(0.0, 0.1, n)).astype(np.float32); p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
