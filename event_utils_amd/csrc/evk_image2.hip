@@ -202,8 +202,10 @@ __device__ __forceinline__ bool img_last_part(uint32_t *index, int ntiles, const
 // pos + 1 (unconditionally: `pos` is always inside the record buffer); use(L, pos, end) accumulates them.  The loads of
 // the next round are in flight while a round is accumulated.
 #define IMG_CAP 448   // chunk descriptors per wave
+// (round 6: entry [IMG_CAP] of every list is a ZERO entry -- a lane group without a chunk reads it: one v_min and an
+// unconditional LDS read instead of a compare, two zero moves and an exec-masked read per list access, as in k_voxel_tiles2)
 template <int WG, int U, typename L, typename LoadF, typename UseF>
-__device__ __forceinline__ void img_records(const uint32_t *table, const Part2 &q, const ImgItem &it, uint2 (*cseg)[IMG_CAP],
+__device__ __forceinline__ void img_records(const uint32_t *table, const Part2 &q, const ImgItem &it, uint2 (*cseg)[IMG_CAP + 1],
                                             LoadF load, UseF use) {
     constexpr int NW = WG / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane * NW + wave, sub = lane & 3, grp = lane >> 2;
@@ -221,8 +223,9 @@ __device__ __forceinline__ void img_records(const uint32_t *table, const Part2 &
         auto meta = [&](uint32_t j0, uint2(&cs)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t j = j0 + 16u * u + grp;
-                cs[u] = j < total ? cseg[wave][j] : make_uint2(0u, 0u);
+                uint32_t j = j0 + 16u * u + grp;
+                j = j < total ? j : (uint32_t)IMG_CAP;
+                cs[u] = cseg[wave][j];
             }
         };
         auto fire = [&](const uint2(&cs)[U], L(&v)[U]) {
@@ -254,6 +257,7 @@ __device__ __forceinline__ void img_records(const uint32_t *table, const Part2 &
         }
     };
     auto entry = [&](int my) -> uint32_t { return my < it.sc_hi ? col[(int64_t)my * q.nt_pad] : 0u; };
+    if (threadIdx.x < NW) cseg[threadIdx.x][IMG_CAP] = make_uint2(0u, 0u);   // (ordered before the first rounds by the first batch's barrier)
     uint32_t ent_next = entry(it.sc_lo + slot);
     for (int base = it.sc_lo; base < it.sc_hi; base += WG) {
         const uint32_t ent = ent_next;
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(WG) k_image_tiles_n(const uint32_t *__restrict
                                                       void *__restrict__ staging_) {
     __shared__ int cnt32[EVK_GRIDG_MAX_CELLS];
     __shared__ acc_t acc64[INT ? 1 : EVK_GRIDG_MAX_CELLS];
-    __shared__ uint2 cseg[WG / 64][IMG_CAP];
+    __shared__ uint2 cseg[WG / 64][IMG_CAP + 1];
     const int ntiles = g.tiles_x * g.tiles_y;
     ImgItem it;
     if (!img_item(index, ntiles, q, flags, it)) return;
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
                                                       TileGridG g, Part2 q, int flags, float *__restrict__ img,
                                                       float *__restrict__ staging) {
     __shared__ acc_t win[IMG_WIN_MAX];   // float64, or int64 multiples of 2^-30 (unit weights)
-    __shared__ uint2 cseg[WG / 64][IMG_CAP];
+    __shared__ uint2 cseg[WG / 64][IMG_CAP + 1];
     const int ntiles = g.tiles_x * g.tiles_y;
     ImgItem it;
     if (!img_item(index, ntiles, q, flags, it)) return;
