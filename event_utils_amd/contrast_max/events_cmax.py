@@ -217,9 +217,18 @@ def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3,
         return [float(v) for v in objective.evaluate_function_batch([np.array(q, dtype=np.float64) for q in points], *args)]
     # an objective that can bind itself to these events (variance_objective.bind_fast) evaluates through closures that resolve
     # everything but the flow once: same library calls, same numbers, ~20 us less host work between two passes
-    bound = objective.bind_fast(*args) if (fast and n == 2 and not numeric_grads and hasattr(objective, "bind_fast")) else None
-    if bound is not None:
+    bound = objective.bind_fast(*args) if (fast and n == 2 and hasattr(objective, "bind_fast")) else None
+    if bound is not None and not numeric_grads:
         fg, f3 = bound
+    elif bound is not None:
+        # numeric gradients (the reference's default: forward differences with epsilon = 1, events_cmax.py:343): f(x), f(x + e1),
+        # f(x + e2) are ONE three-flow pass -- evaluate_function_and_numeric_gradient's arithmetic on the bound closure
+        f3 = bound[1]
+
+        def fg(q):
+            pts = [list(q), [q[0] + 1.0, q[1]], [q[0], q[1] + 1.0]]
+            fs = f3(pts)
+            return fs[0], [(fs[1] - fs[0]) / (pts[1][0] - q[0]), (fs[2] - fs[0]) / (pts[2][1] - q[1])]
 
     def identity():
         return [[1.0 if i == j else 0.0 for j in rng] for i in rng]

@@ -12,6 +12,7 @@ Extensions (all default to the reference's behaviour):
   objective.process_group / objective.distributed  event-sharded data parallelism: each rank accumulates its shard,
                           IWE (+dIWE) are all-reduced over RCCL before blur / reductions.
 """
+import weakref
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -229,6 +230,18 @@ class objective_function(ABC):
         finishes -- no allocation per evaluation, and every rank holds the same scalars."""
         if not uses_fused_linvel(warpfunc):
             return None
+        # (round 6) the SAME evaluation as the last one but for the flow -- a scipy line search, a sampler, bench.py's loops: the
+        # resolved call is repeated directly (tiled.cmax_variance_again checks that its buffers are still the current ones)
+        memo, memo_key = self.__dict__.get("_fast_memo"), None
+        if isinstance(xs, DeviceEvents) and not self.adaptive_lifespan and not (self.distributed or self.process_group is not None) \
+                and not getattr(self, "enqueue_only", False):
+            memo_key = (id(xs), grad, post_flags, blur_sigma, float(img_size[0]), float(img_size[1]), self.impl, self.use_polarity,
+                        self.sensor_size, self.t_ref, tiled.FORCE["iwe_fixed"], tiled.FORCE["iwe_records"], tiled.default_impl(),
+                        xs.p_scale)
+            if memo is not None and memo[0] == memo_key and memo[1]() is xs:
+                r = tiled.cmax_variance_again(memo[2], float(params[0]), float(params[1]))
+                if r is not None:
+                    return r.copy()
         ev = self._lifespan_cut(_as_device_events(xs, ys, ts, ps))
         sharded = self.distributed or self.process_group is not None
         if len(ev) == 0 and not sharded:
@@ -249,6 +262,9 @@ class objective_function(ABC):
             ok = tiled.cmax_variance(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
                                      float(img_size[0]), ch, cw, flags, w, radius, post_flags, buf, out, scratch, nbytes,
                                      impl=self.impl, host_out=None if getattr(self, "enqueue_only", False) else res)
+            if ok and memo_key is not None:
+                c = tiled.cmax_variance_entry(ev, post_flags, True, self)
+                self.__dict__["_fast_memo"] = (memo_key, weakref.ref(ev), c) if c is not None else None
             return res.copy() if ok else None
         from .. import distributed as DD
         img = buf[:planes * ch * cw * 4].view(torch.float32).view(planes, ch, cw)

@@ -759,7 +759,8 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
     cache[ckey] = {"fn": fn, "args": args, "buf": buf, "out": out, "scratch": scratch, "weights": weights,
                    "host_out": host_out, "staging": plan["staging"], "staging_bytes": plan["staging_bytes"],
                    "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6], planes),
-                   "spill": sp_state, "tile": (head[5], head[6]), "planes": planes, "skey_head": (plan["buckets"].ntiles, plan["buckets"].n),
+                   "spill": sp_state, "spill_key": (planes, ch, cw), "tile": (head[5], head[6]), "planes": planes,
+                   "skey_head": (plan["buckets"].ntiles, plan["buckets"].n),
                    "i_staging": len(head) + 3, "ckey": ckey,
                    "i_parity": len(args) - 3, "keep": (plan, spill)}
     ev.__dict__["_cmax_last_single"] = cache[ckey]
@@ -814,7 +815,7 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
                    "win": (head[7], head[8], head[9]), "geo": (abs(head[10] - head[11]), head[5], head[6]),
                    "spill": st, "i_parity": len(args) - 3, "vx": plan["keep"][0], "vy": plan["keep"][1], "keep": (plan, spill),
                    "tile": (head[5], head[6]), "planes": 3, "skey_head": (plan["buckets"].ntiles, plan["buckets"].n),
-                   "i_staging": len(head) + 2, "host_res": host_out, "ckey": ckey}
+                   "spill_key": (3, ch, cw), "i_staging": len(head) + 2, "host_res": host_out, "ckey": ckey}
     ev.__dict__["_cmax_last_b3"] = cache[ckey]
     return True
 
@@ -831,6 +832,22 @@ def cmax_variance_entry(ev, post_flags, single, obj):
     return c if c.get("host_res") is not None else None
 
 
+def _entry_valid(c):
+    """The persistent buffers a cached call was marshalled with are still the ones the layer would hand out now: the image buffer
+    (grow-only: a larger image in between replaces it), the spill pair (release_scratch, a failed call) and the reduction
+    scratch of the current stream."""
+    buf = c["buf"]
+    dev = buf.device
+    sid = D.stream_id(dev)
+    if _persist.get(("iwe_buf", dev.index, sid)) is not buf:
+        return False
+    sc = D._scratch.get((dev.index, sid, "reduce"))
+    if sc is None or sc[0] is not c["scratch"]:
+        return False
+    st = c["spill"]
+    return st is None or _spill.get((dev.index, sid) + c["spill_key"]) is st
+
+
 def _again(c, name):
     args, st = c["args"], c["spill"]
     if st is not None:
@@ -843,7 +860,7 @@ def cmax_variance_again(c, vx, vy):
     """Repeat the cached evaluation `c` at another flow -> its host result array (4 doubles, filled when the call returns), or
     None when the tiled kernels cannot take this flow or the persistent buffers have been replaced."""
     import math
-    if not (math.isfinite(vx) and math.isfinite(vy)):
+    if not (math.isfinite(vx) and math.isfinite(vy)) or not _entry_valid(c):
         return None
     span, tw, th, planes = c["geo"]
     Dx, Dy = abs(vx) * span, abs(vy) * span
@@ -860,7 +877,7 @@ def cmax_variance_again(c, vx, vy):
 def cmax_variance_batch3_again(c, vxs, vys):
     """The same for the three-flow call -> its host result array (12 doubles)."""
     import math
-    if not all(math.isfinite(v) for v in vxs + vys):
+    if not all(math.isfinite(v) for v in vxs + vys) or not _entry_valid(c):
         return None
     span, tw, th = c["geo"]
     Dx, Dy = max(abs(v) for v in vxs) * span, max(abs(v) for v in vys) * span

@@ -336,3 +336,23 @@ def test_bound_evaluators_and_retargeted_calls_give_the_public_methods_numbers()
     for (xa, fa, ga), (xb, fb, gb) in zip(runs[True][1], runs[False][1]):
         assert np.array_equal(xa, xb) and fa == fb and np.array_equal(ga, gb)
     assert np.linalg.norm(runs[True][0] - np.array([40.0, -25.0])) < 3.0
+
+
+def test_evk_bfgs_numeric_gradients_follow_the_same_trajectory_bound_or_not():
+    """numeric_grads=True (the reference's default) through the bound three-flow closure: the forward differences of
+    evaluate_function_and_numeric_gradient, same arithmetic -- identical accepted points with and without the binding."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import evk_bfgs
+    n, H, W = 300_000, 240, 320
+    x, y, t, p = bench.structured_scene(8, n, H, W)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    args = (ev, None, None, None, E.linvel_warp(), (H, W), 1.0)
+    runs = {}
+    for use_fast in (True, False):
+        o, tr = E.variance_objective(), []
+        o.sensor_size = (H, W)
+        runs[use_fast] = (evk_bfgs(o, np.array([0.0, 0.0]), args, numeric_grads=True, trace=tr, fast=use_fast), tr)
+    assert np.array_equal(runs[True][0], runs[False][0]) and len(runs[True][1]) == len(runs[False][1]) >= 3
+    for (xa, fa, ga), (xb, fb, gb) in zip(runs[True][1], runs[False][1]):
+        assert np.array_equal(xa, xb) and fa == fb and np.array_equal(ga, gb)
