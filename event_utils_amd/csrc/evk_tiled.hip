@@ -1305,8 +1305,12 @@ static int bucket_events(const C &c, int64_t n, int key_mode, int dom_h, int dom
             return launch_status();
         }
     }
-    if (try_compact) return EVK_EINVAL;   // (only the sorting scatter writes compact records: the caller asked for what this tiling cannot give)
-    if (stages & EVK_STAGE_STATS) k_set_word<<<1, 1, 0, s>>>(stats + 1, 0xFFFFFFFFu);   // max |p| is NOT delivered by the ring scatter
+    // (only the sorting scatter writes compact records and max |p|: on a tiling it cannot take -- counters that do not fit beside
+    // the sort buffer -- the ring scatter writes 16-byte records and the index says so: verdict 1, max |p| unknown)
+    if (stages & EVK_STAGE_STATS) {
+        if (try_compact) k_set_word<<<1, 1, 0, s>>>(stats, 1u);
+        k_set_word<<<1, 1, 0, s>>>(stats + 1, 0xFFFFFFFFu);
+    }
     // write-combining scatter when the per-tile LDS rings fit (160 KiB per CU), else the plain scatter
     // all partition blocks co-resident, one per CU.  With EVK_STAGE_SHARE_CU the rings take at most 96 KB so that a
     // workgroup of ANOTHER kernel (an overlapped RCCL collective) still fits on every CU: a scatter workgroup that

@@ -267,7 +267,7 @@ int evk_bucket_max_items(int ntiles, int64_t n);
  * (evk_compact_records_f32) and a reduction over p for.  EVK_STAGE_COMPACT (with STATS, IWE key,
  * tiles of <= 1024 pixels): when that verdict is 0 the scatter writes the COMPACT records (see evk_compact_records_f32:
  * same records, same order) into the first 8 n bytes of `records` instead of the 16-byte ones -- the caller learns which
- * from index[len - 2].  EVK_STAGE_LEGACY_SCATTER: the write-combining ring scatter of rounds 1-5 instead of the LDS-sorting
+ * from index[len - 2] (also 1 when the tiling forces the ring scatter, which writes 16-byte records only).  EVK_STAGE_LEGACY_SCATTER: the write-combining ring scatter of rounds 1-5 instead of the LDS-sorting
  * one (A/B, tests; both produce identical records). */
 #define EVK_STAGE_STATS 16
 #define EVK_STAGE_COMPACT 32

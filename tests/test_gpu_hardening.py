@@ -246,6 +246,10 @@ def test_lds_sorting_scatter_equals_the_ring_scatter(case, monkeypatch):
         assert int(sa[-1]) == n - len(x[::1000])
     if case.startswith("ring"):
         assert b.p_absmax is None                      # the ring scatter does not deliver max |p|: the caller reduces the column
+        monkeypatch.setitem(tiled.FORCE, "legacy_scatter", False)
+        xi = [torch.floor(cols[0]), torch.floor(cols[1]), cols[2], cols[3]]     # compactable events on a tiling the sorting scatter
+        c = tiled.bucket_events(*xi, key_mode, dom_h, dom_w, tw, th, stats=True, compact=True).settle()   # cannot take:
+        assert c.iwe_flag == 0 and c.records.dtype == torch.float32             # 16-byte records, and the index says so
     else:
         assert b.p_absmax == 1.0 and b.structured == a.structured
 
