@@ -916,14 +916,17 @@ def bench_cmax(E, DeviceEvents, dev, impl):
 
 def bench_evk_bfgs(E, DeviceEvents, impl):
     """optimize_contrast(..., optimizer='evk_bfgs') with the consistent analytic gradient on the moving-edge scene at configs[2]
-    size (10 M events, 640x480) and configs[3] size (50 M, 1280x720): `warm_seconds` = best of 3 on a DeviceEvents whose events
-    are already bucketed (what rounds 4-5 reported), `cold_seconds` = median of 3 runs each on a FRESH DeviceEvents over the
+    size (10 M events, 640x480), configs[3] size (50 M, 1280x720) and on a 1 M-event window: `warm_seconds` = best of 3 on a
+    DeviceEvents whose events are already bucketed (what rounds 4-5 reported; `warm_seconds_python_loop`: the same iteration
+    driven from Python, rounds 4-6's form), `cold_seconds` = median of 3 runs each on a FRESH DeviceEvents over the
     same device columns (bucketing, record compaction and every first-use allocation inside the timed region)."""
     import warnings
     from event_utils_amd.contrast_max.events_cmax import optimize_contrast
     res = {}
     w = E.linvel_warp()
-    for tag, (n, Hs, Ws) in (("c3_10M_640x480", (N_PER_GPU, H, W)), ("c4_50M_1280x720", (50_000_000, 720, 1280))):
+    from event_utils_amd import tiled
+    for tag, (n, Hs, Ws) in (("c3_10M_640x480", (N_PER_GPU, H, W)), ("c4_50M_1280x720", (50_000_000, 720, 1280)),
+                             ("window_1M_640x480", (1_000_000, H, W))):
         x, y, t, p = structured_scene(3, n, Hs, Ws)
         ev = DeviceEvents.from_arrays(x, y, t, p, precision="f32")
 
@@ -937,16 +940,26 @@ def bench_evk_bfgs(E, DeviceEvents, impl):
                 a = optimize_contrast(e, None, None, None, w, o, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0,
                                       img_size=(Hs, Ws))
             torch.cuda.synchronize()
+            passes[0] = getattr(o, "native_passes", None)
             return time.perf_counter() - t0, np.asarray(a, dtype=float)
+        passes = [None]
         run(ev)                                   # first use of every buffer / code object
         warm = min(run(ev)[0] for _ in range(3))
+        tiled.FORCE["native_bfgs"] = False        # A/B: the same iteration as a Python loop over the bound evaluation calls
+        try:
+            run(ev)
+            warm_py = min(run(ev)[0] for _ in range(3))
+        finally:
+            tiled.FORCE["native_bfgs"] = True
         cold, arg = [], None
         for _ in range(3):
             fresh = DeviceEvents(ev.x, ev.y, ev.t, ev.p, t_host=ev._t_host)
             dt, arg = run(fresh)
             cold.append(dt)
             del fresh
-        res[tag] = {"warm_seconds": round(warm, 5), "cold_seconds": round(float(np.median(cold)), 5),
+        res[tag] = {"loop": "inside the library (evk_cmax_bfgs_variance_tiled_f32)", "warm_seconds": round(warm, 5),
+                    "event_passes": passes[0],
+                    "warm_seconds_python_loop": round(warm_py, 5), "cold_seconds": round(float(np.median(cold)), 5),
                     "cold_runs": [round(v, 5) for v in cold], "cold_minus_warm_ms": round((float(np.median(cold)) - warm) * 1e3, 3),
                     "argmax_cold": [round(float(v), 3) for v in arg], "true_flow": [40.0, -25.0]}
         del ev

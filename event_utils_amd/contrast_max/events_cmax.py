@@ -173,7 +173,7 @@ def segmentation_mask_from_d_iwe(d_iwe, th=None):
 
 
 def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3, gtol=1e-5, ftol=1e-6, maxiter=100, trace=None,
-             unit_first=True, fast=True):
+             unit_first=True, fast=True, native=None):
     """
     BFGS with a line search made for this objective: every quantity it asks for is ONE pass over the resident events and it
     asks for as few as it can.  scipy's fmin_bfgs (the reference's optimiser, events_cmax.py:343-345) runs a strong-Wolfe
@@ -188,12 +188,32 @@ def evk_bfgs(objective, x0, args, numeric_grads=False, callback=None, xtol=1e-3,
     `ftol` of its value (the images are float32: relative differences below ~3e-7 are summation-order noise, and a search
     that keeps following them never ends), or no candidate improves it at all.
     Returns the minimiser (numpy float64).  trace: optional list that receives (x, f, g) of every accepted point.
+    fast / native: plumbing only (identical points either way) -- fast evaluates through closures bound to these events
+    (objective.bind_fast), native runs the whole loop inside the library when the objective offers that (bind_native).
     """
     # (round 6) The iteration's own arithmetic is a handful of operations on dims-vectors (dims = 2 for the linear flow): as
     # numpy calls -- norm, dot, outer, eye, a dozen temporaries per iteration -- they cost ~25 us per event pass, a sixth of a
     # pass at 10 M events and a third at 1 M (tools/bfgs_profile.py).  Plain Python floats, same operations in the same order.
     n = len(x0)
     x = [float(v) for v in x0]
+    # (round 6) an objective that can run this very loop inside the library (variance_objective.bind_native:
+    # evk_cmax_bfgs_variance_tiled_f32, same passes, same arithmetic in C) does so: ~15 us less between two passes.  A callback
+    # other than the objective's own iter_update may want to see every step as it happens: Python loop.
+    if native is None:
+        from .. import tiled
+        native = tiled.FORCE["native_bfgs"]                # (A/B switch of the tools)
+    if native and fast and n == 2 and hasattr(objective, "bind_native") and \
+            (callback is None or getattr(callback, "__self__", None) is objective):
+        run = objective.bind_native(*args)
+        done = run(x, xtol, gtol, ftol, maxiter, numeric_grads, unit_first) if run is not None else None
+        if done is not None:
+            xf, points = done
+            for k, (q, fv, gv) in enumerate(points):
+                if trace is not None:
+                    trace.append((q, fv, gv))
+                if callback is not None and k > 0:
+                    callback(q.copy())
+            return xf
     fg_fn = objective.evaluate_function_and_numeric_gradient if numeric_grads else objective.evaluate_function_and_gradient
     rng = range(n)
 

@@ -417,6 +417,42 @@ class variance_objective(objective_function):
         cfg, cf3 = [None], [None]
         return fg, f3
 
+    def bind_native(self, xs, ys, ts, ps, warpfunc, img_size, blur_sigma):
+        """run(x0, xtol, gtol, ftol, maxiter, numeric_grads, unit_first) -> (x, [(x, f, g), ...]) | None: events_cmax.evk_bfgs on
+        THIS objective and THESE events as ONE library call (tiled.cmax_bfgs; include/evk.h:
+        evk_cmax_bfgs_variance_tiled_f32) -- the same passes at the same flows, the iteration's arithmetic in C.  None (from
+        here, or from run) when the one-call path does not apply: the same conditions as bind_fast, or a trial flow the tiled
+        kernels cannot take; the caller then runs its Python loop."""
+        if (not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None or self.adaptive_lifespan
+                or getattr(self, "enqueue_only", False)):
+            return None
+        ev = _as_device_events(xs, ys, ts, ps)
+        if len(ev) == 0:
+            return None
+        blur = self.default_blur if blur_sigma is None else blur_sigma
+        post = _lib.EVK_POST_MIX if self.reference_exact else _lib.EVK_POST_BLUR_IWE
+        dev = ev.device
+        ss = (180, 240) if self.sensor_size is None else self.sensor_size
+        ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
+        flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        w, radius = _blur_kernel(blur)
+
+        def run(x0, xtol, gtol, ftol, maxiter, numeric_grads, unit_first):
+            buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
+            scratch, nbytes = D.reduce_scratch(dev)
+            cap = int(maxiter) + 1
+            res = tiled.cmax_bfgs(ev, float(t_ref), [float(x0[0]), float(x0[1])], float(img_size[1]), float(img_size[0]), ch, cw,
+                                  flags, w, radius, post, buf, D.out4(dev, 12), scratch, nbytes,
+                                  [xtol, gtol, ftol, maxiter, 1.0 if numeric_grads else 0.0, 1.0 if unit_first else 0.0], cap,
+                                  impl=self.impl)
+            if res is None or res[5] != 0.0:
+                return None
+            self.native_passes = int(res[4])
+            rows = res[6:6 + 5 * min(int(res[3]), cap)].reshape(-1, 5)
+            return res[:2].copy(), [(r[:2].copy(), float(r[2]), r[3:5].copy()) for r in rows]
+        return run
+
     def evaluate_numeric_gradient(self, params=None, xs=None, ys=None, ts=None, ps=None, warpfunc=None, img_size=None,
                                   blur_sigma=None, epsilon=1.0, with_value=False):
         """Forward-difference gradient of evaluate_function with absolute step `epsilon` -- exactly what

@@ -29,7 +29,7 @@ def default_impl():
 #   legacy_scatter  False | True    the write-combining ring scatter of rounds 1-5 (and the separate compaction pass) instead of
 #                                   the LDS-sorting scatter (EVK_STAGE_LEGACY_SCATTER)
 FORCE = {"rec": None, "count": True, "tiles_wg": 0, "xcd_order": True, "share_cu": None, "iwe_records": "auto",
-         "iwe_fixed": True, "image_fixed": True, "live": None, "count2": True, "legacy_scatter": False}
+         "iwe_fixed": True, "image_fixed": True, "live": None, "count2": True, "legacy_scatter": False, "native_bfgs": True}
 
 
 # 'auto' thresholds, measured (profiles/r04_direct_tiled_crossover.txt, profiles/r04_small_calls.txt; tools/crossover.py,
@@ -890,6 +890,43 @@ def cmax_variance_batch3_again(c, vxs, vys):
     c["vy"][:] = vys
     _again(c, "evk_cmax_variance_batch3_tiled_f32")
     return c["host_res"]
+
+
+def cmax_bfgs(ev, t_ref, x0, bounds_w, bounds_h, ch, cw, flags, weights, radius, post_flags, buf, out12, scratch, scratch_bytes,
+              opts, trace_cap, impl=None):
+    """The whole quasi-Newton optimisation in ONE library call (evk_cmax_bfgs_variance_tiled_f32: events_cmax.evk_bfgs with
+    its arithmetic, window planning and result polls in C) -> numpy float64 [x0, x1, f, accepted points, event passes,
+    status, then (x0, x1, f, g0, g1) per accepted point], or None when the tiled plan does not apply to these events.
+    flags: EVK_IWE_ABS_POLARITY or 0; opts: [xtol, gtol, ftol, maxiter, numeric_grads, unit_first].  The loop may use two time
+    slices of the largest LDS window (flows up to 2 x (48 - tile - 4) px of displacement over the stream); a trial flow
+    beyond that ends it with status 1 and the caller runs its own loop."""
+    import numpy as np
+    G = _lib.EVK_IWE_GRADIENT
+    plan = iwe_plan(ev, t_ref, float(x0[0]), float(x0[1]), bounds_w, bounds_h, ch, cw, (flags & ~G) | G, impl)
+    if plan is None:
+        return None
+    head, bk = plan["head"], plan["buckets"]
+    cap = max(int(plan["staging_bytes"]),
+              int(_lib.lib().evk_iwe_tiled_staging_bytes(bk.ntiles, bk.n, 2, 3, _WIN_MAX[3], _WIN_MAX[3])))
+    staging = _buf("iwe_staging", cap, ev.device)
+    st = _spill_pair(ev.device, 3, ch, cw)
+    parity = np.array([st[1]], dtype=np.int32)
+    x0a = np.ascontiguousarray(x0, dtype=np.float64)
+    optsa = np.ascontiguousarray(opts, dtype=np.float64)
+    res = np.zeros(6 + 5 * trace_cap, dtype=np.float64)
+    try:
+        _lib.call("evk_cmax_bfgs_variance_tiled_f32", head[0], head[1], head[2], head[3], head[4], head[5], head[6], head[10],
+                  head[11], head[14], head[15], head[16], head[17], head[18] & ~G, head[19], head[20], head[21],
+                  D.host_ptr(weights) if weights is not None else None, radius, post_flags, D.ptr(staging), staging.numel(),
+                  D.ptr(buf), D.ptr(out12), D.ptr(scratch), scratch_bytes, D.ptr(st[0]), D.host_ptr(parity), D.host_ptr(x0a),
+                  D.host_ptr(optsa), D.host_ptr(res), trace_cap, D.stream())
+    except BaseException:
+        # (as _spill_call: a pass that failed half-way leaves the pair in an unknown state)
+        st[0].zero_()
+        st[1] = 0
+        raise
+    st[1] = int(parity[0]) & 1
+    return res
 
 
 WARM_MS = 40.0

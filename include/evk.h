@@ -529,6 +529,31 @@ int evk_cmax_variance_batch3_tiled_f32(const float *records, const uint32_t *buc
                                        int64_t scratch_bytes, float *spill_pair, int parity, double *host_out,
                                        void *stream);
 
+/* ---- the whole optimisation in one call (round 6; evk_optim.hip) -------------------------------------------------
+ * optimize_contrast for the linear-flow warp and the variance objective (events_cmax.py:313-346, where scipy's fmin_bfgs
+ * drives one Python callback per evaluation): the quasi-Newton iteration of event_utils_amd.contrast_max.evk_bfgs with its
+ * arithmetic, the LDS window of every pass and the result poll inside the library.  Every pass is one
+ * evk_cmax_variance_tiled_f32 (value + gradient at one flow; EVK_POST_VALUE is added to post_flags) or one
+ * evk_cmax_variance_batch3_tiled_f32 (three step lengths of the line search); the arguments up to `spill_pair` mean what
+ * they mean there (iwe_flags WITHOUT EVK_IWE_GRADIENT; iwe_buf: 3 planes; out12: 12 doubles, device; spill_pair required).
+ * Time slices and window are chosen per pass from the flow; `staging_bytes` is the capacity the loop may use
+ * (evk_iwe_tiled_staging_bytes of the largest plan the caller wants it to take).
+ * parity (host, in/out): the spill parity of the LAST successful evaluation on this pair; updated.
+ * x0: 2 doubles.  opts: 6 doubles [xtol (px/s), gtol, ftol, maxiter, numeric_grads (0 | 1: forward differences with
+ * epsilon = 1 from one three-flow pass, the reference's default), unit_first (0 | 1)].
+ * result (host): 6 + 5 * trace_cap doubles: [x0, x1, f(x), accepted points, event passes, status], then one row
+ * [x0, x1, f, g0, g1] per accepted point (the first trace_cap of them).  status 0: finished (converged or maxiter);
+ * 1: a trial flow needs a plan this call cannot take (more than 64 time slices, more than 128 candidate windows, more
+ * staging than staging_bytes, a non-finite flow) -- x is the last accepted point, the caller continues with its own loop.
+ * Returns when the last pass has delivered its results (synchronous, like the evaluation calls with host_out). */
+int evk_cmax_bfgs_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                                     int tw_log2, int th_log2, double t_first, double t_ref, double bounds_w, double bounds_h,
+                                     int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale, double p_bound,
+                                     double dt_bound, const double *host_weights, int radius, uint32_t post_flags,
+                                     void *staging, int64_t staging_bytes, float *iwe_buf, double *out12, void *scratch,
+                                     int64_t scratch_bytes, float *spill_pair, int *parity, const double *x0,
+                                     const double *opts, double *result, int trace_cap, void *stream);
+
 /* Largest singular value SQUARED of a float32 (h, w) image, float64 -> out[0]: what the "rms" objective needs
  * (objectives.py:282: np.linalg.norm(iwe, 2) of a 2-D array is the spectral norm).  Lanczos on the Gram operator with full
  * re-orthogonalisation in one workgroup, then a bisection; h, w <= 4096.  scratch: evk_spectral_scratch_bytes(h, w).

@@ -360,3 +360,55 @@ def test_evk_bfgs_numeric_gradients_follow_the_same_trajectory_bound_or_not():
     assert np.array_equal(runs[True][0], runs[False][0]) and len(runs[True][1]) == len(runs[False][1]) >= 3
     for (xa, fa, ga), (xb, fb, gb) in zip(runs[True][1], runs[False][1]):
         assert np.array_equal(xa, xb) and fa == fb and np.array_equal(ga, gb)
+
+
+def test_native_bfgs_loop_visits_the_points_of_the_python_loop():
+    """Round 6: evk_cmax_bfgs_variance_tiled_f32 -- the quasi-Newton loop inside the library -- against the Python loop over the
+    bound closures (native=False) and over the public methods (fast=False): same accepted points, values and gradients bit
+    for bit, analytic and numeric gradients, reference-exact and consistent gradient; the objective's iter_update sees every
+    accepted point; a foreign callback or a start the tiled kernels cannot take keeps the Python loop."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import evk_bfgs, optimize_contrast
+    for seed, n, H, W in ((7, 400_000, 240, 320), (3, 1_000_000, 480, 640)):
+        x, y, t, p = bench.structured_scene(seed, n, H, W)
+        ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+        args = (ev, None, None, None, E.linvel_warp(), (H, W), 1.0)
+        finals = {}
+        for numeric, exact in ((False, False), (True, False), (False, True)):
+            runs = {}
+            for mode in ("native", "bound", "public"):
+                o, tr = E.variance_objective(), []
+                o.sensor_size, o.reference_exact = (H, W), exact
+                o.native_passes = None
+                xs = evk_bfgs(o, np.array([0.0, 0.0]), args, numeric_grads=numeric, trace=tr, native=mode == "native",
+                              fast=mode != "public")
+                assert (o.native_passes is not None) == (mode == "native"), mode
+                runs[mode] = (xs, tr)
+            for other in ("bound", "public"):
+                assert np.array_equal(runs["native"][0], runs[other][0]) and len(runs["native"][1]) == len(runs[other][1])
+                for (xa, fa, ga), (xb, fb, gb) in zip(runs["native"][1], runs[other][1]):
+                    assert np.array_equal(xa, xb) and fa == fb and np.array_equal(ga, gb), (seed, numeric, exact, other)
+            finals[(numeric, exact)] = runs["native"][0]
+            if not exact:
+                assert np.linalg.norm(runs["native"][0] - np.array([40.0, -25.0])) < 3.0
+        # the callback optimize_contrast hands in (the objective's own iter_update) is replayed over the accepted points
+        o = E.variance_objective()
+        o.sensor_size, o.reference_exact = (H, W), False
+        o.native_passes = None
+        a = optimize_contrast(ev, None, None, None, E.linvel_warp(), o, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0,
+                              img_size=(H, W))
+        assert o.native_passes and np.array_equal(a, finals[(False, False)])
+        assert o.lifespan == o.pixel_crossings / np.linalg.norm(a)
+        # a foreign callback sees the steps as they happen: Python loop
+        seen, o2 = [], E.variance_objective()
+        o2.sensor_size, o2.reference_exact = (H, W), False
+        o2.native_passes = None
+        a2 = evk_bfgs(o2, np.array([0.0, 0.0]), args, callback=lambda q: seen.append(q.copy()))
+        assert o2.native_passes is None and len(seen) >= 3 and np.array_equal(seen[-1], a2) and np.array_equal(a2, a)
+        # a start beyond every LDS window: the library loop declines at its first pass, the Python loop (direct kernels) runs
+        o3 = E.variance_objective()
+        o3.sensor_size, o3.reference_exact = (H, W), False
+        o3.native_passes = None
+        a3 = evk_bfgs(o3, np.array([30000.0, 0.0]), args, maxiter=2)
+        assert o3.native_passes is None and np.all(np.isfinite(a3))

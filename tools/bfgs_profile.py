@@ -15,6 +15,9 @@ import event_utils_amd as E  # noqa: E402
 from event_utils_amd.contrast_max.events_cmax import optimize_contrast  # noqa: E402
 
 n, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (10_000_000, 480, 640)
+if os.environ.get("EVK_BFGS_PYTHON_LOOP") == "1":          # A/B: the Python loop over the bound closures instead of the library's loop
+    from event_utils_amd import tiled
+    tiled.FORCE["native_bfgs"] = False
 x, y, t, p = bench.structured_scene(3, n, H, W)
 ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
 w = E.linvel_warp()
