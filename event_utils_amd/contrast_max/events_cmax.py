@@ -26,6 +26,7 @@ def _resident(xs, ys, ts, ps, warp_function, objective):
     """Upload the events once for the fused linear-flow path; plugin warps keep their host arrays."""
     if uses_fused_linvel(warp_function) and isinstance(objective, objective_function):
         ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
+        ev.many_evaluations = True          # every caller of this is a search / an optimiser: tens of evaluations of these events
         return ev, None, None, None
     return xs, ys, ts, ps
 

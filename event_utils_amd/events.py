@@ -77,6 +77,9 @@ class DeviceEvents:
         self.p_scale = 1.0             # adaptive lifespan multiplies ps by 100 (objectives.py:225), folded here
         self._buckets = {}             # cache of tile-bucketed layouts (see tiled.py)
         self._p_absmax = None
+        # hint of the optimisers (events_cmax._resident): this set will be evaluated many times, so the objective buckets it by
+        # output tile at any event count (tiled.TILED_MIN_EVENTS_IWE_REUSED) instead of only from 150 k events
+        self.many_evaluations = False
         self._t_ends = None            # (ts[0], ts[-1]) when known without touching the column
 
     def _columns(self):

@@ -46,6 +46,11 @@ TILED_MIN_EVENTS = 1
 TILED_MIN_EVENTS_NATIVE = 1
 TILED_MIN_EVENTS_NEG_POS = 1
 TILED_MIN_EVENTS_IWE = 150_000
+# ... and an event set an OPTIMISER works on (DeviceEvents.many_evaluations, set by optimize_contrast / grid_search /
+# recursive_search) is evaluated tens of times: the buckets pay at any event count (round 6: optimize_contrast with evk_bfgs on
+# 100 k events of the moving-edge scene at 240x180, 21 passes: 4.1 ms through the direct kernels -- 137-170 us per value + gradient
+# pass, their global atomics collide on the edges -- against TILED_IWE_REUSED_MS below)
+TILED_MIN_EVENTS_IWE_REUSED = 1
 # EVK_VOXEL2_LIVE (round 5) is NOT a default: at 10 M events the live call takes 0.085 ms against 0.072 ms for the two launches
 # (profiles/r05_live_ab.txt).  EVK_VOXEL_LIVE=1 requests it from this many events (fewer than ~3 sub-chunks per partition
 # workgroup leave the consumer kernel nothing to overlap; the library itself refuses calls it cannot run live)
@@ -587,10 +592,11 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     impl = impl or default_impl()
     vxs, vys = ((vx,), (vy,)) if batch is None else batch
     native = ev.native if ev._cols is None else None     # on-disk dtypes not widened yet: bucket them as they are
+    min_events = TILED_MIN_EVENTS_IWE_REUSED if ev.many_evaluations else TILED_MIN_EVENTS_IWE
     if native is not None:
-        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS_IWE)
+        tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= min_events)
     else:
-        tileable = can_tile((ev.x, ev.y, ev.t, ev.p), impl, TILED_MIN_EVENTS_IWE)
+        tileable = can_tile((ev.x, ev.y, ev.t, ev.p), impl, min_events)
     if not (tileable and all(math.isfinite(v) for v in tuple(vxs) + tuple(vys))):
         return None
     dom_h = max(int(bounds_h) + 1, ch)
