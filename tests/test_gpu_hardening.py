@@ -412,3 +412,39 @@ def test_native_bfgs_loop_visits_the_points_of_the_python_loop():
         o3.native_passes = None
         a3 = evk_bfgs(o3, np.array([30000.0, 0.0]), args, maxiter=2)
         assert o3.native_passes is None and np.all(np.isfinite(a3))
+
+
+def test_optimisers_bucket_small_event_sets():
+    """Round 6: an event set handed to optimize_contrast / grid_search is marked many_evaluations and bucketed by output tile
+    at ANY event count (the 'auto' threshold of 150 k events is sized for a single evaluation); a lone evaluation of a small
+    set keeps the direct kernels.  Both routes agree with each other to float32 accumulation noise."""
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd import tiled
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast, grid_search_optimisation
+    n, H, W = 30_000, 180, 240
+    assert n < tiled.TILED_MIN_EVENTS_IWE
+    x, y, t, p = bench.structured_scene(3, n, H, W)
+    w = E.linvel_warp()
+
+    def objective():
+        o = E.variance_objective()
+        o.sensor_size, o.reference_exact = (H, W), False
+        return o
+    lone = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    f_direct = objective().evaluate_function(np.array([40.0, -25.0]), lone, None, None, None, w, (H, W), 1.0)
+    assert not lone.many_evaluations and not lone._buckets            # one evaluation: no bucketing
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    o = objective()
+    o.native_passes = None
+    a = optimize_contrast(ev, None, None, None, w, o, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0, img_size=(H, W))
+    assert ev.many_evaluations and ev._buckets and o.native_passes     # bucketed, and the library's loop ran on the buckets
+    assert np.linalg.norm(a - np.array([40.0, -25.0])) < 1.0
+    f_tiled = objective().evaluate_function(np.array([40.0, -25.0]), ev, None, None, None, w, (H, W), 1.0)
+    assert abs(float(f_tiled) - float(f_direct)) <= 1e-5 * abs(float(f_direct))
+    # host arrays: optimize_contrast uploads them once and marks its own DeviceEvents; scipy's default optimiser
+    a2 = optimize_contrast(x, y, t, p, w, objective(), numeric_grads=False, blur_sigma=1.0, img_size=(H, W))
+    assert np.linalg.norm(a2 - np.array([40.0, -25.0])) < 1.0
+    ev3 = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    grid_search_optimisation(ev3, None, None, None, w, objective(), (H, W), param_ranges=[[-60, 60], [-60, 60]], num_samples_per_param=5)
+    assert ev3.many_evaluations and ev3._buckets
