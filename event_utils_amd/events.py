@@ -78,8 +78,10 @@ class DeviceEvents:
         self._buckets = {}             # cache of tile-bucketed layouts (see tiled.py)
         self._p_absmax = None
         # hint of the optimisers (events_cmax._resident): this set will be evaluated many times, so the objective buckets it by
-        # output tile at any event count (tiled.TILED_MIN_EVENTS_IWE_REUSED) instead of only from 150 k events
+        # output tile at any event count (tiled.TILED_MIN_EVENTS_IWE_REUSED) instead of only from 150 k events.  Without the hint
+        # the first evaluation of a small set takes the direct kernels and the second one buckets it
         self.many_evaluations = False
+        self._iwe_plans = 0            # evaluations planned on this set so far (the second one buckets it too)
         self._t_ends = None            # (ts[0], ts[-1]) when known without touching the column
 
     def _columns(self):

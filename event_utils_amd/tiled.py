@@ -47,7 +47,7 @@ TILED_MIN_EVENTS_NATIVE = 1
 TILED_MIN_EVENTS_NEG_POS = 1
 TILED_MIN_EVENTS_IWE = 150_000
 # ... and an event set an OPTIMISER works on (DeviceEvents.many_evaluations, set by optimize_contrast / grid_search /
-# recursive_search) is evaluated tens of times: the buckets pay at any event count (round 6: optimize_contrast with evk_bfgs on
+# recursive_search), or any DeviceEvents that is evaluated a second time, is evaluated tens of times: the buckets pay at any event count (round 6: optimize_contrast with evk_bfgs on
 # 100 k events of the moving-edge scene at 240x180, 21 passes: 4.1 ms through the direct kernels -- 137-170 us per value + gradient
 # pass, their global atomics collide on the edges -- against TILED_IWE_REUSED_MS below)
 TILED_MIN_EVENTS_IWE_REUSED = 1
@@ -592,7 +592,10 @@ def iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl=None, ba
     impl = impl or default_impl()
     vxs, vys = ((vx,), (vy,)) if batch is None else batch
     native = ev.native if ev._cols is None else None     # on-disk dtypes not widened yet: bucket them as they are
-    min_events = TILED_MIN_EVENTS_IWE_REUSED if ev.many_evaluations else TILED_MIN_EVENTS_IWE
+    # (the SECOND evaluation of the same DeviceEvents is evidence enough: a loop of the caller's own, scipy driven by hand.
+    # One count per evaluation: a fused call that declines takes its count back, its direct route plans again)
+    ev._iwe_plans += 1
+    min_events = TILED_MIN_EVENTS_IWE_REUSED if (ev.many_evaluations or ev._iwe_plans > 1) else TILED_MIN_EVENTS_IWE
     if native is not None:
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= min_events)
     else:
@@ -751,6 +754,7 @@ def cmax_variance(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, weights,
             return True
     plan = iwe_plan(ev, t_ref, vx, vy, bounds_w, bounds_h, ch, cw, flags, impl)
     if plan is None:
+        ev._iwe_plans -= 1                # (the caller's direct-kernel route plans the SAME evaluation again: iwe_linvel)
         return False
     planes = 3 if flags & _lib.EVK_IWE_GRADIENT else 1
     sp_state = _spill_pair(buf.device, planes, ch, cw)
@@ -807,6 +811,7 @@ def cmax_variance_batch3(ev, t_ref, vxs, vys, bounds_w, bounds_h, ch, cw, flags,
             return True
     plan = iwe_plan(ev, t_ref, None, None, bounds_w, bounds_h, ch, cw, flags, impl, batch=(vxs, vys))
     if plan is None:
+        ev._iwe_plans -= 1                # (as cmax_variance: the flows are then evaluated one by one)
         return False
     st = _spill_pair(buf.device, 3, ch, cw)
     spill, parity = (st[0], st[1] ^ 1) if st is not None else (None, 0)
@@ -910,6 +915,7 @@ def cmax_bfgs(ev, t_ref, x0, bounds_w, bounds_h, ch, cw, flags, weights, radius,
     G = _lib.EVK_IWE_GRADIENT
     plan = iwe_plan(ev, t_ref, float(x0[0]), float(x0[1]), bounds_w, bounds_h, ch, cw, (flags & ~G) | G, impl)
     if plan is None:
+        ev._iwe_plans -= 1                # (the caller's own loop evaluates the same start again)
         return None
     head, bk = plan["head"], plan["buckets"]
     cap = max(int(plan["staging_bytes"]),

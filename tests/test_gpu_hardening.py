@@ -434,6 +434,8 @@ def test_optimisers_bucket_small_event_sets():
     lone = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
     f_direct = objective().evaluate_function(np.array([40.0, -25.0]), lone, None, None, None, w, (H, W), 1.0)
     assert not lone.many_evaluations and not lone._buckets            # one evaluation: no bucketing
+    f_again = objective().evaluate_function(np.array([40.0, -25.0]), lone, None, None, None, w, (H, W), 1.0)
+    assert lone._buckets and abs(float(f_again) - float(f_direct)) <= 1e-5 * abs(float(f_direct))   # evaluated again: bucketed
     ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
     o = objective()
     o.native_passes = None
