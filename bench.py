@@ -387,6 +387,10 @@ def main():
             result["prebucketed"] = {"error": repr(e)}
         result["native_dtypes"] = bench_native(DeviceEvents, _voxel_f32_device, x, y, t, p, B, H, W, impl,
                                                max(5, args.steps))
+        try:
+            result["from_host_arrays"] = bench_from_host(E, x, y, t, p, B, H, W)
+        except Exception as e:  # noqa: BLE001
+            result["from_host_arrays"] = {"error": repr(e)}
         for key, fn in (("voxel_structured", bench_structured), ("image_10m", bench_image_10m), ("image_c1", bench_image_c1)):
             try:
                 result[key] = fn(E, tiled, dev, impl)
@@ -912,6 +916,30 @@ def bench_cmax(E, DeviceEvents, dev, impl):
     except Exception as e:  # noqa: BLE001
         out["evk_bfgs"] = {"error": repr(e)}
     return out
+
+
+def bench_from_host(E, x, y, t, p, B, H, W):
+    """The PCIe-inclusive rate of the headline call (never `value`): events_to_voxel_torch on HOST tensors -- what a caller
+    who keeps the reference's CPU tensors pays -- 160 MB of columns up, the 6 MB grid back, per call; pageable memory (what
+    torch.from_numpy gives) and pinned memory.  Median of 5 calls after 2 warm-up calls."""
+    res = {"workload": "configs[1] columns as CPU float32 tensors in, CPU grid out (160 MB up + 6.1 MB down per call)"}
+    cols = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in (x, y, t, p)]
+    for kind in ("pageable", "pinned"):
+        c = cols if kind == "pageable" else [a.pin_memory() for a in cols]
+        ts = []
+        for k in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g = E.events_to_voxel_torch(c[0], c[1], c[2], c[3], B, sensor_size=(H, W))
+            torch.cuda.synchronize()
+            if k >= 2:
+                ts.append(time.perf_counter() - t0)
+        assert g.device.type == "cpu"
+        ms = float(np.median(ts)) * 1e3
+        res[kind] = {"ms_per_call": round(ms, 3), "Mevents_per_s": round(len(x) / ms / 1e3, 1),
+                     "host_link_GB_per_s": round((16.0 * len(x) + 4.0 * B * H * W) / ms / 1e6, 1)}
+        del c
+    return res
 
 
 def bench_evk_bfgs(E, DeviceEvents, impl):
