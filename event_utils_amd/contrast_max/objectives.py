@@ -373,6 +373,14 @@ class variance_objective(objective_function):
                                               out12, scratch, nbytes, impl=self.impl, host_out=host_out)
         return ev, float(t_ref), launch
 
+    def _evaluators_overridden(self):
+        """A subclass that redefines an evaluating method (a plugin objective derived from this one) must be evaluated through
+        its own methods: the bound short cuts below call the library for THIS class's arithmetic."""
+        cls = type(self)
+        return any(getattr(cls, m, None) is not getattr(variance_objective, m)
+                   for m in ("evaluate_function", "evaluate_gradient", "evaluate_function_and_gradient", "evaluate_function_batch",
+                             "evaluate_numeric_gradient", "evaluate_function_and_numeric_gradient", "_one_call", "_batch3_setup"))
+
     def bind_fast(self, xs, ys, ts, ps, warpfunc, img_size, blur_sigma):
         """(fg, f3) closures for a loop that evaluates THIS objective on THESE events many times (events_cmax.evk_bfgs):
         fg(q) -> (f, [g0, g1]) = evaluate_function_and_gradient, f3([q0, q1, q2]) -> [f0, f1, f2] = evaluate_function_batch,
@@ -382,7 +390,7 @@ class variance_objective(objective_function):
         (tools/bfgs_timeline.sh), a third of a pass at 10 M events.  None when the one-call path does not apply (plugin warp,
         sharded run, adaptive lifespan, direct-kernel regime): the caller then uses the public methods."""
         if (not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None or self.adaptive_lifespan
-                or getattr(self, "enqueue_only", False)):
+                or getattr(self, "enqueue_only", False) or self._evaluators_overridden()):
             return None
         ev = _as_device_events(xs, ys, ts, ps)
         if len(ev) == 0:
@@ -424,7 +432,7 @@ class variance_objective(objective_function):
         here, or from run) when the one-call path does not apply: the same conditions as bind_fast, or a trial flow the tiled
         kernels cannot take; the caller then runs its Python loop."""
         if (not uses_fused_linvel(warpfunc) or self.distributed or self.process_group is not None or self.adaptive_lifespan
-                or getattr(self, "enqueue_only", False)):
+                or getattr(self, "enqueue_only", False) or self._evaluators_overridden()):
             return None
         ev = _as_device_events(xs, ys, ts, ps)
         if len(ev) == 0:

@@ -406,6 +406,23 @@ def test_native_bfgs_loop_visits_the_points_of_the_python_loop():
         o2.native_passes = None
         a2 = evk_bfgs(o2, np.array([0.0, 0.0]), args, callback=lambda q: seen.append(q.copy()))
         assert o2.native_passes is None and len(seen) >= 3 and np.array_equal(seen[-1], a2) and np.array_equal(a2, a)
+        # a plugin objective derived from the variance objective is evaluated through ITS methods, not through the short cuts
+        calls = []
+
+        class scaled(E.variance_objective):
+            def evaluate_function_and_gradient(self, params=None, *a, **k):
+                fv, gv = super().evaluate_function_and_gradient(params, *a, **k)
+                calls.append(np.array(params, dtype=float))
+                return 2.0 * fv, 2.0 * gv
+
+            def evaluate_function_batch(self, params_list, *a, **k):
+                return [2.0 * v for v in super().evaluate_function_batch(params_list, *a, **k)]
+        o4 = scaled()
+        o4.sensor_size, o4.reference_exact = (H, W), False
+        o4.native_passes = None
+        assert o4.bind_fast(*args) is None and o4.bind_native(*args) is None
+        a4 = evk_bfgs(o4, np.array([0.0, 0.0]), args)
+        assert o4.native_passes is None and len(calls) >= 3 and np.linalg.norm(a4 - np.array([40.0, -25.0])) < 3.0
         # a start beyond every LDS window: the library loop declines at its first pass, the Python loop (direct kernels) runs
         o3 = E.variance_objective()
         o3.sensor_size, o3.reference_exact = (H, W), False
