@@ -83,6 +83,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
+    # EVK_BENCH_DRY_RUN_ONE_GPU=1: a dry run of the N > 1 control flow where only ONE GPU exists -- every rank on cuda:0, the
+    # collectives over gloo (RCCL refuses two ranks on one device).  Its numbers mean nothing and the line says so ("dry_run");
+    # it exists so that rank-dependent branches, barriers and collectives have run with world_size > 1 before the first
+    # multi-GPU node sees this file.
+    dry = os.environ.get("EVK_BENCH_DRY_RUN_ONE_GPU") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)          # fails loudly when this rank has no GPU
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -95,7 +102,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     import event_utils_amd as E
@@ -262,8 +272,10 @@ def main():
                                 "barrier + synchronize, after `warmup` warm-up steps"},
         "roofline": roofline,
     }
+    if dry:
+        result["dry_run"] = "EVK_BENCH_DRY_RUN_ONE_GPU=1: %d ranks share cuda:0, collectives over gloo -- control flow only, NOT a measurement" % world
     if use_dist:
-        result["rccl_ranks"] = dist.get_world_size()
+        result["rccl_ranks"] = 0 if dry else dist.get_world_size()       # (the dry run's collectives are gloo's)
         result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], sets[(args.steps - 1) % COLUMN_SETS][3], n, world))
         if exchange_choice:
             result["exchange"] = exchange_choice
