@@ -359,7 +359,36 @@ def optimize_contrast(xs, ys, ts, ps, warp_function, objective, optimizer=opt.fm
 
     def kept(x):
         return last["g"] if "x" in last and np.array_equal(last["x"], np.asarray(x, dtype=np.float64)) else None
-    if numeric_grads and hasattr(objective, "evaluate_function_and_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
+    # (round 6) scipy's callbacks through the closures bound to these events (variance_objective.bind_fast: same library calls,
+    # same numbers and return types as the public methods, ~8 us less Python per evaluation -- a tenth of an evaluation at the
+    # reference's own window sizes, tools/eval_paths.py); None for any other objective, a subclass or an instance with its own
+    # evaluating methods, plugin warps, sharded runs
+    bound = objective.bind_fast(*args) if (fused and optimizer is opt.fmin_bfgs and hasattr(objective, "bind_fast")) else None
+    if bound is not None and numeric_grads:
+        f3 = bound[1]
+
+        def f_num3(x, *a):          # evaluate_function_and_numeric_gradient's arithmetic (forward differences, epsilon = 1)
+            q0, q1 = float(x[0]), float(x[1])
+            e0, e1 = q0 + 1.0, q1 + 1.0
+            fs = f3([[q0, q1], [e0, q1], [q0, e1]])
+            return keep(x, np.float32(fs[0]), np.array([(fs[1] - fs[0]) / (e0 - q0), (fs[2] - fs[0]) / (e1 - q1)]))
+
+        def g_num3(x, *a):
+            g = kept(x)
+            return (f_num3(x), last["g"])[1] if g is None else g
+        argmax = optimizer(f_num3, x0, fprime=g_num3, args=args, disp=False, callback=objective.iter_update)
+    elif bound is not None:
+        fg = bound[0]
+
+        def f_fg(x, *a):
+            fv, gv = fg([float(x[0]), float(x[1])])
+            return keep(x, np.float32(fv), np.array(gv, dtype=np.float32))
+
+        def g_fg(x, *a):
+            g = kept(x)
+            return (f_fg(x), last["g"])[1] if g is None else g
+        argmax = optimizer(f_fg, x0, fprime=g_fg, args=args, disp=False, callback=objective.iter_update)
+    elif numeric_grads and hasattr(objective, "evaluate_function_and_numeric_gradient") and fused and optimizer is opt.fmin_bfgs:
         # same forward differences (epsilon = 1) scipy would take internally, but f(x), f(x + e1), f(x + e2) share a
         # single pass over the events, and that pass serves both the f and the f' request of a trial point
         def f_num(x, *a):

@@ -377,9 +377,10 @@ class variance_objective(objective_function):
         """A subclass that redefines an evaluating method (a plugin objective derived from this one) must be evaluated through
         its own methods: the bound short cuts below call the library for THIS class's arithmetic."""
         cls = type(self)
-        return any(getattr(cls, m, None) is not getattr(variance_objective, m)
-                   for m in ("evaluate_function", "evaluate_gradient", "evaluate_function_and_gradient", "evaluate_function_batch",
-                             "evaluate_numeric_gradient", "evaluate_function_and_numeric_gradient", "_one_call", "_batch3_setup"))
+        names = ("evaluate_function", "evaluate_gradient", "evaluate_function_and_gradient", "evaluate_function_batch",
+                 "evaluate_numeric_gradient", "evaluate_function_and_numeric_gradient", "_one_call", "_batch3_setup")
+        # (a method replaced on the INSTANCE -- a tracing wrapper, as tests/test_gpu_parity.py installs -- counts as well)
+        return any(getattr(cls, m, None) is not getattr(variance_objective, m) or m in self.__dict__ for m in names)
 
     def bind_fast(self, xs, ys, ts, ps, warpfunc, img_size, blur_sigma):
         """(fg, f3) closures for a loop that evaluates THIS objective on THESE events many times (events_cmax.evk_bfgs):

@@ -467,3 +467,37 @@ def test_optimisers_bucket_small_event_sets():
     ev3 = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
     grid_search_optimisation(ev3, None, None, None, w, objective(), (H, W), param_ranges=[[-60, 60], [-60, 60]], num_samples_per_param=5)
     assert ev3.many_evaluations and ev3._buckets
+
+
+def test_scipy_callbacks_through_the_bound_closures_change_nothing():
+    """Round 6: optimize_contrast hands scipy's fmin_bfgs closures bound to the events (variance_objective.bind_fast) instead of
+    the public methods -- plumbing only: same argmax bit for bit as through the public methods (an objective whose methods are
+    replaced on the instance keeps them, which is how the public route is taken here), numeric and analytic gradients."""
+    import warnings
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast
+    n, H, W = 60_000, 180, 240
+    x, y, t, p = bench.structured_scene(5, n, H, W)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    w = E.linvel_warp()
+    for numeric in (True, False):
+        got = {}
+        for route in ("bound", "public"):
+            o = E.variance_objective()
+            o.sensor_size, o.reference_exact = (H, W), False
+            calls = [0]
+            if route == "public":
+                inner = o.evaluate_function_and_numeric_gradient if numeric else o.evaluate_function_and_gradient
+
+                def counted(*a, _inner=inner, **k):
+                    calls[0] += 1
+                    return _inner(*a, **k)
+                setattr(o, "evaluate_function_and_numeric_gradient" if numeric else "evaluate_function_and_gradient", counted)
+                assert o.bind_fast(ev, None, None, None, w, (H, W), 1.0) is None
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got[route] = optimize_contrast(ev, None, None, None, w, o, numeric_grads=numeric, blur_sigma=1.0, img_size=(H, W))
+            assert (calls[0] > 5) == (route == "public")
+        assert np.array_equal(got["bound"], got["public"]), (numeric, got)
+        assert np.linalg.norm(got["bound"] - np.array([40.0, -25.0])) < 1.5
