@@ -72,6 +72,7 @@ SIGNATURES = {
     "evk_cmax_bfgs_variance_tiled_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
                                          c_int, c_int, c_uint32, c_double, c_double, c_double, P, c_int, c_uint32, P, c_int64,
                                          P, P, P, c_int64, P, P, P, P, P, c_int, P],
+    "evk_bfgs2_minimize": [P, P, P, P, P, P, c_int],
     "evk_iwe_linvel_tiled_batch3_f32": [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                         c_double, P, P, c_double, c_double, c_int, c_int, c_uint32, c_double, c_double,
                                         c_double, P, c_int64, P, P],

@@ -114,9 +114,40 @@ static int eval_f3(Loop &L, const double pts[3][2], double fs[3]) {
     return EVK_OK;
 }
 
+// An evaluator the host supplies through the C ABI (evk_bfgs2_minimize): the same loop for any two-parameter objective
+struct Callbacks {
+    evk_bfgs2_fg_fn fg;
+    evk_bfgs2_f3_fn f3;
+    void *user;
+    int passes = 0;
+    bool replan = false;
+    bool numeric = false;
+};
+static int eval_fg(Callbacks &C, const double q[2], double &f, double g[2]) {
+    if (!C.fg) return EVK_EINVAL;
+    const int rc = C.fg(C.user, q, &f, g);
+    if (rc == 1) {
+        C.replan = true;
+        return EVK_OK;
+    }
+    if (rc == EVK_OK) ++C.passes;
+    return rc;
+}
+static int eval_f3(Callbacks &C, const double pts[3][2], double fs[3]) {
+    if (!C.f3) return EVK_EINVAL;
+    const int rc = C.f3(C.user, &pts[0][0], fs);
+    if (rc == 1) {
+        C.replan = true;
+        return EVK_OK;
+    }
+    if (rc == EVK_OK) ++C.passes;
+    return rc;
+}
+
 // value + gradient the way the run asked for it: analytic, or forward differences with epsilon = 1 from one three-flow pass
 // (the reference's default, events_cmax.py:343)
-static int value_grad(Loop &L, const double q[2], double &f, double g[2]) {
+template <typename EVAL>
+static int value_grad(EVAL &L, const double q[2], double &f, double g[2]) {
     if (!L.numeric) return eval_fg(L, q, f, g);
     const double pts[3][2] = {{q[0], q[1]}, {q[0] + 1.0, q[1]}, {q[0], q[1] + 1.0}};
     double fs[3];
@@ -140,27 +171,9 @@ static inline void axpy2(double al, const double d[2], const double base[2], dou
     out[1] = base[1] + al * d[1];
 }
 
-}  // namespace
-
-extern "C" int evk_cmax_bfgs_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
-                                                int tw_log2, int th_log2, double t_first, double t_ref, double bounds_w,
-                                                double bounds_h, int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale,
-                                                double p_bound, double dt_bound, const double *host_weights, int radius,
-                                                uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf,
-                                                double *out12, void *scratch, int64_t scratch_bytes, float *spill_pair,
-                                                int *parity, const double *x0, const double *opts, double *result,
-                                                int trace_cap, void *stream) {
-    if (!x0 || !opts || !result || !parity || !spill_pair || trace_cap < 0 || (iwe_flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
-    Loop L;
-    L.records = records, L.index = bucket_index, L.n = n, L.dom_h = dom_h, L.dom_w = dom_w, L.tw_log2 = tw_log2, L.th_log2 = th_log2;
-    L.t_first = t_first, L.t_ref = t_ref, L.bounds_w = bounds_w, L.bounds_h = bounds_h, L.ch = canvas_h, L.cw = canvas_w;
-    L.iwe_flags = iwe_flags, L.p_scale = p_scale, L.p_bound = p_bound, L.dt_bound = dt_bound, L.weights = host_weights;
-    L.radius = radius, L.post_flags = post_flags & ~(EVK_POST_NONE | EVK_POST_VALUE), L.staging = staging, L.staging_bytes = staging_bytes;
-    L.iwe_buf = iwe_buf, L.out12 = out12, L.scratch = scratch, L.scratch_bytes = scratch_bytes, L.spill = spill_pair;
-    L.parity = parity, L.stream = stream;
-    L.span = std::fabs(t_first - t_ref);
-    L.ntiles = evk_bucket_num_tiles(dom_h, dom_w, tw_log2, th_log2);
-    if (L.ntiles <= 0) return EVK_EINVAL;
+// events_cmax.evk_bfgs, two parameters, on any evaluator
+template <typename EVAL>
+static int minimise(EVAL &L, const double *x0, const double *opts, double *result, int trace_cap) {
     const double xtol = opts[0], gtol = opts[1], ftol = opts[2];
     const int maxiter = (int)opts[3];
     L.numeric = opts[4] != 0.0;
@@ -270,4 +283,36 @@ extern "C" int evk_cmax_bfgs_variance_tiled_f32(const float *records, const uint
 #undef EVK_STEP
     finish(x, f, 0);
     return EVK_OK;
+}
+
+}  // namespace
+
+extern "C" int evk_cmax_bfgs_variance_tiled_f32(const float *records, const uint32_t *bucket_index, int64_t n, int dom_h, int dom_w,
+                                                int tw_log2, int th_log2, double t_first, double t_ref, double bounds_w,
+                                                double bounds_h, int canvas_h, int canvas_w, uint32_t iwe_flags, double p_scale,
+                                                double p_bound, double dt_bound, const double *host_weights, int radius,
+                                                uint32_t post_flags, void *staging, int64_t staging_bytes, float *iwe_buf,
+                                                double *out12, void *scratch, int64_t scratch_bytes, float *spill_pair,
+                                                int *parity, const double *x0, const double *opts, double *result,
+                                                int trace_cap, void *stream) {
+    if (!x0 || !opts || !result || !parity || !spill_pair || trace_cap < 0 || (iwe_flags & EVK_IWE_GRADIENT)) return EVK_EINVAL;
+    Loop L;
+    L.records = records, L.index = bucket_index, L.n = n, L.dom_h = dom_h, L.dom_w = dom_w, L.tw_log2 = tw_log2, L.th_log2 = th_log2;
+    L.t_first = t_first, L.t_ref = t_ref, L.bounds_w = bounds_w, L.bounds_h = bounds_h, L.ch = canvas_h, L.cw = canvas_w;
+    L.iwe_flags = iwe_flags, L.p_scale = p_scale, L.p_bound = p_bound, L.dt_bound = dt_bound, L.weights = host_weights;
+    L.radius = radius, L.post_flags = post_flags & ~(EVK_POST_NONE | EVK_POST_VALUE), L.staging = staging, L.staging_bytes = staging_bytes;
+    L.iwe_buf = iwe_buf, L.out12 = out12, L.scratch = scratch, L.scratch_bytes = scratch_bytes, L.spill = spill_pair;
+    L.parity = parity, L.stream = stream;
+    L.span = std::fabs(t_first - t_ref);
+    L.ntiles = evk_bucket_num_tiles(dom_h, dom_w, tw_log2, th_log2);
+    if (L.ntiles <= 0) return EVK_EINVAL;
+    return minimise(L, x0, opts, result, trace_cap);
+}
+
+extern "C" int evk_bfgs2_minimize(evk_bfgs2_fg_fn fg, evk_bfgs2_f3_fn f3, void *user, const double *x0, const double *opts,
+                                  double *result, int trace_cap) {
+    if (!x0 || !opts || !result || trace_cap < 0 || !f3 || (!fg && opts[4] == 0.0)) return EVK_EINVAL;
+    Callbacks C;
+    C.fg = fg, C.f3 = f3, C.user = user;
+    return minimise(C, x0, opts, result, trace_cap);
 }

@@ -553,6 +553,15 @@ int evk_cmax_bfgs_variance_tiled_f32(const float *records, const uint32_t *bucke
                                      void *staging, int64_t staging_bytes, float *iwe_buf, double *out12, void *scratch,
                                      int64_t scratch_bytes, float *spill_pair, int *parity, const double *x0,
                                      const double *opts, double *result, int trace_cap, void *stream);
+/* The same iteration on an evaluator of the caller's (any two-parameter objective; no GPU work of its own -- a host function):
+ * fg(user, x[2], &f, g[2]) = value and gradient at x; f3(user, pts[6] = {x0a, x1a, x0b, x1b, x0c, x1c}, fs[3]) = the values at
+ * three points (one pass over the events when the objective can do that).  Both return 0, or 1 to decline the point (the
+ * run ends with status 1, as above), or any other code, which is returned as it is.  fg may be NULL when opts[4]
+ * (numeric_grads) is set: value and gradient then come from f3 at x, x + e0, x + e1.  opts / result / trace_cap as above. */
+typedef int (*evk_bfgs2_fg_fn)(void *user, const double *x, double *f, double *g);
+typedef int (*evk_bfgs2_f3_fn)(void *user, const double *pts, double *fs);
+int evk_bfgs2_minimize(evk_bfgs2_fg_fn fg, evk_bfgs2_f3_fn f3, void *user, const double *x0, const double *opts,
+                       double *result, int trace_cap);
 
 /* Largest singular value SQUARED of a float32 (h, w) image, float64 -> out[0]: what the "rms" objective needs
  * (objectives.py:282: np.linalg.norm(iwe, 2) of a 2-D array is the spectral norm).  Lanczos on the Gram operator with full

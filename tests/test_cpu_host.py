@@ -369,3 +369,83 @@ def test_evk_bfgs_line_search_logic_on_a_known_function():
         assert len(seen) == len(tr) - 1 and o.fg_calls == len(tr)
         assert o.fg_calls <= 25 and o.batch_calls <= 40
         assert all(tr[k + 1][1] <= tr[k][1] for k in range(len(tr) - 1))       # monotone: every accepted point improves f
+
+
+def test_library_bfgs_loop_equals_the_python_loop_on_a_known_function():
+    """evk_bfgs2_minimize (evk_optim.hip: the quasi-Newton loop of events_cmax.evk_bfgs in C, here on caller-supplied
+    evaluators; the GPU entry evk_cmax_bfgs_variance_tiled_f32 is the same template on the library's own evaluation calls) is a
+    host function: on the bowl of the test above, driven through ctypes callbacks, it must visit the points of the Python loop
+    BIT FOR BIT -- analytic and numeric gradients, unit step first or not -- and hand a declined point and an evaluator's
+    error code back."""
+    import ctypes
+    from event_utils_amd import _lib
+    from event_utils_amd.contrast_max.events_cmax import evk_bfgs
+    A = np.array([[3.0, 0.3], [0.3, 0.05]])
+    xm = np.array([40.0, -25.0])
+
+    def f(q):
+        d = np.asarray(q, dtype=np.float64) - xm
+        return float(np.float32(0.5 * d.dot(A).dot(d) * 1e-3 + 1e-7 * np.sum(d ** 4) - 2.0))
+
+    def fg(q):
+        d = np.asarray(q, dtype=np.float64) - xm
+        return f(q), [float(v) for v in (A.dot(d) * 1e-3 + 4e-7 * d ** 3).astype(np.float32)]
+
+    def f3(pts):
+        return [f(q) for q in pts]
+
+    class Bound:                                   # what evk_bfgs asks of an objective that can bind itself to its events
+        evaluate_function_and_gradient = evaluate_function_and_numeric_gradient = None     # (never reached: the closures are used)
+
+        def bind_fast(self, *a):
+            return fg, f3
+    FG = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_double))
+    F3 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
+    limit = [None]
+
+    def c_fg(user, xp, fp, gp):
+        if limit[0] is not None and abs(xp[0]) > limit[0]:
+            return 1
+        fv, gv = fg([xp[0], xp[1]])
+        fp[0], gp[0], gp[1] = fv, gv[0], gv[1]
+        return 0
+
+    def c_f3(user, pp, fsp):
+        if limit[0] is not None and max(abs(pp[0]), abs(pp[2]), abs(pp[4])) > limit[0]:
+            return 1
+        for k, v in enumerate(f3([[pp[2 * k], pp[2 * k + 1]] for k in range(3)])):
+            fsp[k] = v
+        return 0
+    cb_fg, cb_f3 = FG(c_fg), F3(c_f3)
+    fn = _lib.lib().evk_bfgs2_minimize
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+
+    def run_c(numeric, unit_first, fg_cb=cb_fg, f3_cb=cb_f3):
+        x0 = np.zeros(2)
+        opts = np.array([1e-3, 1e-5, 1e-6, 100.0, float(numeric), float(unit_first)])
+        res = np.zeros(6 + 5 * 101)
+        rc = fn(ctypes.cast(fg_cb, ctypes.c_void_p) if fg_cb is not None else None, ctypes.cast(f3_cb, ctypes.c_void_p), None,
+                ptr(x0), ptr(opts), ptr(res), 101)
+        return rc, res
+    for numeric in (False, True):
+        for unit_first in (True, False):
+            tr = []
+            xp = evk_bfgs(Bound(), np.zeros(2), (), numeric_grads=numeric, trace=tr, unit_first=unit_first, native=False)
+            rc, res = run_c(numeric, unit_first, None if numeric else cb_fg)
+            assert rc == 0 and res[5] == 0.0 and int(res[3]) == len(tr) and np.array_equal(res[:2], xp), (numeric, unit_first)
+            rows = res[6:6 + 5 * len(tr)].reshape(-1, 5)
+            for row, (q, fv, gv) in zip(rows, tr):
+                assert np.array_equal(row[:2], q) and row[2] == fv and np.array_equal(row[3:], gv)
+            if numeric:     # (forward differences with epsilon = 1: a biased gradient along the flat axis, as in the test above)
+                assert f(xp) - f(xm) < 1e-3 * (f(np.zeros(2)) - f(xm))
+            else:
+                assert np.linalg.norm(xp - xm) < 0.2
+    # a declined point ends the run with status 1 at the last accepted point; an evaluator's error code comes back as it is
+    limit[0] = 20.0
+    rc, res = run_c(False, True)
+    assert rc == 0 and res[5] == 1.0 and abs(res[0]) <= 20.0 and res[4] >= 1
+    limit[0] = None
+    bad = FG(lambda user, xp, fp, gp: -7)
+    assert run_c(False, True, bad)[0] == -7
+    assert run_c(False, True, None)[0] == -1          # EVK_EINVAL: analytic gradients need fg
