@@ -8,7 +8,9 @@ export TMPDIR=/tmp
 R=${ROUND:-r06}
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
+t0=$SECONDS
 timeout -s KILL 500 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
+echo "python bench.py (defaults, cpu_baseline included): $((SECONDS - t0)) s wall" > $OUT/${R}_bench_wall.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --no-cpu > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_bench_kernel_stats.csv \;
 rm -rf $OUT/stats
