@@ -501,3 +501,45 @@ def test_scipy_callbacks_through_the_bound_closures_change_nothing():
             assert (calls[0] > 5) == (route == "public")
         assert np.array_equal(got["bound"], got["public"]), (numeric, got)
         assert np.linalg.norm(got["bound"] - np.array([40.0, -25.0])) < 1.5
+
+
+def test_a_used_objective_can_be_copied_and_the_lifespan_cut_is_reused():
+    """Round 6: (a) an objective that has evaluated something holds a resolved library call (ctypes pointers, device buffers);
+    copy.deepcopy -- which grid_search_optimisation and optimize_contrast(grid_search_init=True) do, as upstream -- must leave
+    that behind instead of failing, and the copy evaluates like the original.  (b) With adaptive_lifespan the evaluations
+    between two iter_update calls share ONE cut view of the events (and so its buckets)."""
+    import copy
+    import warnings
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd.contrast_max.events_cmax import optimize_contrast
+    n, H, W = 200_000, 180, 240
+    x, y, t, p = bench.structured_scene(3, n, H, W)
+    ev = E.DeviceEvents.from_arrays(x, y, t, p, precision="f32")
+    w = E.linvel_warp()
+    o = E.variance_objective()
+    o.sensor_size = (H, W)
+    q = np.array([35.0, -20.0])
+    f1 = o.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
+    f2 = o.evaluate_function(q + 1.0, ev, None, None, None, w, (H, W), 1.0)
+    assert o.__dict__.get("_fast_memo") is not None and f1 != f2
+    o2 = copy.deepcopy(o)
+    assert "_fast_memo" not in o2.__dict__ and o2.sensor_size == (H, W)
+    assert o2.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0) == f1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = optimize_contrast(ev, None, None, None, w, o, numeric_grads=False, blur_sigma=1.0, img_size=(H, W), grid_search_init=True)
+    assert np.linalg.norm(a - np.array([40.0, -25.0])) < 1.5
+    # (b)
+    oa = E.variance_objective(adaptive_lifespan=True, minimum_events=1000)
+    oa.sensor_size = (H, W)
+    oa.iter_update(np.array([40.0, -25.0]))
+    v1 = oa.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
+    cut1 = oa.__dict__["_cut_cache"][2]
+    v2, g2 = oa.evaluate_function_and_gradient(q, ev, None, None, None, w, (H, W), 1.0)
+    assert oa.__dict__["_cut_cache"][2] is cut1 and len(cut1) < len(ev) and float(v1) == float(v2)
+    oa.iter_update(np.array([80.0, -50.0]))               # a shorter lifespan: another cut
+    oa.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
+    cut2 = oa.__dict__["_cut_cache"][2]
+    assert cut2 is not cut1 and len(cut2) < len(cut1)
+    assert "_cut_cache" not in copy.deepcopy(oa).__dict__
