@@ -84,6 +84,15 @@ class DeviceEvents:
         self._iwe_plans = 0            # evaluations planned on this set so far (the second one buckets it too)
         self._t_ends = None            # (ts[0], ts[-1]) when known without touching the column
 
+    # marshalled library calls cached on the object (tiled.cmax_variance: ctypes pointers into per-stream scratch) are not part
+    # of its state: a copy / pickle of resident events carries the columns and the buckets only
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_cmax")}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        _LIVE.add(self)
+
     def _columns(self):
         if self._cols is None:
             self._cols = tuple(self.native.widen())

@@ -449,3 +449,30 @@ def test_library_bfgs_loop_equals_the_python_loop_on_a_known_function():
     bad = FG(lambda user, xp, fp, gp: -7)
     assert run_c(False, True, bad)[0] == -7
     assert run_c(False, True, None)[0] == -1          # EVK_EINVAL: analytic gradients need fg
+
+
+def test_resident_events_and_objectives_copy_without_their_call_caches():
+    """Marshalled library calls cached on a DeviceEvents / an objective hold ctypes pointers (which copy.deepcopy and pickle
+    refuse) into per-stream scratch: they are transient, a copy carries the state only and registers itself for
+    release_scratch like any other DeviceEvents."""
+    import copy
+    import ctypes
+    import pickle
+    import torch
+    import event_utils_amd as E
+    from event_utils_amd.events import _LIVE
+    x = torch.arange(4, dtype=torch.float32)
+    ev = E.DeviceEvents(x, x.clone(), x.clone(), x.clone())
+    ev.many_evaluations = True
+    ev.__dict__["_cmax_calls"] = {"k": {"args": [ctypes.c_void_p(3)]}}
+    ev.__dict__["_cmax_last_single"] = ev.__dict__["_cmax_calls"]["k"]
+    for clone in (copy.deepcopy(ev), pickle.loads(pickle.dumps(ev))):
+        assert not any(k.startswith("_cmax") for k in clone.__dict__) and clone in _LIVE
+        assert clone.many_evaluations and torch.equal(clone.x, ev.x) and len(clone) == 4
+    o = E.variance_objective(adaptive_lifespan=True)
+    o.sensor_size = (12, 16)
+    o.__dict__["_fast_memo"] = (("key",), None, {"args": [ctypes.c_void_p(5)]})
+    o.__dict__["_cut_cache"] = (("key",), None, ev)
+    o2 = copy.deepcopy(o)
+    assert "_fast_memo" not in o2.__dict__ and "_cut_cache" not in o2.__dict__
+    assert o2.sensor_size == (12, 16) and o2.adaptive_lifespan and "_fast_memo" in o.__dict__
