@@ -222,18 +222,18 @@ class objective_function(ABC):
             self.recompute_lifespan = False
         # (round 6) the cut changes once per optimiser iteration (iter_update), the line search in between evaluates the SAME
         # cut several times: one view per (event set, start index), so that its buckets are made once and not per evaluation
-        key = (id(ev), int(self.s_idx))
-        c = self.__dict__.get("_cut_cache")
-        if c is not None and c[0] == key and c[1]() is ev:
-            return c[2]
+        # (kept ON the event set, so that it goes when the events go)
+        c = ev.__dict__.get("_lifespan_cut")
+        if c is not None and c[0] == int(self.s_idx):
+            return c[1]
         cut = ev.slice(int(self.s_idx), -1).scaled(100.0)
         cut.many_evaluations = ev.many_evaluations
-        self.__dict__["_cut_cache"] = (key, weakref.ref(ev), cut)
+        ev.__dict__["_lifespan_cut"] = (int(self.s_idx), cut)
         return cut
 
     # caches that tie the object to device buffers and marshalled library calls: not part of its state (copy.deepcopy of an
     # objective -- grid_search_optimisation, optimize_contrast(grid_search_init=True) do it, as upstream -- and pickling)
-    _TRANSIENT = ("_fast_memo", "_cut_cache")
+    _TRANSIENT = ("_fast_memo",)
 
     def __getstate__(self):
         return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}

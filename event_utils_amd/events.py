@@ -87,7 +87,7 @@ class DeviceEvents:
     # marshalled library calls cached on the object (tiled.cmax_variance: ctypes pointers into per-stream scratch) are not part
     # of its state: a copy / pickle of resident events carries the columns and the buckets only
     def __getstate__(self):
-        return {k: v for k, v in self.__dict__.items() if not k.startswith("_cmax")}
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_cmax") and k != "_lifespan_cut"}
 
     def __setstate__(self, state):
         self.__dict__.update(state)

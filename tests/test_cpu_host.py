@@ -472,7 +472,6 @@ def test_resident_events_and_objectives_copy_without_their_call_caches():
     o = E.variance_objective(adaptive_lifespan=True)
     o.sensor_size = (12, 16)
     o.__dict__["_fast_memo"] = (("key",), None, {"args": [ctypes.c_void_p(5)]})
-    o.__dict__["_cut_cache"] = (("key",), None, ev)
     o2 = copy.deepcopy(o)
-    assert "_fast_memo" not in o2.__dict__ and "_cut_cache" not in o2.__dict__
+    assert "_fast_memo" not in o2.__dict__
     assert o2.sensor_size == (12, 16) and o2.adaptive_lifespan and "_fast_memo" in o.__dict__

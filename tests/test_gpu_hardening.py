@@ -535,11 +535,10 @@ def test_a_used_objective_can_be_copied_and_the_lifespan_cut_is_reused():
     oa.sensor_size = (H, W)
     oa.iter_update(np.array([40.0, -25.0]))
     v1 = oa.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
-    cut1 = oa.__dict__["_cut_cache"][2]
+    cut1 = ev.__dict__["_lifespan_cut"][1]
     v2, g2 = oa.evaluate_function_and_gradient(q, ev, None, None, None, w, (H, W), 1.0)
-    assert oa.__dict__["_cut_cache"][2] is cut1 and len(cut1) < len(ev) and float(v1) == float(v2)
+    assert ev.__dict__["_lifespan_cut"][1] is cut1 and len(cut1) < len(ev) and float(v1) == float(v2)
     oa.iter_update(np.array([80.0, -50.0]))               # a shorter lifespan: another cut
     oa.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
-    cut2 = oa.__dict__["_cut_cache"][2]
+    cut2 = ev.__dict__["_lifespan_cut"][1]
     assert cut2 is not cut1 and len(cut2) < len(cut1)
-    assert "_cut_cache" not in copy.deepcopy(oa).__dict__
