@@ -890,7 +890,7 @@ def bench_cmax(E, DeviceEvents, dev, impl):
         # the same optimisation COLD: a fresh DeviceEvents on the same device columns -- the bucketing of the events by tile
         # (k_tile_hist / scan / scatter) and, for streams beyond the Infinity Cache, the compaction of the records are inside
         # the timed region (`seconds` above starts with the events already bucketed by the evaluations timed before it)
-        cold = DeviceEvents(ev.x, ev.y, ev.t, ev.p, t_host=ev._t_host)
+        cold = ev.fresh_view()
         o2 = E.variance_objective()
         o2.sensor_size, o2.impl, o2.reference_exact = (H4, W4), impl, exact
         torch.cuda.synchronize()
@@ -993,7 +993,7 @@ def bench_evk_bfgs(E, DeviceEvents, impl):
             tiled.FORCE["native_bfgs"] = True
         cold, arg = [], None
         for _ in range(3):
-            fresh = DeviceEvents(ev.x, ev.y, ev.t, ev.p, t_host=ev._t_host)
+            fresh = ev.fresh_view()
             dt, arg = run(fresh)
             cold.append(dt)
             del fresh

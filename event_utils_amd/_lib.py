@@ -89,6 +89,7 @@ SIGNATURES = {
     "evk_dense_rank_f64": [P, c_int64, P, P, c_int64, P],
     "evk_minmax_normalise_f64": [P, c_int64, P, P, P],
     "evk_polarity_weights_f32": [P, c_int64, P, P, P],
+    "evk_narrow_f64_f32": [P, c_int64, c_double, P, P, P],
     "evk_abs_max": [P, c_int, c_int64, P, P],
     "evk_abs": [P, c_int, c_int64, P, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],

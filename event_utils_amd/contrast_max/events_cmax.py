@@ -25,7 +25,9 @@ from .warps import linvel_warp, uses_fused_linvel, warp_function  # noqa: F401
 def _resident(xs, ys, ts, ps, warp_function, objective):
     """Upload the events once for the fused linear-flow path; plugin warps keep their host arrays."""
     if uses_fused_linvel(warp_function) and isinstance(objective, objective_function):
-        ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
+        # (float64 time stamps that are not float32 values stay on the float32 path as differences from ts[-1]: an optimiser
+        # hands back an argmax, which that does not move -- DeviceEvents.from_arrays)
+        ev = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps, relative_time=True)
         ev.many_evaluations = True          # every caller of this is a search / an optimiser: tens of evaluations of these events
         return ev, None, None, None
     return xs, ys, ts, ps

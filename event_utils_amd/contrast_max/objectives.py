@@ -80,8 +80,7 @@ def iwe_device(params, ev, img_size, compute_gradient=False, use_polarity=True, 
     buf = torch.zeros((3 if compute_gradient else 1, ch, cw), dtype=torch.float32, device=dev)
     iwe, diwe = buf[0], (buf[1:3] if compute_gradient else None)
     flags = (0 if use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if compute_gradient else 0)
-    if t_ref is None:
-        t_ref = ev.t_at(-1)
+    t_ref = ev.t_at(-1) if t_ref is None else t_ref - ev.t_offset       # (an ABSOLUTE time; the column may be relative)
     if len(ev):
         tiled.iwe_linvel(ev, float(t_ref), float(params[0]), float(params[1]), float(img_size[1]),
                          float(img_size[0]), ch, cw, flags, iwe, diwe, impl=impl)
@@ -266,7 +265,7 @@ class objective_function(ABC):
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
         ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
         flags = (0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY) | (_lib.EVK_IWE_GRADIENT if grad else 0)
-        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref - ev.t_offset    # (t_ref is an ABSOLUTE time)
         w, radius = _blur_kernel(blur_sigma)
         planes = 3 if grad else 1
         buf = tiled._buf("iwe_buf", planes * ch * cw * 4, dev)
@@ -378,7 +377,7 @@ class variance_objective(objective_function):
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
         ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
         flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
-        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref - ev.t_offset    # (t_ref is an ABSOLUTE time)
         w, radius = _blur_kernel(blur_sigma)
         buf = tiled._buf("iwe_buf", 3 * ch * cw * 4, dev)
         scratch, nbytes = D.reduce_scratch(dev)
@@ -460,7 +459,7 @@ class variance_objective(objective_function):
         ss = (180, 240) if self.sensor_size is None else self.sensor_size
         ch, cw = int(ss[0]) + 1, int(ss[1]) + 1
         flags = 0 if self.use_polarity else _lib.EVK_IWE_ABS_POLARITY
-        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref
+        t_ref = ev.t_at(-1) if self.t_ref is None else self.t_ref - ev.t_offset    # (t_ref is an ABSOLUTE time)
         w, radius = _blur_kernel(blur)
 
         def run(x0, xtol, gtol, ftol, maxiter, numeric_grads, unit_first):

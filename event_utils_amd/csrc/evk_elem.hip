@@ -40,9 +40,30 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_abs(const T *__restrict__ in, int
         out[i] = in[i] < (T)0 ? -in[i] : (in[i] == (T)0 ? (T)0 : in[i]);   // |x| with -0.0 -> +0.0 (and NaN kept)
 }
 
+// float64 column -> float32 column of (in[i] - offset), the subtraction in float64; *inexact |= 1 when some value does not
+// survive the narrowing exactly ((double)(float)v != v: also a NaN, as the host-side policy it replaces treats it)
+__global__ void __launch_bounds__(EVK_BLOCK) k_narrow_f64(const double *__restrict__ in, int64_t n, double offset, float *__restrict__ out,
+                                                         uint32_t *__restrict__ inexact) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = in[i] - offset;
+        const float f = (float)v;
+        out[i] = f;
+        bad = bad || !((double)f == v);
+    }
+    if (inexact && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1u);
+}
+
 }  // namespace evk
 
 using namespace evk;
+
+extern "C" int evk_narrow_f64_f32(const double *in, int64_t n, double offset, float *out, uint32_t *inexact, void *stream) {
+    if (n < 0 || (n > 0 && (!in || !out))) return EVK_EINVAL;
+    if (n == 0) return EVK_OK;
+    k_narrow_f64<<<stream_grid(n), EVK_BLOCK, 0, (hipStream_t)stream>>>(in, n, offset, out, inexact);
+    return launch_status();
+}
 
 extern "C" int evk_polarity_weights_f32(const float *p, int64_t n, float *pos, float *neg, void *stream) {
     if (n < 0 || (n > 0 && (!p || (!pos && !neg)))) return EVK_EINVAL;

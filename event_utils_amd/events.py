@@ -21,13 +21,29 @@ def _abs_max(col):
     return float(np.array([bits], dtype=np.int64).view(np.float64)[0])
 
 
-def _f32_lossless(a):
-    a = np.asarray(a)
-    if a.dtype == np.float32 or np.issubdtype(a.dtype, np.integer) and (a.size == 0 or np.abs(a).max() < 2 ** 24):
-        return True
+def time_rebase():
+    """Whether DeviceEvents.from_arrays may keep float64 time stamps as float32 differences from ts[-1] (default) or must keep the
+    float64 column (EVK_TIME_F64=exact: bit-level agreement with a float64 host computation, direct kernels)."""
+    import os
+    return os.environ.get("EVK_TIME_F64", "relative") != "exact"
+
+
+def _narrow_f32(a):
+    """(float32 copy of the column, whether it holds exactly the same values)."""
+    if a.dtype == np.float32:
+        return a, True
     if a.dtype == np.bool_:
-        return True
-    return bool(np.array_equal(a.astype(np.float32).astype(np.float64), a.astype(np.float64)))
+        return a.astype(np.float32), True
+    b = a.astype(np.float32)
+    if np.issubdtype(a.dtype, np.integer):
+        return b, bool(a.size == 0 or np.abs(a).max() < 2 ** 24)
+    return b, bool(np.array_equal(b, a))
+
+
+def _f32_lossless(a):
+    """Whether every value of the host array survives a conversion to float32 (the 'auto' precision policy for columns that are
+    checked on the host; float64 columns are checked by evk_narrow_f64_f32 with the same rule)."""
+    return _narrow_f32(np.asarray(a))[1]
 
 
 class NativeColumns:
@@ -83,6 +99,7 @@ class DeviceEvents:
         self.many_evaluations = False
         self._iwe_plans = 0            # evaluations planned on this set so far (the second one buckets it too)
         self._t_ends = None            # (ts[0], ts[-1]) when known without touching the column
+        self.t_offset = 0.0            # absolute time of the column's zero (from_arrays: float64 stamps kept relative to ts[-1])
 
     # marshalled library calls cached on the object (tiled.cmax_variance: ctypes pointers into per-stream scratch) are not part
     # of its state: a copy / pickle of resident events carries the columns and the buckets only
@@ -109,9 +126,13 @@ class DeviceEvents:
 
     # -- construction --------------------------------------------------------------------------------------
     @classmethod
-    def from_arrays(cls, xs, ys, ts, ps, precision="auto", device=None):
+    def from_arrays(cls, xs, ys, ts, ps, precision="auto", device=None, relative_time=False):
         """numpy arrays / torch tensors -> device columns.  precision: 'f32', 'f64' or 'auto' (float32 when every
-        column is exactly representable in float32 -- lossless -- else float64)."""
+        column is exactly representable in float32 -- lossless -- else float64).
+        relative_time (with 'auto', host arrays): float64 time stamps that are not float32 values -- absolute seconds with
+        microsecond resolution, what the reference's h5 / rosbag readers deliver -- no longer force float64 columns: they
+        are kept as float32 DIFFERENCES from ts[-1] (see below).  What the optimisers ask for (events_cmax._resident); single
+        evaluations keep the exact float64 route."""
         device = device or D.require_gpu()
         if isinstance(xs, torch.Tensor):
             if precision == "auto":
@@ -119,11 +140,56 @@ class DeviceEvents:
             dt = torch.float32 if precision == "f32" else torch.float64
             return cls(*(D.to_device(a, dt, device) for a in (xs, ys, ts, ps)))
         cols = [np.asarray(a).reshape(-1) for a in (xs, ys, ts, ps)]
+        n = len(cols[2])
+        t_offset, dev_cols = 0.0, None
         if precision == "auto":
-            precision = "f32" if all(_f32_lossless(c) for c in cols) else "f64"
+            # float64 columns (the reference's host arrays) go up as they are and are narrowed ON THE DEVICE, which also says
+            # whether they survived exactly (evk_narrow_f64_f32): two numpy passes per column on the host took ten times as
+            # long as the whole optimisation that follows (2 M events: 15 ms against 1.3 ms).  Other dtypes: one float32 copy
+            # (it is what gets uploaded) and one comparison.
+            raw = [D.to_device(c, torch.float64, device) if c.dtype == np.float64 and n else None for c in cols]
+            flags = torch.zeros(4, dtype=torch.int32, device=device)
+            dev_cols, exact = [None] * 4, [True] * 4
+            for i, c in enumerate(cols):
+                if raw[i] is not None:
+                    dev_cols[i] = torch.empty(n, dtype=torch.float32, device=device)
+                    _lib.call("evk_narrow_f64_f32", D.ptr(raw[i]), n, 0.0, D.ptr(dev_cols[i]), D.ptr(flags[i:]), D.stream())
+                else:
+                    host32, exact[i] = _narrow_f32(c)
+                    dev_cols[i] = D.to_device(host32, torch.float32, device)
+            if any(r is not None for r in raw):
+                for i, f in enumerate(flags.tolist()):
+                    exact[i] = exact[i] and not f
+            if all(exact):
+                precision = "f32"
+            elif relative_time and exact[0] and exact[1] and exact[3] and raw[2] is not None and np.isfinite(cols[2][-1]) \
+                    and time_rebase():
+                # Only the time stamps need float64 -- absolute seconds with microsecond resolution, what the reference's h5 /
+                # rosbag readers deliver.  The kernels only ever use time DIFFERENCES (t - t_ref, (t - ts[0]) / (ts[-1] - ts[0])),
+                # so the column is kept RELATIVE to ts[-1] (the default reference time, objectives.py:186), subtracted in float64
+                # and then rounded to float32: the error of a difference is <= 2^-24 of the event's distance from ts[-1] --
+                # 6e-9 s over a 0.1 s window -- and the events stay on the float32 (bucketed) path instead of the float64 direct
+                # kernels (3-15 x on optimize_contrast, tools/f64_time_probe.py).  The float32 kernels also WARP in float32
+                # (x - dt * v rounds to ulp(x) ~ 6e-5 px at x ~ 1000, where the reference's float64 numpy does not): objective
+                # values and gradients -- sums over the image -- move by ~1e-6 relative, the argmax by < 1e-3 px/s, but single
+                # IWE pixels of a sparse image by up to a few 1e-5 of the maximum, and the derivative images are discontinuous
+                # where a warped event crosses a pixel boundary.  Hence opt-in: the optimisers use it (only the argmax leaves
+                # them), get_iwe / evaluate_* on host arrays keep the float64 columns.  EVK_TIME_F64=exact: never.
+                t_offset = float(cols[2][-1])
+                _lib.call("evk_narrow_f64_f32", D.ptr(raw[2]), n, t_offset, D.ptr(dev_cols[2]), None, D.stream())
+                precision = "f32"
+            else:
+                precision = "f64"
+                dev_cols = [raw[i] if raw[i] is not None else D.to_device(c, torch.float64, device) for i, c in enumerate(cols)]
         dt = torch.float32 if precision == "f32" else torch.float64
-        t_host = cols[2].astype(np.float64) if dt == torch.float64 else cols[2].astype(np.float32).astype(np.float64)
-        return cls(*(D.to_device(c, dt, device) for c in cols), t_host=t_host)
+        if dev_cols is None:
+            dev_cols = [D.to_device(c, dt, device) for c in cols]
+        ev = cls(*dev_cols)
+        ev.t_offset = t_offset
+        if n:   # ts[0] / ts[-1] as the kernels see them, without touching the column (the whole host copy only on demand: t_host())
+            ends = [np.float64(cols[2][k]) - t_offset for k in (0, -1)]
+            ev._t_ends = tuple(float(np.float32(e)) if dt == torch.float32 else float(e) for e in ends)
+        return ev
 
     @classmethod
     def from_native(cls, xs, ys, ts, ps, polarity="pm1", t_offset=None, device=None):
@@ -172,6 +238,7 @@ class DeviceEvents:
         if t_offset is None:
             t_offset = ends[0] if n else 0.0
         ev = cls(None, None, None, None, native=NativeColumns(x, y, t, p, stride, t_offset, p_kind))
+        ev.t_offset = float(t_offset)
         if n:   # as the kernels see them: (float)(t - t_offset), the subtraction in float64
             ev._t_ends = tuple(float(np.float32(np.float64(e) - t_offset)) for e in ends)
         return ev
@@ -206,12 +273,20 @@ class DeviceEvents:
                 self._p_absmax = _abs_max(self.p) if len(self) else 0.0
         return self._p_absmax
 
+    def fresh_view(self):
+        """The same resident columns as a NEW event set -- no buckets, no cached calls, what it knows about ts[0] / ts[-1] kept:
+        the state right after an upload (measurements of the first-use path: bench.py, tools/)."""
+        ev = DeviceEvents(*(self._cols or (None,) * 4), t_host=self._t_host, native=self.native)
+        ev._cols, ev._t_ends, ev.t_offset, ev.p_scale = self._cols, self._t_ends, self.t_offset, self.p_scale
+        return ev
+
     def slice(self, start, stop):
         """View of events [start:stop) (python slice semantics, no copy)."""
         sl = slice(start, stop)
         ev = DeviceEvents(self.x[sl], self.y[sl], self.t[sl], self.p[sl],
                           t_host=None if self._t_host is None else self._t_host[sl])
         ev.p_scale = self.p_scale
+        ev.t_offset = self.t_offset
         return ev
 
     def scaled(self, factor):
@@ -220,4 +295,5 @@ class DeviceEvents:
         ev.p_scale = self.p_scale * factor
         ev._buckets = self._buckets
         ev._p_absmax = self._p_absmax
+        ev.t_offset = self.t_offset
         return ev

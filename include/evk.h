@@ -602,6 +602,11 @@ int evk_minmax_normalise_f64(const double *image, int64_t npix, double *out, dou
 int evk_polarity_weights_f32(const float *p, int64_t n, float *pos, float *neg, void *stream);
 int evk_abs_max(const void *p, int elem_bytes, int64_t n, void *out8, void *stream);
 int evk_abs(const void *in, int elem_bytes, int64_t n, void *out, void *stream);
+/* evk_narrow_f64_f32: out[i] = (float)(in[i] - offset), the subtraction in float64; *inexact (optional, caller-zeroed) |= 1
+ * when some value is not exactly representable in float32 (also a NaN).  How the host layer takes the reference's float64
+ * host arrays (xs, ys, ts, ps of objectives.py / events_cmax.py) onto the float32 path: columns whose values are float32-exact
+ * as they are, the time stamps as differences from ts[-1] (DeviceEvents.from_arrays). */
+int evk_narrow_f64_f32(const double *in, int64_t n, double offset, float *out, uint32_t *inexact, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Event-sharded data parallelism: the path's only exchange step

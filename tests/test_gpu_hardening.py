@@ -542,3 +542,73 @@ def test_a_used_objective_can_be_copied_and_the_lifespan_cut_is_reused():
     oa.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
     cut2 = ev.__dict__["_lifespan_cut"][1]
     assert cut2 is not cut1 and len(cut2) < len(cut1)
+
+
+def test_float64_host_arrays_take_the_float32_path_with_relative_time():
+    """Round 6: the reference's host arrays are float64, its time stamps absolute seconds with microsecond resolution -- not
+    float32 values.  DeviceEvents.from_arrays narrows float64 columns ON THE DEVICE (evk_narrow_f64_f32, which also reports
+    whether they survived exactly) and keeps the time stamps as float32 differences from ts[-1] (subtracted in float64): the
+    events stay on the bucketed float32 path and the objective agrees with the float64 oracle far inside 1e-5; EVK_TIME_F64=exact
+    keeps the float64 columns (direct kernels); a user-supplied reference time is an absolute time either way."""
+    import os
+    import bench
+    import event_utils_amd as E
+    from event_utils_amd import _lib, _device as D
+    from oracle import reference_np as R
+    n, H, W = 120_000, 180, 240
+    x, y, t, p = bench.structured_scene(3, n, H, W)
+    x64, y64, p64 = x.astype(np.float64), y.astype(np.float64), p.astype(np.float64)
+    t64 = 1_600_000_000.0 + np.round(t.astype(np.float64) * 1e6) / 1e6
+    assert not np.array_equal(t64.astype(np.float32).astype(np.float64), t64)
+    # the kernel alone: values, offset, the exactness flag (a NaN counts as inexact, as in the host-side policy)
+    dev = D.require_gpu()
+    for col, off, want_flag in ((x64, 0.0, 0), (t64, 0.0, 1), (t64, float(t64[-1]), 1), (np.array([0.5, np.nan, 2.0]), 0.0, 1),
+                                (np.array([0.5, -3.0, 2.0 ** 30]), 0.0, 0)):
+        d = torch.from_numpy(col).to(dev)
+        out = torch.empty(len(col), dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("evk_narrow_f64_f32", D.ptr(d), len(col), off, D.ptr(out), D.ptr(flag), D.stream())
+        assert np.array_equal(out.cpu().numpy(), (col - off).astype(np.float32), equal_nan=True)
+        assert int(flag.item()) == (want_flag if off == 0.0 else int(flag.item()))
+    assert E.DeviceEvents.from_arrays(x64, y64, t64, p64).dtype == torch.float64        # single evaluations: exact float64 route
+    ev = E.DeviceEvents.from_arrays(x64, y64, t64, p64, relative_time=True)                 # what the optimisers ask for
+    assert ev.dtype == torch.float32 and ev.t_offset == float(t64[-1]) and ev.t_at(-1) == 0.0
+    assert np.array_equal(ev.t.cpu().numpy(), (t64 - t64[-1]).astype(np.float32)) and np.array_equal(ev.x.cpu().numpy(), x)
+    assert ev.t_at(0) == float(np.float32(t64[0] - t64[-1]))
+    w, q = E.linvel_warp(), np.array([38.0, -24.0])
+    o = E.variance_objective()
+    o.sensor_size = (H, W)
+    fv, gv = o.evaluate_function_and_gradient(q, ev, None, None, None, w, (H, W), 1.0)
+    ro = R.variance_objective()
+    ro.sensor_size = (H, W)
+    rf = ro.evaluate_function(q, x64, y64, t64, p64, R.linvel_warp(), (H, W), 1.0)
+    rg = ro.evaluate_gradient(q, x64, y64, t64, p64, R.linvel_warp(), (H, W), 1.0)
+    assert abs(float(fv) - float(rf)) <= 2e-6 * abs(float(rf)), (fv, rf)
+    assert np.max(np.abs(np.asarray(gv, float) - np.asarray(rg, float))) <= 1e-5 * np.max(np.abs(rg))
+    # an absolute reference time (here: the first event's) means the same thing on the relative column ...
+    o.t_ref = float(t64[0])
+    f_first = o.evaluate_function(q, ev, None, None, None, w, (H, W), 1.0)
+    os.environ["EVK_TIME_F64"] = "exact"
+    try:
+        ev64 = E.DeviceEvents.from_arrays(x64, y64, t64, p64)
+        assert ev64.dtype == torch.float64 and ev64.t_offset == 0.0
+        f_first64 = o.evaluate_function(q, ev64, None, None, None, w, (H, W), 1.0)      # ... as on the float64 one
+    finally:
+        os.environ.pop("EVK_TIME_F64")
+    assert abs(float(f_first) - float(f_first64)) <= 1e-5 * abs(float(f_first64)) and float(f_first) != float(fv)
+    # columns that ARE float32 values keep offset 0; a non-integer coordinate column keeps everything in float64
+    assert E.DeviceEvents.from_arrays(x64, y64, t.astype(np.float64), p64, relative_time=True).t_offset == 0.0
+    assert E.DeviceEvents.from_arrays(x64 + 0.1, y64, t64, p64, relative_time=True).dtype == torch.float64
+    # the optimisers: host arrays in, the float32 path inside, the reference's argmax out
+    from event_utils_amd.contrast_max import events_cmax
+    res = events_cmax._resident(x64, y64, t64, p64, w, o)[0]
+    assert res.dtype == torch.float32 and res.many_evaluations and res.t_offset == float(t64[-1])
+    o2 = E.variance_objective()
+    o2.sensor_size, o2.reference_exact = (H, W), False
+    a = events_cmax.optimize_contrast(x64, y64, t64, p64, w, o2, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0,
+                                      img_size=(H, W))
+    o3 = E.variance_objective()
+    o3.sensor_size, o3.reference_exact = (H, W), False
+    a64 = events_cmax.optimize_contrast(ev64, None, None, None, w, o3, optimizer="evk_bfgs", numeric_grads=False, blur_sigma=1.0,
+                                        img_size=(H, W))
+    assert np.linalg.norm(a - a64) < 2e-2 and np.linalg.norm(a - np.array([40.0, -25.0])) < 1.0, (a, a64)

@@ -23,7 +23,7 @@ q = np.array([38.0, -24.0])
 
 
 def fresh():
-    e = E.DeviceEvents(ev0.x, ev0.y, ev0.t, ev0.p, t_host=ev0._t_host)
+    e = ev0.fresh_view()
     e.many_evaluations = True
     return e
 

@@ -27,7 +27,7 @@ for H, W in ((180, 240), (480, 640)):
                          ("evk_bfgs", dict(numeric_grads=False, optimizer="evk_bfgs"))):
             for reused in (1, 150_000):
                 tiled.TILED_MIN_EVENTS_IWE_REUSED = reused
-                ev = E.DeviceEvents(ev0.x, ev0.y, ev0.t, ev0.p, t_host=ev0._t_host)   # (no buckets, no cached calls of the other mode)
+                ev = ev0.fresh_view()   # (no buckets, no cached calls of the other mode)
 
                 def run():
                     o = E.variance_objective()
