@@ -67,7 +67,8 @@ def events_to_image(xs, ys, ps, sensor_size=(180, 240), interpolation=None, padd
                       oob.ptr, D.stream())
             return c
 
-        if int_w and (n == 0 or float(np.abs(ps.astype(np.int64)).max()) * n < 2 ** 31):
+        # (two reductions without temporaries: abs(astype(int64)).max() took 18 ms at 10 M events, min() and max() take 3)
+        if int_w and (n == 0 or float(max(abs(int(ps.min())), abs(int(ps.max())))) * n < 2 ** 31):
             wd_ = D.to_device(ps, torch.int32)      # keep every device temporary alive until the launch
             canvas = count_image(wd_)
         else:
