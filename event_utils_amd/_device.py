@@ -67,7 +67,7 @@ def to_device(a, dtype, device=None):
         # (round 6) a column of another width goes up AS IT IS and is converted by a device copy: numpy's single-threaded astype
         # of 10 M int64 / float64 values takes 4.6 ms and the upload of its result 1.5 ms more, the raw upload + device
         # conversion 1.5 ms together.  Same values: C conversions between these types round / wrap alike on both sides.
-        if a.dtype.type in _RAW_UPLOAD and a.size and a.flags.writeable:
+        if a.dtype.type in _RAW_UPLOAD and a.dtype.isnative and a.size and a.flags.writeable:
             return torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=False).to(dtype)
         a = a.astype(want)
     a = np.ascontiguousarray(a)
