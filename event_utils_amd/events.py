@@ -162,8 +162,7 @@ class DeviceEvents:
                     exact[i] = exact[i] and not f
             if all(exact):
                 precision = "f32"
-            elif relative_time and exact[0] and exact[1] and exact[3] and raw[2] is not None and np.isfinite(cols[2][-1]) \
-                    and time_rebase():
+            elif relative_time and n and time_rebase() and cols[2].dtype.kind in "fiu" and np.isfinite(cols[2][-1]):
                 # Only the time stamps need float64 -- absolute seconds with microsecond resolution, what the reference's h5 /
                 # rosbag readers deliver.  The kernels only ever use time DIFFERENCES (t - t_ref, (t - ts[0]) / (ts[-1] - ts[0])),
                 # so the column is kept RELATIVE to ts[-1] (the default reference time, objectives.py:186), subtracted in float64
@@ -175,8 +174,14 @@ class DeviceEvents:
                 # IWE pixels of a sparse image by up to a few 1e-5 of the maximum, and the derivative images are discontinuous
                 # where a warped event crosses a pixel boundary.  Hence opt-in: the optimisers use it (only the argmax leaves
                 # them), get_iwe / evaluate_* on host arrays keep the float64 columns.  EVK_TIME_F64=exact: never.
-                t_offset = float(cols[2][-1])
-                _lib.call("evk_narrow_f64_f32", D.ptr(raw[2]), n, t_offset, D.ptr(dev_cols[2]), None, D.stream())
+                # Coordinates or weights that are not float32 values (undistorted sub-pixel coordinates) go the same way: their
+                # rounding -- <= ulp(x) / 2 -- is of the size of the float32 warp's own.
+                if not exact[2]:
+                    t_offset = float(cols[2][-1])
+                    if raw[2] is not None:
+                        _lib.call("evk_narrow_f64_f32", D.ptr(raw[2]), n, t_offset, D.ptr(dev_cols[2]), None, D.stream())
+                    else:       # (integer time stamps -- microseconds since the epoch: the subtraction is exact)
+                        dev_cols[2] = D.to_device((cols[2] - cols[2][-1]).astype(np.float32), torch.float32, device)
                 precision = "f32"
             else:
                 precision = "f64"

@@ -598,7 +598,15 @@ def test_float64_host_arrays_take_the_float32_path_with_relative_time():
     assert abs(float(f_first) - float(f_first64)) <= 1e-5 * abs(float(f_first64)) and float(f_first) != float(fv)
     # columns that ARE float32 values keep offset 0; a non-integer coordinate column keeps everything in float64
     assert E.DeviceEvents.from_arrays(x64, y64, t.astype(np.float64), p64, relative_time=True).t_offset == 0.0
-    assert E.DeviceEvents.from_arrays(x64 + 0.1, y64, t64, p64, relative_time=True).dtype == torch.float64
+    # sub-pixel coordinates that are not float32 values (undistorted events) and integer microsecond stamps: float64 for a single
+    # evaluation, the float32 route inside the optimisers (their rounding is of the size of the float32 warp's own)
+    assert E.DeviceEvents.from_arrays(x64 + 0.1, y64, t64, p64).dtype == torch.float64
+    sub = E.DeviceEvents.from_arrays(x64 + 0.1, y64, t64, p64, relative_time=True)
+    assert sub.dtype == torch.float32 and np.array_equal(sub.x.cpu().numpy(), (x64 + 0.1).astype(np.float32))
+    us = (np.round(t.astype(np.float64) * 1e6)).astype(np.int64) + 1_600_000_000_000_000
+    evus = E.DeviceEvents.from_arrays(x64, y64, us, p64, relative_time=True)
+    assert evus.dtype == torch.float32 and evus.t_offset == float(us[-1])
+    assert np.array_equal(evus.t.cpu().numpy(), (us - us[-1]).astype(np.float32))
     # the optimisers: host arrays in, the float32 path inside, the reference's argmax out
     from event_utils_amd.contrast_max import events_cmax
     res = events_cmax._resident(x64, y64, t64, p64, w, o)[0]
