@@ -455,7 +455,7 @@ def grid_cmax(xs, ys, ts, ps, roi_size=(20, 20), step=None, warp=None, obj=None,
     if not uses_fused_linvel(warp):
         raise NotImplementedError("grid_cmax is provided for the fused linear-flow warp (upstream hard-wires it too, :47)")
     # the events go to the device once; the cells are cut out of the resident columns there
-    everything = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps)
+    everything = xs if isinstance(xs, DeviceEvents) else DeviceEvents.from_arrays(xs, ys, ts, ps, relative_time=True)
     ex, ey = everything.x, everything.y
     resolution = [int(ey.max().item()) + 1, int(ex.max().item()) + 1]
     results_params, results_rois, results_f_evals = [], [], []
@@ -466,6 +466,7 @@ def grid_cmax(xs, ys, ts, ps, roi_size=(20, 20), step=None, warp=None, obj=None,
             if int(sel.sum().item()) <= min_events:
                 continue
             roi = DeviceEvents(ex[sel], ey[sel], everything.t[sel], everything.p[sel])
+            roi.t_offset = everything.t_offset
             obj = variance_objective(adaptive_lifespan=True, minimum_events=105)
             params = optimize_contrast(roi, None, None, None, warp, obj, numeric_grads=False, blur_sigma=2.0,
                                        img_size=resolution, grid_search_init=True)
