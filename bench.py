@@ -274,12 +274,22 @@ def main():
     }
     if dry:
         result["dry_run"] = "EVK_BENCH_DRY_RUN_ONE_GPU=1: %d ranks share cuda:0, collectives over gloo -- control flow only, NOT a measurement" % world
+    guard = None
     if use_dist:
+        # From here on everything is EXTRA information beside a headline that has been measured.  These legs have run on ONE
+        # GPU only (EVK_BENCH_FORCE_DIST, the gloo dry run): should one of them hang on the first multi-GPU node -- a collective
+        # that one rank never enters --, rank 0 still prints the line it has after EVK_BENCH_EXTRAS_TIMEOUT seconds
+        # (`extras_timed_out` says which leg it was in) and every rank leaves.  A WRONG result is different: the self-checks
+        # below end the run without a line (SystemExit), as before.
+        guard = _ExtrasGuard(result, rank, float(os.environ.get("EVK_BENCH_EXTRAS_TIMEOUT", "420")))
+        guard.leg = "check_sharded"
         result["rccl_ranks"] = 0 if dry else dist.get_world_size()       # (the dry run's collectives are gloo's)
         result.update(check_sharded(dist, dev, outs[(args.steps - 1) % 2], sets[(args.steps - 1) % COLUMN_SETS][3], n, world))
         if exchange_choice:
             result["exchange"] = exchange_choice
+        guard.leg = "oracle_self_check"
         result["oracle_self_check"] = oracle_self_check(dist, dev, _voxel_f32_device, sets[0], t_first, t_last, impl)
+        guard.leg = "breakdown"
         # ---- what the step is made of, so that a 1 -> N curve can be read without re-running: the kernels alone, the grid
         #      collective alone (same buffer shape, both forms), the two back to back, and the N = 1 entry point on this rank
         from event_utils_amd import distributed as DD
@@ -318,7 +328,7 @@ def main():
                 return ms(fn)
             finally:
                 tiled.FORCE["share_cu"] = prev
-        result["breakdown"] = {
+        breakdown = lambda: {   # noqa: E731
             "headline_ms": round(ms_per_step, 4), "compute_ms": ms(compute_only),
             "compute_share_cu_on_ms": with_share_cu(True, compute_only), "compute_share_cu_off_ms": with_share_cu(False, compute_only),
             "allreduce_ms": ms(allreduce_only),
@@ -336,6 +346,10 @@ def main():
                     "collective (it allocates the grid and reads ts[0]/ts[-1] on the device: ~1 % above compute_ms); "
                     "compute_share_cu_on / _off_ms = compute_ms with the partition geometry that leaves LDS for a collective's "
                     "workgroups forced on / off (tiled.FORCE['share_cu']; default: on in a multi-rank job)"}
+        try:   # extra information only: it must never cost the scaling run its JSON line
+            result["breakdown"] = breakdown()
+        except Exception as e:  # noqa: BLE001
+            result["breakdown"] = {"error": repr(e)}
     else:
         # the same work through the internal entry point (resident output, host-supplied ts[0]/ts[-1], no out-of-range
         # check) and through the public call with per-call synchronous error reporting
@@ -383,6 +397,7 @@ def main():
         result["public_api_deferred_errors_ms"] = round(el_deferred / args.steps * 1e3, 4)
 
     if use_dist and not args.no_cmax:
+        guard.leg = "c5"
         try:   # extra information only: it must never cost the scaling run its JSON line
             c5 = bench_c5(E, DeviceEvents, dist, rank, world, dev, impl)
         except Exception as e:  # noqa: BLE001
@@ -413,7 +428,9 @@ def main():
     if rank == 0 and world == 1 and not use_dist and not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline(x, y, t, p)
     if use_dist:
+        guard.leg = "final barrier"
         dist.barrier()
+        guard.done()
         dist.destroy_process_group()
     # RCCL's version banner sits in the C stdio buffer (stdout is a pipe) and would come out at exit, AFTER the JSON:
     # push everything out first so that the JSON is the last line of stdout
@@ -422,6 +439,36 @@ def main():
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+class _ExtrasGuard:
+    """Watchdog of the N > 1 line's extra legs (see main): after `seconds` rank 0 prints the line as it stands and every
+    rank leaves with os._exit -- a rank blocked inside a collective cannot be unwound any other way."""
+
+    def __init__(self, result, rank, seconds):
+        import threading
+        self.result, self.rank, self.seconds, self.leg = result, rank, seconds, "?"
+        self._finished = threading.Event()
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        self._thread.start()
+
+    def done(self):
+        self._finished.set()
+
+    def _watch(self):
+        if self._finished.wait(self.seconds):
+            return
+        try:
+            if self.rank == 0:
+                line = dict(self.result)
+                line["extras_timed_out"] = {"leg": self.leg, "after_seconds": self.seconds,
+                                            "note": "the headline above was complete; an extra leg did not return"}
+                sys.stdout.flush()
+                print(json.dumps(line), flush=True)
+        finally:
+            if self.rank != 0:
+                time.sleep(5.0)     # rank 0's line first: the launcher ends the job when any rank has left
+            os._exit(0)
 
 
 def roofline_block(kinfo, alg_bytes, n, tag):

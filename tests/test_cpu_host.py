@@ -475,3 +475,22 @@ def test_resident_events_and_objectives_copy_without_their_call_caches():
     o2 = copy.deepcopy(o)
     assert "_fast_memo" not in o2.__dict__
     assert o2.sensor_size == (12, 16) and o2.adaptive_lifespan and "_fast_memo" in o.__dict__
+
+
+def test_bench_extras_guard_prints_the_line_it_has_and_leaves():
+    """bench.py's watchdog of the N > 1 extra legs: when a leg does not return (a collective one rank never enters), rank 0
+    prints the line as it stands -- the headline measured before the extras -- with `extras_timed_out`, and the process
+    leaves with exit code 0; when the legs do return in time nothing is printed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "g = bench._ExtrasGuard({'metric': 'm', 'value': 1.5}, 0, float(sys.argv[1])); g.leg = 'breakdown'\n"
+            "time.sleep(float(sys.argv[2])); g.done(); time.sleep(0.3); print('finished')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code, "0.2", "30"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.5 and line["extras_timed_out"]["leg"] == "breakdown"
+    r = subprocess.run([sys.executable, "-c", code, "20", "0.1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "finished", (r.stdout, r.stderr)
