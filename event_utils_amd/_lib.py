@@ -91,6 +91,8 @@ SIGNATURES = {
     "evk_polarity_weights_f32": [P, c_int64, P, P, P],
     "evk_narrow_f64_f32": [P, c_int64, c_double, P, P, P],
     "evk_abs_max": [P, c_int, c_int64, P, P],
+    "evk_timestamp_planes_init_f32": [P, c_int64, P],
+    "evk_timestamp_finalise_f32": [P, c_int64, P, P, P],
     "evk_abs": [P, c_int, c_int64, P, P],
     "evk_bucket_num_tiles": [c_int, c_int, c_int, c_int],
     "evk_bucket_events_f32": [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, c_int, P],
@@ -109,6 +111,8 @@ SIGNATURES = {
                                c_uint32, P],
     "evk_image2_bilinear_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
                                 c_uint32, P],
+    "evk_timestamp_images2_f32": [P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, c_int,
+                                  c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_comm_unique_id": [P],
     "evk_comm_init": [P, c_int, c_int, P],
     "evk_comm_destroy": [P],
@@ -138,6 +142,7 @@ _SPECIAL = {
     "evk_voxel2_fits": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "evk_num_cu": ([], c_int),
     "evk_image2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
+    "evk_timestamp_images2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
     "evk_dense_rank_scratch_bytes": ([c_int64], c_int64),
     "evk_spectral_scratch_bytes": ([c_int, c_int], c_int64),
     "evk_minmax_scratch_bytes": ([], c_int64),

@@ -54,9 +54,36 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_narrow_f64(const double *__restri
     if (inexact && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1u);
 }
 
+// the four planes of the average-timestamp images before / after their events (image.py:266-283): time planes 0, count
+// planes ONE (upstream quirk: img_*_cnt = torch.ones); then cnt[cnt == 0] = 1 and time / cnt, float32
+__global__ void __launch_bounds__(EVK_BLOCK) k_ts_planes_init(float *__restrict__ out4, int64_t plane) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * plane; i += (int64_t)gridDim.x * blockDim.x)
+        out4[i] = ((i / plane) & 1) ? 1.0f : 0.0f;
+}
+__global__ void __launch_bounds__(EVK_BLOCK) k_ts_finalise(const float *__restrict__ in4, int64_t plane, float *__restrict__ pos,
+                                                          float *__restrict__ neg) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (int64_t)gridDim.x * blockDim.x) {
+        const float cp = in4[plane + i], cn = in4[3 * plane + i];
+        pos[i] = in4[i] / (cp == 0.0f ? 1.0f : cp);
+        neg[i] = in4[2 * plane + i] / (cn == 0.0f ? 1.0f : cn);
+    }
+}
+
 }  // namespace evk
 
 using namespace evk;
+
+extern "C" int evk_timestamp_planes_init_f32(float *out4, int64_t plane_elems, void *stream) {
+    if (plane_elems <= 0 || !out4) return EVK_EINVAL;
+    k_ts_planes_init<<<stream_grid(4 * plane_elems), EVK_BLOCK, 0, (hipStream_t)stream>>>(out4, plane_elems);
+    return launch_status();
+}
+
+extern "C" int evk_timestamp_finalise_f32(const float *planes4, int64_t plane_elems, float *pos, float *neg, void *stream) {
+    if (plane_elems <= 0 || !planes4 || !pos || !neg) return EVK_EINVAL;
+    k_ts_finalise<<<stream_grid(plane_elems), EVK_BLOCK, 0, (hipStream_t)stream>>>(planes4, plane_elems, pos, neg);
+    return launch_status();
+}
 
 extern "C" int evk_narrow_f64_f32(const double *in, int64_t n, double offset, float *out, uint32_t *inexact, void *stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return EVK_EINVAL;

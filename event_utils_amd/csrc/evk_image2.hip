@@ -120,6 +120,70 @@ struct SrcImgI32 {
     }
 };
 
+// x, y, t, p float32: the average-timestamp images (image.py:219-353; V2_FMT_IMGT).  Every event is splat bilinearly, with
+// weight nts (its normalised time stamp: mode 0 (t - ta) / td, 1 (-t + ta) / td, 2 t) into the time image of its class and
+// with weight 1 into the count image of its class -- positive / non-positive polarity.  Upstream quirk kept (as in the direct
+// kernel, evk_scatter.hip:k_timestamp_images_f32): an event with x >= clipx or y >= clipy is moved to pixel (0, 0) -- the mask
+// multiplies the INDICES -- but keeps its fractions and its weights (masked_ps is never used, image.py:264,336).
+struct SrcTsF32 {
+    static constexpr int G = 4, XYW = 8, TPW = 8;
+    const float *x, *y, *t, *p;
+    float clipx, clipy;
+    int mode;
+    float ta, td;
+    float *out4;   // (4, h, wd): time+ | count+ | time- | count-; the rare path adds to it directly
+    int h, wd;
+    template <bool NT = false>
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = load_col16<NT>(x, ev0, gl), b = load_col16<NT>(y, ev0, gl);
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    template <bool NT = false>
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = load_col16<NT>(t, ev0, gl), b = load_col16<NT>(p, ev0, gl);
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    }
+    // Tile of (floor(x), floor(y)) -- of pixel (0, 0) for a masked event -- and the coordinates relative to that tile's origin
+    // (a masked event: its fractions, i.e. pixel (0, 0) of tile 0 with dx, dy intact).  -3 (xr, yr = x, y): an event the LDS
+    // windows cannot take (a pixel or its right / lower neighbour outside the image, non-finite coordinates) -> rare_ts().
+    __device__ __forceinline__ int key_rel(const uint32_t *r, int e, const TileGridG &g, float &xr, float &yr) const {
+        const float xf = __uint_as_float(r[e]), yf = __uint_as_float(r[4 + e]);
+        const float fx = floorf(xf), fy = floorf(yf);
+        const bool masked = (xf >= clipx) | (yf >= clipy);
+        const bool finite = fabsf(xf) <= 3.0e38f && fabsf(yf) <= 3.0e38f;
+        const bool inwin = (fx >= 0.0f) & (fx <= (float)(g.dom_w - 2)) & (fy >= 0.0f) & (fy <= (float)(g.dom_h - 2));
+        const bool ok = finite & (masked | inwin);
+        const int px = (ok & !masked) ? (int)fx : 0, py = (ok & !masked) ? (int)fy : 0;
+        const int tx = tile_of(px, g.ix), ty = tile_of(py, g.iy);
+        xr = ok ? (masked ? xf - fx : xf - (float)__mul24(tx, g.tw)) : xf;   // exact either way
+        yr = ok ? (masked ? yf - fy : yf - (float)__mul24(ty, g.th)) : yf;
+        return ok ? __mul24(ty, g.tiles_x) + tx : -3;
+    }
+    __device__ __forceinline__ float nts_of(float tf) const {
+        return mode == 0 ? (tf - ta) / td : (mode == 1 ? (-tf + ta) / td : tf);
+    }
+    __device__ __forceinline__ uint32_t w_bits(const uint32_t *r, int e) const { return __float_as_uint(nts_of(__uint_as_float(r[e]))); }
+    // pos_events_mask = ps > 0, neg_events_mask = ps <= 0 (image.py:258-259); a NaN polarity is in neither
+    __device__ __forceinline__ uint32_t cls(const uint32_t *r, int e) const {
+        const float pv = __uint_as_float(r[4 + e]);
+        return pv > 0.0f ? 0u : (pv <= 0.0f ? 1u : 2u);
+    }
+    // the direct kernel's per-event code (evk_scatter.hip, k_timestamp_images_f32); false = IndexError
+    __device__ __forceinline__ bool rare_ts(float xf, float yf, const uint32_t *r, int e) const {
+        const uint32_t k = cls(r, e);
+        if (k == 2u) return true;
+        const float mask = (!(xf >= clipx) && !(yf >= clipy)) ? 1.0f : 0.0f;
+        const float fx = floorf(xf), fy = floorf(yf);
+        Splat s;
+        s.dx = xf - fx;
+        s.dy = yf - fy;
+        s.px = (long long)(fx * mask);
+        s.py = (long long)(fy * mask);
+        float *val = out4 + (int64_t)(2u * k) * h * wd, *cnt = val + (int64_t)h * wd;
+        return splat_iwe(val, h, wd, s, nts_of(__uint_as_float(r[e]))) && splat_iwe(cnt, h, wd, s, 1.0f);
+    }
+};
+
 #ifndef IMG_WG
 #define IMG_WG 512    // threads of a tile workgroup (768 and up: the chunk lists no longer fit the 64 KB of static LDS)
 #endif
@@ -495,6 +559,117 @@ __global__ void __launch_bounds__(WG) k_image_tiles_b(const uint2 *__restrict__ 
     });
 }
 
+// ---- average-timestamp images: four windows per tile (time and count of the positive / of the non-positive events) ----
+// The bilinear kernel with the record's two sign bits read as the event's class and the side run as its normalised time
+// stamp: four float64 LDS atomics into the class's time window (nts (1 - dx) (1 - dy) ..., float32 products in the reference's
+// order, image.py:111-114) and four fixed-point ones (2^-30 steps, as k_image_tiles_b's unit weights) into its count window.
+template <int WG>
+__global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__ rec, const uint32_t *__restrict__ side,
+                                                       const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                       TileGridG g, Part2 q, int flags, float *__restrict__ out4,
+                                                       float *__restrict__ staging) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ts_smem[];
+    acc_t *const win = reinterpret_cast<acc_t *>(ts_smem);   // [4][wcells]: time+ | count+ | time- | count-
+    __shared__ uint2 cseg[WG / 64][IMG_CAP + 1];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    ImgItem it;
+    if (!img_item(index, ntiles, q, flags, it)) return;
+    const bool fixed = !(flags & EVK_IMAGE2_NO_FIXED);
+    const int tw = g.tw, th = g.th;
+    const int ww = tw + 1, wh = th + 1, wpitch = ww | 1, wcells = wpitch * wh;
+    for (int i = threadIdx.x; i < 4 * wcells; i += WG) win[i] = 0.0;
+    unsigned long long *const winq = reinterpret_cast<unsigned long long *>(win);
+    auto one = [&](auto fixed_tag, uint32_t xb, uint32_t yb, uint32_t wside) {
+        constexpr bool FIXED = decltype(fixed_tag)::value;
+        const uint32_t k = (xb >> 31) | ((yb >> 31) << 1);
+        if (k >= 2u) return;   // a NaN polarity: in neither class
+        const float xr = __uint_as_float(xb & 0x7FFFFFFFu), yr = __uint_as_float(yb & 0x7FFFFFFFu);
+        const float fx = floorf(xr), fy = floorf(yr);
+        const float dx = xr - fx, dy = yr - fy;
+        const float ax = 1.0f - dx, ay = 1.0f - dy;
+        const int c0 = __mul24((int)fy, wpitch) + (int)fx;
+        acc_t *const val = win + __mul24((int)(2u * k), wcells);
+        const float nts = __uint_as_float(wside);
+        const float ta_ = nts * ax, td_ = nts * dx;
+        lds_add(val + c0, ta_ * ay), lds_add(val + c0 + 1, td_ * ay), lds_add(val + c0 + wpitch, ta_ * dy),
+            lds_add(val + c0 + wpitch + 1, td_ * dy);
+        if constexpr (FIXED) {
+            unsigned long long *const cnt = winq + __mul24((int)(2u * k + 1u), wcells);
+            const float wa = IMG_FIX_ONE * ax, wd = IMG_FIX_ONE * dx;   // the weight is 1.0: 1.0f * ax == ax
+            auto addq = [&](int c, float v) {
+                __hip_atomic_fetch_add(cnt + c, (unsigned long long)(long long)__float2int_rn(v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            addq(c0, wa * ay), addq(c0 + 1, wd * ay), addq(c0 + wpitch, wa * dy), addq(c0 + wpitch + 1, wd * dy);
+        } else {
+            acc_t *const cnt = val + wcells;
+            lds_add(cnt + c0, ax * ay), lds_add(cnt + c0 + 1, dx * ay), lds_add(cnt + c0 + wpitch, ax * dy),
+                lds_add(cnt + c0 + wpitch + 1, dx * dy);
+        }
+    };
+    auto run = [&](auto fixed_tag) {
+        img_records<WG, IMG_U, RecB>(
+            table, q, it, cseg,
+            [&](uint32_t pos) -> RecB {
+                RecB v;
+                v.r = load_u4(rec + pos);
+                v.w = load_u2(side + pos);
+                return v;
+            },
+            [&](const RecB &v, uint32_t pos, uint32_t end) {
+                one(fixed_tag, v.r.x, v.r.y, v.w.x);
+                if (pos + 1 < end) one(fixed_tag, v.r.z, v.r.w, v.w.y);
+            });
+    };
+    if (fixed) run(std::true_type{});
+    else run(std::false_type{});
+    __syncthreads();
+    const int tx0 = (it.tile % g.tiles_x) * tw, ty0 = (it.tile / g.tiles_x) * th;
+    const int dcells = ww * wh;   // dense cells of one window
+    const uint32_t mw = magic_div((uint32_t)ww);
+    const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    auto lds_cell = [&](int pl, int c) -> float {
+        const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww, l = pl * wcells + row * wpitch + col;
+        if (fixed && (pl & 1)) return (float)((double)(long long)winq[l] * (1.0 / (double)IMG_FIX_ONE));
+        return (float)win[l];
+    };
+    // interior pixels belong to this window alone (plain read-modify-write), the ring is shared with the neighbours' windows
+    auto flush = [&](auto value_of) {
+        for (int i = threadIdx.x; i < 4 * dcells; i += WG) {
+            const int pl = i / dcells, c = i - pl * dcells;
+            const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww;
+            const int X = tx0 + col, Y = ty0 + row;
+            if (X < g.dom_w && Y < g.dom_h) {
+                float *o = out4 + pl * plane + (int64_t)Y * g.dom_w + X;
+                const float v = value_of(pl, c);
+                if (row == 0 || row == th || col == 0 || col == tw) {
+                    if (v != 0.0f || v != v) atomic_add(o, v);
+                } else {
+                    *o += v;
+                }
+            }
+        }
+    };
+    if (it.nparts == 1) {
+        flush(lds_cell);
+        return;
+    }
+    const int64_t stride = v2_staging_stride(4 * dcells);
+    float *mine = staging + (int64_t)it.item * stride;
+    for (int i = threadIdx.x; i < 4 * dcells; i += WG) {
+        const int pl = i / dcells;
+        __hip_atomic_store(mine + i, lds_cell(pl, i - pl * dcells), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!img_last_part(index, ntiles, it)) return;
+    const float *parts = staging + (int64_t)it.first_item * stride;
+    flush([&](int pl, int c) {
+        float sum = 0.0f;
+        for (uint32_t pp = 0; pp < it.nparts; ++pp)
+            sum += __hip_atomic_load(parts + (int64_t)pp * stride + pl * dcells + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return sum;
+    });
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 // One geometry for the images: 1024 threads x 8 events, sub-chunks of 8 K events (68 KB of LDS with 4-byte records,
 // 100 KB with the 12 bytes of the bilinear format).
@@ -511,8 +686,9 @@ struct ImgCall {
     V2Layout L;
     int ntiles;
 };
+#define IMG_TS_PLANES 6   // staging of a cut tile's piece, in tw x th floats x 2: four (tw + 1) x (th + 1) float windows fit
 static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile_h, int flags, const void *out, uint32_t *index,
-                     void *scratch, int64_t scratch_bytes, uint32_t *host_report) {
+                     void *scratch, int64_t scratch_bytes, uint32_t *host_report, int planes = 2) {
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL2_PARTITION_ONLY | EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER |
                       EVK_IMAGE2_NO_FIXED;
     if (make_grid_g(ic.g, h, wd, tile_w, tile_h) != EVK_OK || !out || !index || !scratch || n <= 0 ||
@@ -524,7 +700,7 @@ static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile
         (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX)
         return EVK_EINVAL;
     const bool small = img_small(ic.ntiles);
-    ic.L = v2_layout(ic.ntiles, n, 2, tile_w, tile_h, small);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
+    ic.L = v2_layout(ic.ntiles, n, planes, tile_w, tile_h, small);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
     if (scratch_bytes < ic.L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
     ic.q = v2_geometry(n, ic.ntiles, small);
@@ -610,5 +786,43 @@ extern "C" int evk_image2_bilinear_f32(const float *x, const float *y, const flo
         k_image_tiles_b<IMG_WG><<<v2_max_items(n, ic.ntiles), IMG_WG, 0, s>>>(
             (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
             ic.q, flags, img, (float *)(sb + ic.L.staging));
+    return launch_status();
+}
+
+extern "C" int64_t evk_timestamp_images2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h) {
+    if (ntiles <= 0 || n < 0 || tile_w <= 0 || tile_h <= 0) return 0;
+    return v2_layout(ntiles, n, IMG_TS_PLANES, tile_w, tile_h, img_small(ntiles)).total;
+}
+
+extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
+                                         float clipx, float clipy, int mode, float ta, float td, int tile_w, int tile_h,
+                                         int flags, float *out4, uint32_t *index, void *scratch, int64_t scratch_bytes,
+                                         uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream) {
+    if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
+    if (mode < 0 || mode > 2 || (flags & EVK_VOXEL_OVERWRITE)) return EVK_EINVAL;   // (the windows are ADDED to the images)
+    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    ImgCall ic;
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, out4, index, scratch, scratch_bytes, host_report, IMG_TS_PLANES);
+    if (rc != EVK_OK) return rc;
+    if (h < 2 || wd < 2) return EVK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY))
+        img_partition<V2_FMT_IMGT>(SrcTsF32{x, y, t, p, clipx, clipy, mode, ta, td, out4, h, wd}, n, ic, index, scratch, oob,
+                                   host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
+        const int wcells = ((tile_w + 1) | 1) * (tile_h + 1);
+        const size_t lds = (size_t)4 * wcells * sizeof(acc_t);
+        static std::once_flag once[64];   // per device: the attribute belongs to the loaded code object
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 63], [] {
+            (void)hipFuncSetAttribute((const void *)k_image_tiles_ts<IMG_WG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * IMG_WIN_MAX * (int)sizeof(acc_t));
+        });
+        k_image_tiles_ts<IMG_WG><<<v2_max_items(n, ic.ntiles), IMG_WG, lds, s>>>(
+            (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, out4, (float *)(sb + ic.L.staging));
+    }
     return launch_status();
 }

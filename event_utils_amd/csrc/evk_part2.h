@@ -170,6 +170,11 @@ struct Part2 {
 //   handed to the column source's `rare()` -- the direct kernel's global atomics -- by this kernel itself.
 #define V2_FMT_IMGN 1
 #define V2_FMT_IMGB 12
+// REC = V2_FMT_IMGT (round 6: the average-timestamp images, image.py:219-353 -- four bilinear splats per event): the IMGB
+//   record, its two sign bits carrying the event's CLASS instead of a weight code -- 0 = positive, 1 = non-positive polarity,
+//   2 = neither (NaN: contributes nothing) -- and the side run, always written, the event's normalised time stamp (the
+//   column source's w_bits).  16 B/event read, 12 written.  Rare events go to the column source's rare_ts().
+#define V2_FMT_IMGT 13
 // REC = V2_FMT_VOX8W: the 8-byte voxel records, with the EXACT polarities of a sub-chunk staged in LDS (4 more bytes per
 // event) and written as a second dense run when one of them is wide -- instead of a scattered 4-byte store per wide
 // polarity (arbitrary float32 weights: partition 78 -> ~50 us at 10 M events).  The geometry with 8 K-event sub-chunks
@@ -179,7 +184,7 @@ struct Part2 {
 #define V2_DELTA_LIMIT (1u << 20)
 #define V2_CODE_SHIFT 10
 // bytes of LDS per event of the sorted buffer
-__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : (rec == V2_FMT_VOX8W ? 12 : rec); }
+__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : ((rec == V2_FMT_VOX8W || rec == V2_FMT_IMGT) ? 12 : rec); }
 // LIVE (round 5; evk_voxel_live.hip): the runs are consumed WHILE the partition is still sorting, by a second kernel on a
 // second stream (k_voxel_live: two tiles per workgroup, one workgroup per CU beside this kernel's).  What that needs here:
 // the table row of a sub-chunk leaves with its run, as write-through 16-byte stores out of an LDS copy (plain 4-byte stores
@@ -197,9 +202,10 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                                                             uint32_t seq, uint32_t *live_progress = nullptr,
                                                             uint32_t live_epoch = 0) {
     static_assert(!LIVE || (REC == 8 && V2_STORE_SC1), "the live consumer reads 8-byte records written through");
-    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_VOX8W, "record format");
+    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_VOX8W, "record format");
     constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
-    constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB;   // exact weights staged in LDS, dense side run on demand
+    constexpr bool IMGBT = REC == V2_FMT_IMGB || REC == V2_FMT_IMGT;   // bilinear formats: {x, y} relative to the tile + a side run
+    constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || IMGBT;   // exact weights staged in LDS, dense side run on demand
     constexpr bool VOX = R8 || REC == 4;                      // voxel formats: a time column, t_norm in the record
     constexpr int LB = v2_fmt_lds_bytes(REC);
     uint2 *const rec = static_cast<uint2 *>(rec_);            // REC 8 / IMGB: 8-byte records | REC 4 / IMGN: viewed as uint32 below
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     // atomic, so that its ticket is taken behind it -- and the last of these tickets publishes the report: most of a pass
     // and the plan's tail earlier than the end of the kernel, which is what lets the host's ~20 us between two calls
     // disappear behind the tile kernel.  (Not the bilinear image format: its rare path can still drop events in the placement.)
-    constexpr bool EARLY = REC != V2_FMT_IMGB;
+    constexpr bool EARLY = !IMGBT;
     uint32_t early_prev = 0;   // lane 0: what its early-report ticket returned
     // (three steps, none of which makes a wave wait where the others need it: the count leaves as a no-return atomic behind the
     // last pass's histogram barrier; the ticket is taken behind that pass's "everything outstanding has landed" wait, i.e. when
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
     auto write_out = [&]() {   // the previous pass's run(s) of records
         if (V2_ABLATE_A >= 4) {
             const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
-            if constexpr (R8 || REC == V2_FMT_IMGB)
+            if constexpr (R8 || IMGBT)
                 store_run(src, reinterpret_cast<uint4 *>(rec + lo_prev), (int)((kept_prev + 1) >> 1));
             else
                 store_run(src, reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(rec_) + lo_prev), (int)((kept_prev + 3) >> 2));
@@ -377,13 +383,13 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             for (int e = 0; e < G; ++e) {
                 uint32_t cell = 0;
                 int key;   // (of stale words beyond the stream)
-                if constexpr (REC == V2_FMT_IMGB) key = c.key_rel(xyr + C::XYW * k, e, g, xr[G * k + e], yr[G * k + e]);
+                if constexpr (IMGBT) key = c.key_rel(xyr + C::XYW * k, e, g, xr[G * k + e], yr[G * k + e]);
                 else key = c.key_of(xyr + C::XYW * k, e, g, cell);
                 kl[G * k + e] = ((key >= 0) & (e < nv)) ? (((uint32_t)key << V2_LB) | cell) : 0xFFFFFFFFu;
                 // image sources: -1 = outside the image (counted: the reference raises), -2 = contributes nothing, -3 = rare
                 if constexpr (VOX) dropped += ((key < 0) & (e < nv)) ? 1u : 0u;
                 else dropped += ((key == -1) & (e < nv)) ? 1u : 0u;
-                if constexpr (REC == V2_FMT_IMGB) rare |= ((key == -3) & (e < nv)) ? (1u << (G * k + e)) : 0u;
+                if constexpr (IMGBT) rare |= ((key == -3) & (e < nv)) ? (1u << (G * k + e)) : 0u;
                 asm volatile("" : "+v"(dropped));   // counted HERE: sunk to the end of the loop body it kept a copy of every key alive
                 // one event at a time: GCN issues dependent VALU instructions back to back, while interleaving the EPT
                 // independent chains (what the scheduler does for ILP) keeps ~4 temporaries per event live at once
@@ -582,6 +588,26 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 for (int s2 = 0; s2 < EPT; ++s2)
                     if (rare >> s2 & 1u)
                         dropped += c.rare(xr[s2], yr[s2], __uint_as_float(c.w_bits(tpr + C::TPW * (s2 / G), s2 % G))) ? 0u : 1u;
+            }
+            rare = 0;
+        } else if constexpr (REC == V2_FMT_IMGT) {
+            bool any_t = false;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                if (kl[s2] != 0xFFFFFFFFu) {
+                    const uint32_t pos = slot_of(s2);
+                    const uint32_t cls = c.cls(tpr + C::TPW * (s2 / G), s2 % G);   // 0 / 1 / 2: positive / non-positive / neither
+                    sorted[pos] = make_uint2((__float_as_uint(xr[s2]) & 0x7FFFFFFFu) | ((cls & 1u) << 31),
+                                             (__float_as_uint(yr[s2]) & 0x7FFFFFFFu) | ((cls >> 1) << 31));
+                    sortedp[pos] = c.w_bits(tpr + C::TPW * (s2 / G), s2 % G);      // the normalised time stamp
+                    any_t = true;
+                }
+            }
+            if (any_t) tmp[65] = 1u;   // the side run of this sub-chunk is always written
+            if (__any(rare != 0u)) {   // rare: pixels that wrap or raise in index_put_ -- the direct kernel's global atomics
+#pragma unroll
+                for (int s2 = 0; s2 < EPT; ++s2)
+                    if (rare >> s2 & 1u) dropped += c.rare_ts(xr[s2], yr[s2], tpr + C::TPW * (s2 / G), s2 % G) ? 0u : 1u;
             }
             rare = 0;
         } else {

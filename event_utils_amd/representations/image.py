@@ -230,14 +230,29 @@ def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interp
     quirk, image.py:269,271: img_*_cnt = torch.ones)."""
     dev = xd.device
     clipx, clipy = _clip_thresholds(img_size, clip_out_of_range, interpolation, padding)
-    out = torch.zeros((4,) + tuple(img_size), dtype=torch.float32, device=dev)
-    out[1].fill_(1.0)
-    out[3].fill_(1.0)
+    out = torch.empty((4,) + tuple(img_size), dtype=torch.float32, device=dev)
+    _lib.call("evk_timestamp_planes_init_f32", D.ptr(out), int(img_size[0]) * int(img_size[1]), D.stream())
     oob = D.OobCounter(dev)
-    _lib.call("evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), xd.shape[0], img_size[0], img_size[1],
-              clipx, clipy, mode, float(ta), float(tdiv), D.ptr(out), oob.ptr, D.stream())
+    from .. import tiled
+    n = xd.shape[0]
+    # Above the crossover: one partition + four LDS windows per tile (evk_image2.hip, round 6); below it, or for columns the
+    # one-pass path cannot take (unaligned views), eight global atomics per event (evk_scatter.hip).  Same semantics either way.
+    impl = tiled.default_impl()
+    fast = (tiled.can_tile_image((xd, yd, td, pd), impl, True) and xd.shape == yd.shape == td.shape == pd.shape
+            and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_TIMESTAMP)
+            and tiled.timestamp_images2(xd, yd, td, pd, n, img_size[0], img_size[1], clipx, clipy, mode, ta, tdiv, out, oob))
+    if not fast:
+        _lib.call("evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, img_size[0], img_size[1],
+                  clipx, clipy, mode, float(ta), float(tdiv), D.ptr(out), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),))
     return out
+
+
+def _timestamp_finalise(planes):
+    """cnt[cnt == 0] = 1; time / cnt for both classes (image.py:278-282) -> (2, H, W) float32 device tensor [pos, neg]."""
+    res = torch.empty((2,) + tuple(planes.shape[1:]), dtype=torch.float32, device=planes.device)
+    _lib.call("evk_timestamp_finalise_f32", D.ptr(planes), planes[0].numel(), D.ptr(res[0]), D.ptr(res[1]), D.stream())
+    return res
 
 
 def events_to_timestamp_image(xn, yn, ts, pn, device=None, sensor_size=(180, 240), clip_out_of_range=True,
@@ -257,11 +272,8 @@ def events_to_timestamp_image(xn, yn, ts, pn, device=None, sensor_size=(180, 240
     else:
         mode, ta, tdiv = 2, 0.0, 1.0
     img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)
-    img = img.cpu().numpy()
-    img_pos, img_pos_cnt, img_neg, img_neg_cnt = img[0], img[1], img[2], img[3]
-    img_pos_cnt[img_pos_cnt == 0] = 1
-    img_neg_cnt[img_neg_cnt == 0] = 1
-    return img_pos / img_pos_cnt, img_neg / img_neg_cnt
+    res = _timestamp_finalise(img).cpu().numpy()
+    return res[0], res[1]
 
 
 def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(180, 240), clip_out_of_range=True,
@@ -277,14 +289,13 @@ def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(18
     img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    t_first, t_last = (np.float32(e) for e in D.ends(td))
+    # (ts[0], ts[-1]: from the caller's tensor when it lives on the host -- no device round trip)
+    t_first, t_last = (np.float32(e) for e in (D.ends(td) if (ts.is_cuda or ts.dim() != 1) else D.ends(ts[[0, -1]].to(torch.float32))))
     tdiv = np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
     mode, ta = (1, t_last) if timestamp_reverse else (0, t_first)
     img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)
-    img_pos, img_pos_cnt, img_neg, img_neg_cnt = img[0], img[1], img[2], img[3]
-    img_pos_cnt[img_pos_cnt == 0] = 1
-    img_neg_cnt[img_neg_cnt == 0] = 1
-    return img_pos.div(img_pos_cnt).to(device), img_neg.div(img_neg_cnt).to(device)
+    res = _timestamp_finalise(img)
+    return res[0].to(device), res[1].to(device)
 
 
 # ---- the stateful image classes (image.py:355-396) ------------------------------------------------------------------

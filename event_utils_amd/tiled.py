@@ -445,6 +445,8 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
 # the public call is host-bound below that and cheaper to issue on the one-pass path (see above): any count
 TILED_MIN_EVENTS_IMAGE = 1
 TILED_MIN_EVENTS_IMAGE_BILINEAR = 1
+# the average-timestamp images (round 6): eight global atomics per event at ~21 G/s against the two launches' ~20 us
+TILED_MIN_EVENTS_TIMESTAMP = 50_000
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
@@ -482,6 +484,41 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     else:
         _rezero_on_failure(index, lambda: _lib.call("evk_image2_%s_f32" % ("bilinear" if kind == "bilinear" else "nearest"),
                                                     D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, clipx, clipy, *tail))
+    return True
+
+
+def timestamp_images2(xd, yd, td, pd, n, H, W, clipx, clipy, mode, ta, tdiv, out4, oob, stage=0):
+    """evk_timestamp_images2_f32: the four average-timestamp planes of the device columns ADDED to `out4` (4, H, W) on the one-pass
+    partition + LDS windows (image.py:219-353).  Returns False when the one-pass path has no tiling for this image (the caller
+    then uses the direct kernel, evk_timestamp_images_f32)."""
+    L = _lib.lib()
+    shape = voxel2_shape(H, W, 1)
+    if shape is None or H < 2 or W < 2:
+        return False
+    tw, th = shape
+    if (tw + 2) * (th + 1) > 2048:
+        return False
+    dev = out4.device
+    ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
+    key = ("timestamp2", ntiles, n, tw, th)
+    sizes = _staging_bytes.get(key)
+    if sizes is None:
+        sizes = (int(L.evk_voxel2_index_len(ntiles, n)), int(L.evk_timestamp_images2_scratch_bytes(ntiles, n, tw, th)))
+        if sizes[0] <= 0:
+            return False
+        _staging_bytes[key] = sizes
+    index = _zbuf("image2_index", sizes[0], dev)
+    scratch = _buf("voxel2_scratch", sizes[1], dev)
+    flags = stage
+    if not FORCE["image_fixed"]:
+        flags |= _lib.EVK_IMAGE2_NO_FIXED
+    if not FORCE["xcd_order"]:
+        flags |= 64
+    report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
+    _rezero_on_failure(index, lambda: _lib.call(
+        "evk_timestamp_images2_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, H, W, clipx, clipy, mode, float(ta), float(tdiv),
+        tw, th, flags, D.ptr(out4), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None,
+        report, seq, D.stream()))
     return True
 
 

@@ -441,6 +441,17 @@ int evk_image2_nearest_f32(const float *x, const float *y, const float *w, int64
 int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
                             float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
                             int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+/* evk_timestamp_images_f32 (above; events_to_timestamp_image[_torch], image.py:219-353: eight global atomics per event) on
+ * the same design (round 6): one partition -- 16 B/event read, a 12-byte record {x, y relative to the tile; the event's
+ * class in their sign bits; its normalised time stamp} moved once -- and a tile kernel with four LDS windows per tile
+ * (time / count of the positive and of the non-positive events).  Arguments x .. td and the meaning of *oob as
+ * evk_timestamp_images_f32, including the upstream quirk (a clipped event lands on pixel (0, 0) with its weights intact);
+ * the rest as evk_image2_bilinear_f32, with evk_timestamp_images2_scratch_bytes for `scratch`.  out4 = (4, h, wd), ADDED to. */
+int64_t evk_timestamp_images2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h);
+int evk_timestamp_images2_f32(const float *x, const float *y, const float *t, const float *p, int64_t n, int h, int wd,
+                              float clipx, float clipy, int mode, float ta, float td, int tile_w, int tile_h, int flags,
+                              float *out4, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                              uint32_t *host_report, uint32_t seq, void *stream);
 
 /* get_iwe (linear flow) on bucketed records (EVK_KEY_FLOOR_CLAMP over a (dom_h, dom_w) domain covering the events):
  * one workgroup per (work item, time slice) accumulates a (win_h x win_w) LDS window (tile + flow halo, origin shifted
@@ -601,6 +612,11 @@ int evk_minmax_normalise_f64(const double *image, int64_t npix, double *out, dou
  * evk_abs: out[i] = |in[i]| (get_iwe's use_polarity=False, objectives.py:184-185); float32 or float64. */
 int evk_polarity_weights_f32(const float *p, int64_t n, float *pos, float *neg, void *stream);
 int evk_abs_max(const void *p, int elem_bytes, int64_t n, void *out8, void *stream);
+/* the average-timestamp images around their events (image.py:266-283): evk_timestamp_planes_init_f32 sets the (4, plane_elems)
+ * planes [time+, count+, time-, count-] to 0 / 1 / 0 / 1 (the counts START AT ONE upstream); evk_timestamp_finalise_f32 forms
+ * pos = time+ / (count+ == 0 ? 1 : count+) and neg likewise (image.py:278-282), float32 divisions */
+int evk_timestamp_planes_init_f32(float *out4, int64_t plane_elems, void *stream);
+int evk_timestamp_finalise_f32(const float *planes4, int64_t plane_elems, float *pos, float *neg, void *stream);
 int evk_abs(const void *in, int elem_bytes, int64_t n, void *out, void *stream);
 /* evk_narrow_f64_f32: out[i] = (float)(in[i] - offset), the subtraction in float64; *inexact (optional, caller-zeroed) |= 1
  * when some value is not exactly representable in float32 (also a NaN).  How the host layer takes the reference's float64

@@ -227,3 +227,120 @@ def test_images_at_50m_events_720p(E):
     for kw in (dict(interpolation=None, padding=False), dict(interpolation='bilinear', padding=True)):
         ref = R.events_to_image_torch(x, y, p, sensor_size=(H, W), accum="f64", **kw)
         close(E.events_to_image_torch(xd, yd, pd, sensor_size=(H, W), **kw).cpu().numpy(), ref)
+
+
+# ---- average-timestamp images on the one-pass path (round 6: evk_timestamp_images2_f32, image.py:219-353) --------------------
+def _ts_planes(E, x, y, t, p, img_size, mode, ta, tdiv, impl, clip=True, fixed=True):
+    """The four raw planes (time+ | count+ | time- | count-; the counts start at ONE) through one kernel family."""
+    import os
+    from event_utils_amd import tiled
+    from event_utils_amd.representations import image as I
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    old, tiled.FORCE["image_fixed"] = tiled.FORCE["image_fixed"], fixed
+    os.environ["EVK_IMPL"] = impl
+    try:
+        out = I._timestamp_images_device(*cols, img_size, clip, 'bilinear', True, mode, ta, tdiv)
+    finally:
+        os.environ["EVK_IMPL"] = "tiled"
+        tiled.FORCE["image_fixed"] = old
+    return out.cpu().numpy().astype(np.float64)
+
+
+def _ts_planes_oracle(x, y, nts, p, img_size, clip=True):
+    """The same four planes from the oracle's splat (float64 accumulation), before the division."""
+    mask = np.ones(x.shape, np.float32)
+    if clip:
+        mask = np.where(x >= img_size[1] - 1, np.float32(0), np.float32(1)) * np.where(y >= img_size[0] - 1, np.float32(0), np.float32(1))
+    pxs, pys = np.floor(x), np.floor(y)
+    dxs, dys = (x - pxs).astype(np.float32), (y - pys).astype(np.float32)
+    pxs, pys = (pxs * mask).astype(np.int64), (pys * mask).astype(np.int64)
+    pos, neg = (p > 0).astype(np.float32), (p <= 0).astype(np.float32)
+    out = []
+    for wts, init in ((nts * pos, 0), (pos, 1), (nts * neg, 0), (neg, 1)):
+        img = np.full(img_size, init, dtype=np.float32)
+        R.interpolate_to_image(pxs, pys, dxs, dys, wts.astype(np.float32), img, "f64")
+        out.append(img.astype(np.float64))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("scene", ["uniform", "blob", "edges"])
+def test_timestamp_images_one_pass_against_direct_kernel_and_oracle(E, scene):
+    """2 M events at 640x480 (+ padding): the four planes of the one-pass path (fixed-point and float64 counts) against the
+    direct global-atomic kernel and the oracle's float64 splat, for the three time modes; clipped events (they land on pixel
+    (0, 0) WITH their weights, upstream quirk), negative pixels that wrap (rare path), NaN polarities (in neither class)."""
+    from event_utils_amd import _lib
+    rng = np.random.default_rng(31)
+    n, H, W = 2_000_000, 480, 640
+    img_size = (H + 1, W + 1)
+    x = rng.uniform(0, W, n).astype(np.float32); y = rng.uniform(0, H, n).astype(np.float32)
+    if scene == "blob":
+        hot = rng.random(n) < 0.5
+        x[hot] = rng.uniform(300, 340, hot.sum()).astype(np.float32); y[hot] = rng.uniform(200, 230, hot.sum()).astype(np.float32)
+    elif scene == "edges":
+        u = np.linspace(0, 1, n)
+        hot = rng.random(n) < 0.8
+        x[hot] = (100 + 400 * u[hot] + rng.normal(0, 0.7, hot.sum())).astype(np.float32)
+    t = np.sort(rng.uniform(0.0, 0.1, n)).astype(np.float32)
+    p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    p[::1000] = 0.0                                                  # non-positive class
+    p[7::5000] = np.nan                                              # neither class
+    x[:2000] = rng.uniform(-1, 0, 2000).astype(np.float32)           # px = -1 wraps to the last column
+    y[2000:3000] = rng.uniform(-1, 0, 1000).astype(np.float32)
+    x[3000:6000] = rng.uniform(W, W + 7, 3000).astype(np.float32)    # clipped: pixel (0, 0), weights intact
+    y[6000:6500] = np.float32(H + 0.25)
+    calls = []
+    orig = _lib.call
+    _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        t_first, t_last = np.float32(t[0]), np.float32(t[-1])
+        tdiv = np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
+        for mode, ta, td_, nts in ((0, t_first, tdiv, (t - t_first) / tdiv), (1, t_last, tdiv, (-t + t_last) / tdiv), (2, 0.0, 1.0, t)):
+            ref = _ts_planes_oracle(x, y, nts.astype(np.float32), p, img_size)
+            direct = _ts_planes(E, x, y, t, p, img_size, mode, ta, td_, "direct")
+            assert calls[-1] == "evk_timestamp_images_f32"
+            for fixed in (True, False):
+                fast = _ts_planes(E, x, y, t, p, img_size, mode, ta, td_, "tiled", fixed=fixed)
+                assert calls[-1] == "evk_timestamp_images2_f32"
+                for k in range(4):
+                    close(fast[k], ref[k])
+                    close(fast[k], direct[k])
+    finally:
+        _lib.call = orig
+    # the public functions on this stream (device tensors in, device tensors out) against the oracle's
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    for rev in (False, True):
+        a, b = E.events_to_timestamp_image_torch(*cols, sensor_size=(H, W), timestamp_reverse=rev)
+        ra, rb = R.events_to_timestamp_image_torch(x, y, t, p, sensor_size=(H, W), timestamp_reverse=rev, accum="f64")
+        assert a.is_cuda and a.dtype == torch.float32
+        close(a.cpu().numpy(), ra); close(b.cpu().numpy(), rb)
+
+
+def test_timestamp_images_one_pass_errors_small_images_and_unsorted_time(E):
+    """Without clipping an out-of-range event raises IndexError on both kernel families; images smaller than a tile, sizes that
+    are not multiples of anything, unsorted time stamps (negative normalised times) and two events."""
+    import os
+    rng = np.random.default_rng(32)
+    for n, H, W in ((60_000, 37, 53), (200_000, 180, 240), (2, 20, 20), (130_001, 719, 1279)):
+        x = rng.uniform(0, W, n).astype(np.float32); y = rng.uniform(0, H, n).astype(np.float32)
+        t = rng.uniform(0.0, 1.0, n).astype(np.float32)                  # NOT sorted: (t - t[0]) / (t[-1] - t[0] + eps) of any sign
+        p = rng.normal(size=n).astype(np.float32)
+        cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+        ra, rb = R.events_to_timestamp_image_torch(x, y, t, p, sensor_size=(H, W), accum="f64")
+        a, b = E.events_to_timestamp_image_torch(*cols, sensor_size=(H, W))
+        # (a ratio of two sums: where the count is tiny the quotient amplifies the 1e-7 relative error of the sums)
+        scale = max(np.max(np.abs(ra)), np.max(np.abs(rb)), 1e-30)
+        assert np.max(np.abs(a.cpu().numpy() - ra)) <= 2e-5 * scale and np.max(np.abs(b.cpu().numpy() - rb)) <= 2e-5 * scale
+    x[5] = np.float32(W + 3)
+    cols = [torch.from_numpy(a).cuda() for a in (x, y, t, p)]
+    msgs = []
+    for impl in ("tiled", "direct"):
+        os.environ["EVK_IMPL"] = impl
+        try:
+            with pytest.raises(IndexError) as ei:
+                E.events_to_timestamp_image_torch(*cols, sensor_size=(H, W), clip_out_of_range=False)
+            msgs.append(str(ei.value))
+        finally:
+            os.environ["EVK_IMPL"] = "tiled"
+    assert msgs[0] == msgs[1]
+    a, b = E.events_to_timestamp_image_torch(*cols, sensor_size=(H, W))           # the stream works on after the error
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
