@@ -744,6 +744,35 @@ def bench_image_10m(E, tiled, dev, impl):
                                                                       D.ptr(canvas), None, D.stream()), 3), 4),
         "k_image_bilinear_f32": round(tiled._time_ms(lambda: _lib.call("evk_image_bilinear_f32", D.ptr(xd), D.ptr(yd), D.ptr(pud), n, H,
                                                                        W, inf, inf, D.ptr(img), None, D.stream()), 3), 4)}
+    # the average-timestamp images (events_to_timestamp_image_torch, image.py:285-353) on the same design
+    # since round 6: 16 B/event + four (H+1, W+1) planes; eight global atomics per event before
+    try:
+        td_ = torch.sort(torch.rand(n, device=dev) * 0.1).values.contiguous()
+        planes = torch.zeros((4, H + 1, W + 1), dtype=torch.float32, device=dev)
+        ts_args = (n, H + 1, W + 1, float(W), float(H), 0, 0.0, 0.1)
+        ts_call = lambda stage=0: tiled.timestamp_images2(xd, yd, td_, pud, *ts_args, planes, None, stage=stage)  # noqa: E731
+        alg_ts = 16.0 * n + 4 * (H + 1) * (W + 1) * 4.0
+        keep = [None]
+
+        def ts_public():
+            keep[0] = E.events_to_timestamp_image_torch(xd, yd, td_, pud, sensor_size=(H, W))
+        if ts_call():
+            call_ms = tiled._time_ms(ts_call, 20)
+            res["events_to_timestamp_image_torch"] = {
+                "call_ms": round(call_ms, 4), "Mevents_per_s": round(n / call_ms / 1e3, 1),
+                "roofline_frac": round(alg_ts / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels_ms": {"k_part_sorted": round(tiled._time_ms(lambda: ts_call(_lib.EVK_VOXEL2_PARTITION_ONLY), 20), 4),
+                               "k_image_tiles_ts": round(tiled._time_ms(lambda: ts_call(_lib.EVK_VOXEL2_TILES_ONLY), 20), 4)},
+                "public_call_ms": round(tiled._time_ms(ts_public, 20), 4),
+                "direct_kernel_ms": round(tiled._time_ms(lambda: _lib.call(
+                    "evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td_), D.ptr(pud), n, H + 1, W + 1, float(W), float(H), 0, 0.0,
+                    0.1, D.ptr(planes), None, D.stream()), 3), 4),
+                "algorithmic_bytes": alg_ts,
+                "note": "16 B/event + four planes; the tile kernel is bound by its eight LDS atomics per event (four float64, four "
+                        "64-bit fixed-point); direct_kernel_ms = evk_timestamp_images_f32, eight global atomics per event"}
+        E.check_errors()
+    except Exception as e:  # noqa: BLE001
+        res["events_to_timestamp_image_torch"] = {"error": repr(e)}
     return res
 
 

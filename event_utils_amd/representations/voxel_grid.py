@@ -88,23 +88,34 @@ def events_to_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_bilinear
     integer coordinates on the (H+1, W+1) canvas of events_to_image (image.py:17,28-44): non-integer coordinates
     raise TypeError, coordinates outside the canvas ValueError, x == W / y == H fall in the cropped pad.
     """
-    assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
+    return _events_to_voxel_numpy(xs, ys, ts, (ps,), B, sensor_size, temporal_bilinear)[0]
+
+
+def _events_to_voxel_numpy(xs, ys, ts, weight_columns, B, sensor_size, temporal_bilinear):
+    """events_to_voxel for every weight column of `weight_columns` on the SAME events: x, y, t go to the device once
+    (events_to_neg_pos_voxel voxelises its events twice, voxel_grid.py:240-241: host arrays, so the link is what it costs)."""
+    for ps in weight_columns:
+        assert (len(xs) == len(ys) and len(ys) == len(ts) and len(ts) == len(ps))
     if not temporal_bilinear:
         raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:213-214)")
     xs, ys = np.asarray(xs).squeeze(), np.asarray(ys).squeeze()
-    ts, ps = np.asarray(ts, dtype=np.float64), np.asarray(ps)
+    ts = np.asarray(ts, dtype=np.float64)
     if not (np.issubdtype(xs.dtype, np.integer) and np.issubdtype(ys.dtype, np.integer)):
         raise TypeError("only int indices permitted")
     dev = D.require_gpu()
     H, W = int(sensor_size[0]), int(sensor_size[1])
-    out = torch.zeros((B, H, W), dtype=torch.float64, device=dev)
-    oob = D.OobCounter(dev)
     xd, yd = D.to_device(xs, torch.int32), D.to_device(ys, torch.int32)
-    td, pd = D.to_device(ts, torch.float64), D.to_device(ps.squeeze(), torch.float64)
-    _lib.call("evk_voxel_f64", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), len(xs),
-              float(ts[0]), float(ts[-1]), B, H, W, D.ptr(out), oob.ptr, D.stream())
-    oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas")
-    return out.cpu().numpy()
+    td = D.to_device(ts, torch.float64)
+    grids = []
+    for ps in weight_columns:
+        out = torch.zeros((B, H, W), dtype=torch.float64, device=dev)
+        oob = D.OobCounter(dev)
+        pd = D.to_device(np.asarray(ps).squeeze(), torch.float64)
+        _lib.call("evk_voxel_f64", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), len(xs),
+                  float(ts[0]), float(ts[-1]), B, H, W, D.ptr(out), oob.ptr, D.stream())
+        oob.raise_if_set(ValueError, "events outside the (H+1, W+1) canvas")
+        grids.append(out.cpu().numpy())
+    return grids
 
 
 def events_to_neg_pos_voxel_torch(xs, ys, ts, ps, B, device=None, sensor_size=(180, 240), temporal_bilinear=True):
@@ -186,8 +197,7 @@ def events_to_neg_pos_voxel(xs, ys, ts, ps, B, sensor_size=(180, 240), temporal_
     """numpy twin (reference: voxel_grid.py:219-243): np.where(ps, 1, 0) / np.where(ps, 0, 1) weights."""
     pos_weights = np.where(ps, 1, 0)
     neg_weights = np.where(ps, 0, 1)
-    voxel_pos = events_to_voxel(xs, ys, ts, pos_weights, B, sensor_size=sensor_size, temporal_bilinear=temporal_bilinear)
-    voxel_neg = events_to_voxel(xs, ys, ts, neg_weights, B, sensor_size=sensor_size, temporal_bilinear=temporal_bilinear)
+    voxel_pos, voxel_neg = _events_to_voxel_numpy(xs, ys, ts, (pos_weights, neg_weights), B, sensor_size, temporal_bilinear)
     return voxel_pos, voxel_neg
 
 

@@ -481,7 +481,7 @@ def case_search(rng):
 def case_misc(rng):
     """events_to_voxel (numpy float64 path), the timestamp images, the event-weights gather, batched objective evaluation"""
     from event_utils_amd.events import DeviceEvents
-    which = str(rng.choice(["voxel_np", "ts_image", "ts_image_torch", "gather", "batch"]))
+    which = str(rng.choice(["voxel_np", "ts_image", "ts_image_torch", "ts_hard", "gather", "batch"]))
     H, W = int(rng.integers(4, 300)), int(rng.integers(4, 400))
     n = int(rng.choice([2, 65, 1000, 8193, 100_000, 400_000]))
     impl = str(rng.choice(["auto", "tiled", "direct"]))
@@ -513,6 +513,31 @@ def case_misc(rng):
                     ref = R.events_to_timestamp_image_torch(*(a.numpy() for a in c), sensor_size=(H, W), padding=pad, timestamp_reverse=rev, accum="f64")
                 for k in range(2):
                     # a ratio of two float32 images: where the count is a handful of weights, the quotient carries their rounding
+                    err = same(got[k], ref[k], np.ones_like(ref[k]), "image %d" % k, 2e-5)
+                    if err is not None:
+                        return desc, err
+                return desc, None
+            if which == "ts_hard":
+                # the one-pass timestamp path (round 6) on what the plain case leaves out: scenes that cut hot tiles, polarities of
+                # every kind (zeros -> the non-positive class, NaN -> neither), unsorted / constant time stamps, pixels that wrap
+                n = int(rng.choice([2, 65, 8193, 60_000, 400_000, 1_000_003, 2_500_000]))
+                impl = str(rng.choice(["auto", "tiled"] + (["direct"] if n <= 100_000 else [])))
+                os.environ["EVK_IMPL"] = impl
+                scene = str(rng.choice(["uniform", "blob", "pixel", "edge"]))
+                tk, pk = str(rng.choice(["sorted", "const", "few", "unsorted"])), str(rng.choice(["pm1", "pm1z", "float", "special"]))
+                x, y = coords(rng, n, H + 1, W + 1, True, scene)
+                if n > 100:
+                    k = n // 50
+                    x[:k] = rng.uniform(-1, 0, k).astype(np.float32)                  # px = -1: wraps to the last column
+                    y[k:2 * k] = rng.uniform(-1, 0, k).astype(np.float32)
+                    x[2 * k:3 * k] = rng.uniform(W, W + 3, k).astype(np.float32)      # clipped: pixel (0, 0) with its weights
+                t, pw = times(rng, n, tk), weights(rng, n, pk)
+                rev = bool(rng.integers(0, 2))
+                desc = "misc ts_hard %dx%d n=%d %s t=%s p=%s rev=%d impl=%s" % (H, W, n, scene, tk, pk, rev, impl)
+                c = [torch.from_numpy(a).cuda() for a in (x, y, t, pw)]
+                got = [g.cpu().numpy() for g in E.events_to_timestamp_image_torch(*c, sensor_size=(H, W), timestamp_reverse=rev)]
+                ref = R.events_to_timestamp_image_torch(x, y, t, pw, sensor_size=(H, W), timestamp_reverse=rev, accum="f64")
+                for k in range(2):
                     err = same(got[k], ref[k], np.ones_like(ref[k]), "image %d" % k, 2e-5)
                     if err is not None:
                         return desc, err
