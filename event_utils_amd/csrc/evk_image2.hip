@@ -159,17 +159,28 @@ struct SrcTsF32 {
         yr = ok ? (masked ? yf - fy : yf - (float)__mul24(ty, g.th)) : yf;
         return ok ? __mul24(ty, g.tiles_x) + tx : -3;
     }
-    __device__ __forceinline__ float nts_of(float tf) const {
-        return mode == 0 ? (tf - ta) / td : (mode == 1 ? (-tf + ta) / td : tf);
+    // from_events (modes 0 / 1): ta = ts[0] (mode 1: ts[-1]), td = (ts[-1] - ts[0]) + 1e-6 in float32 (image.py:326-329)
+    __device__ __forceinline__ void time_constants(int64_t n, int from_events, float &a, float &d) const {
+        a = ta, d = td;
+        if (from_events && mode != 2) {
+            const float t0 = t[0], t1 = t[n - 1];
+            a = mode == 0 ? t0 : t1;
+            d = (t1 - t0) + 1e-6f;
+        }
     }
-    __device__ __forceinline__ uint32_t w_bits(const uint32_t *r, int e) const { return __float_as_uint(nts_of(__uint_as_float(r[e]))); }
+    __device__ __forceinline__ float nts_of(float tf, float a, float d) const {
+        return mode == 0 ? (tf - a) / d : (mode == 1 ? (-tf + a) / d : tf);
+    }
+    __device__ __forceinline__ uint32_t nts_bits(const uint32_t *r, int e, float a, float d) const {
+        return __float_as_uint(nts_of(__uint_as_float(r[e]), a, d));
+    }
     // pos_events_mask = ps > 0, neg_events_mask = ps <= 0 (image.py:258-259); a NaN polarity is in neither
     __device__ __forceinline__ uint32_t cls(const uint32_t *r, int e) const {
         const float pv = __uint_as_float(r[4 + e]);
         return pv > 0.0f ? 0u : (pv <= 0.0f ? 1u : 2u);
     }
     // the direct kernel's per-event code (evk_scatter.hip, k_timestamp_images_f32); false = IndexError
-    __device__ __forceinline__ bool rare_ts(float xf, float yf, const uint32_t *r, int e) const {
+    __device__ __forceinline__ bool rare_ts(float xf, float yf, const uint32_t *r, int e, float a, float d) const {
         const uint32_t k = cls(r, e);
         if (k == 2u) return true;
         const float mask = (!(xf >= clipx) && !(yf >= clipy)) ? 1.0f : 0.0f;
@@ -180,7 +191,7 @@ struct SrcTsF32 {
         s.px = (long long)(fx * mask);
         s.py = (long long)(fy * mask);
         float *val = out4 + (int64_t)(2u * k) * h * wd, *cnt = val + (int64_t)h * wd;
-        return splat_iwe(val, h, wd, s, nts_of(__uint_as_float(r[e]))) && splat_iwe(cnt, h, wd, s, 1.0f);
+        return splat_iwe(val, h, wd, s, nts_of(__uint_as_float(r[e]), a, d)) && splat_iwe(cnt, h, wd, s, 1.0f);
     }
 };
 
@@ -709,13 +720,13 @@ static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile
 
 template <int FMT, typename C>
 static void img_partition(const C &c, int64_t n, const ImgCall &ic, uint32_t *index, void *scratch, uint32_t *oob,
-                          uint32_t *host_report, uint32_t seq, hipStream_t s) {
+                          uint32_t *host_report, uint32_t seq, hipStream_t s, int t_from_events = 0) {
     char *sb = (char *)scratch;
     if (img_small(ic.ntiles))
-        launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
+        launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, t_from_events, sb + ic.L.rec, sb + ic.L.pw,
                                   (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
     else
-        launch_part<1024, 12, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, 0, sb + ic.L.rec, sb + ic.L.pw,
+        launch_part<1024, 12, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, t_from_events, sb + ic.L.rec, sb + ic.L.pw,
                                    (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
 }
 
@@ -800,6 +811,8 @@ extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const f
                                          uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
     if (mode < 0 || mode > 2 || (flags & EVK_VOXEL_OVERWRITE)) return EVK_EINVAL;   // (the windows are ADDED to the images)
+    const int from_events = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
+    flags &= ~EVK_VOXEL_T_FROM_EVENTS;
     if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
     ImgCall ic;
     const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, out4, index, scratch, scratch_bytes, host_report, IMG_TS_PLANES);
@@ -809,7 +822,7 @@ extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const f
     char *sb = (char *)scratch;
     if (!(flags & EVK_VOXEL2_TILES_ONLY))
         img_partition<V2_FMT_IMGT>(SrcTsF32{x, y, t, p, clipx, clipy, mode, ta, td, out4, h, wd}, n, ic, index, scratch, oob,
-                                   host_report, seq, s);
+                                   host_report, seq, s, from_events);
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int wcells = ((tile_w + 1) | 1) * (tile_h + 1);
         const size_t lds = (size_t)4 * wcells * sizeof(acc_t);

@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
         if (t_from_events) t_first = c.t1(0), t_last = c.t1(n - 1);   // ts[0], ts[-1] (voxel_grid.py:133)
     }
     const TimeNorm tnorm = make_time_norm(t_first, t_last, bm1);
+    // IMGT: the two constants of the normalised time stamp -- the column source's, or (t_from_events: ts[0] / ts[-1] read HERE, no
+    // device-to-host transfer before the launch) what image.py:326-329 forms from the stream's ends
+    float ts_a = 0.0f, ts_d = 1.0f;
+    if constexpr (REC == V2_FMT_IMGT) c.time_constants(n, t_from_events, ts_a, ts_d);
     // EARLY REPORT of dropped events (round 5).  A synchronous caller (EVK_ERRORS=strict, the default: the reference raises
     // before it returns, image.py:96-99) waits for {seq, dropped events} in its pinned slot, then prepares its next call while
     // the tile kernel runs.  The count is final long before this kernel ends: a workgroup's dropped events are known with the
@@ -599,7 +603,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                     const uint32_t cls = c.cls(tpr + C::TPW * (s2 / G), s2 % G);   // 0 / 1 / 2: positive / non-positive / neither
                     sorted[pos] = make_uint2((__float_as_uint(xr[s2]) & 0x7FFFFFFFu) | ((cls & 1u) << 31),
                                              (__float_as_uint(yr[s2]) & 0x7FFFFFFFu) | ((cls >> 1) << 31));
-                    sortedp[pos] = c.w_bits(tpr + C::TPW * (s2 / G), s2 % G);      // the normalised time stamp
+                    sortedp[pos] = c.nts_bits(tpr + C::TPW * (s2 / G), s2 % G, ts_a, ts_d);   // the normalised time stamp
                     any_t = true;
                 }
             }
@@ -607,7 +611,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             if (__any(rare != 0u)) {   // rare: pixels that wrap or raise in index_put_ -- the direct kernel's global atomics
 #pragma unroll
                 for (int s2 = 0; s2 < EPT; ++s2)
-                    if (rare >> s2 & 1u) dropped += c.rare_ts(xr[s2], yr[s2], tpr + C::TPW * (s2 / G), s2 % G) ? 0u : 1u;
+                    if (rare >> s2 & 1u) dropped += c.rare_ts(xr[s2], yr[s2], tpr + C::TPW * (s2 / G), s2 % G, ts_a, ts_d) ? 0u : 1u;
             }
             rare = 0;
         } else {

@@ -225,9 +225,11 @@ def image_to_event_weights(xs, ys, img):
     return out if on_device else out.cpu().numpy()
 
 
-def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv):
+def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv, resident=False):
     """(4, H, W) float32 device tensor [ts_pos, cnt_pos, ts_neg, cnt_neg]; the count planes start at ONE (upstream
-    quirk, image.py:269,271: img_*_cnt = torch.ones)."""
+    quirk, image.py:269,271: img_*_cnt = torch.ones).  ta is None (modes 0 / 1): the time constants come from td[0] / td[-1] --
+    read by the one-pass kernels themselves, read back for the direct kernel.  resident: events and images stay on the device, the
+    IndexError check waits for the partition kernel's report only (or not at all under EVK_ERRORS=deferred)."""
     dev = xd.device
     clipx, clipy = _clip_thresholds(img_size, clip_out_of_range, interpolation, padding)
     out = torch.empty((4,) + tuple(img_size), dtype=torch.float32, device=dev)
@@ -238,14 +240,25 @@ def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interp
     # Above the crossover: one partition + four LDS windows per tile (evk_image2.hip, round 6); below it, or for columns the
     # one-pass path cannot take (unaligned views), eight global atomics per event (evk_scatter.hip).  Same semantics either way.
     impl = tiled.default_impl()
+    from_events = ta is None
     fast = (tiled.can_tile_image((xd, yd, td, pd), impl, True) and xd.shape == yd.shape == td.shape == pd.shape
             and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_TIMESTAMP)
-            and tiled.timestamp_images2(xd, yd, td, pd, n, img_size[0], img_size[1], clipx, clipy, mode, ta, tdiv, out, oob))
+            and tiled.timestamp_images2(xd, yd, td, pd, n, img_size[0], img_size[1], clipx, clipy, mode, 0.0 if from_events else ta,
+                                        1.0 if from_events else tdiv, out, oob, from_events=from_events))
     if not fast:
+        if from_events:
+            ta, tdiv = _timestamp_constants(D.ends(td), mode)
         _lib.call("evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td), D.ptr(pd), n, img_size[0], img_size[1],
                   clipx, clipy, mode, float(ta), float(tdiv), D.ptr(out), oob.ptr, D.stream())
-    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),))
+    oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(img_size),), deferrable=resident and fast)
     return out
+
+
+def _timestamp_constants(ends, mode):
+    """(ta, tdiv) of events_to_timestamp_image_torch (image.py:326-329), float32 arithmetic: ta = ts[0] (reversed: ts[-1]),
+    tdiv = (ts[-1] - ts[0]) + 1e-6."""
+    t_first, t_last = (np.float32(e) for e in ends)
+    return (t_last if mode == 1 else t_first), np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
 
 
 def _timestamp_finalise(planes):
@@ -289,11 +302,14 @@ def events_to_timestamp_image_torch(xs, ys, ts, ps, device=None, sensor_size=(18
     img_size = (sensor_size[0] + 1, sensor_size[1] + 1) if padding else tuple(sensor_size)
     xd, yd = D.to_device(xs, torch.float32, dev), D.to_device(ys, torch.float32, dev)
     td, pd = D.to_device(ts, torch.float32, dev), D.to_device(ps, torch.float32, dev)
-    # (ts[0], ts[-1]: from the caller's tensor when it lives on the host -- no device round trip)
-    t_first, t_last = (np.float32(e) for e in (D.ends(td) if (ts.is_cuda or ts.dim() != 1) else D.ends(ts[[0, -1]].to(torch.float32))))
-    tdiv = np.float32(np.float32(t_last - t_first) + np.float32(1e-6))
-    mode, ta = (1, t_last) if timestamp_reverse else (0, t_first)
-    img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv)
+    mode = 1 if timestamp_reverse else 0
+    if ts.is_cuda and ts.dim() == 1:
+        ta = tdiv = None            # ts[0], ts[-1] are read on the device (no round trip before the launches)
+    else:                           # (a host tensor: read directly)
+        ta, tdiv = _timestamp_constants(D.ends(td) if ts.dim() != 1 else D.ends(ts[[0, -1]].to(torch.float32)), mode)
+    resident = xs.is_cuda and torch.device(device).type == "cuda"
+    img = _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interpolation, padding, mode, ta, tdiv,
+                                   resident=resident)
     res = _timestamp_finalise(img)
     return res[0].to(device), res[1].to(device)
 

@@ -445,8 +445,10 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
 # the public call is host-bound below that and cheaper to issue on the one-pass path (see above): any count
 TILED_MIN_EVENTS_IMAGE = 1
 TILED_MIN_EVENTS_IMAGE_BILINEAR = 1
-# the average-timestamp images (round 6): eight global atomics per event at ~21 G/s against the two launches' ~20 us
-TILED_MIN_EVENTS_TIMESTAMP = 50_000
+# the average-timestamp images (round 6): as the event images -- the one-pass call of device tensors has no read-back and no
+# stream synchronisation (ts[0] / ts[-1] read by the kernel, the IndexError check on the partition kernel's report), the direct one
+# has both: 0.054 against 0.090 ms per public call at 50 k events (profiles/r06_timestamp_images.txt): any count
+TILED_MIN_EVENTS_TIMESTAMP = 1
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
@@ -487,10 +489,11 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     return True
 
 
-def timestamp_images2(xd, yd, td, pd, n, H, W, clipx, clipy, mode, ta, tdiv, out4, oob, stage=0):
+def timestamp_images2(xd, yd, td, pd, n, H, W, clipx, clipy, mode, ta, tdiv, out4, oob, stage=0, from_events=False):
     """evk_timestamp_images2_f32: the four average-timestamp planes of the device columns ADDED to `out4` (4, H, W) on the one-pass
     partition + LDS windows (image.py:219-353).  Returns False when the one-pass path has no tiling for this image (the caller
-    then uses the direct kernel, evk_timestamp_images_f32)."""
+    then uses the direct kernel, evk_timestamp_images_f32).  from_events (modes 0 / 1): ta / tdiv are formed on the device from
+    td[0] / td[-1] (image.py:326-329) -- no read-back before the launches."""
     L = _lib.lib()
     shape = voxel2_shape(H, W, 1)
     if shape is None or H < 2 or W < 2:
@@ -509,7 +512,7 @@ def timestamp_images2(xd, yd, td, pd, n, H, W, clipx, clipy, mode, ta, tdiv, out
         _staging_bytes[key] = sizes
     index = _zbuf("image2_index", sizes[0], dev)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
-    flags = stage
+    flags = stage | (_lib.EVK_VOXEL_T_FROM_EVENTS if from_events else 0)
     if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
     if not FORCE["xcd_order"]:
