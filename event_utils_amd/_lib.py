@@ -91,6 +91,7 @@ SIGNATURES = {
     "evk_polarity_weights_f32": [P, c_int64, P, P, P],
     "evk_narrow_f64_f32": [P, c_int64, c_double, P, P, P],
     "evk_abs_max": [P, c_int, c_int64, P, P],
+    "evk_searchsorted_left": [P, c_int, c_int64, P, c_int64, P, P],
     "evk_timestamp_planes_init_f32": [P, c_int64, P],
     "evk_timestamp_finalise_f32": [P, c_int64, P, P, P],
     "evk_abs": [P, c_int, c_int64, P, P],

@@ -69,9 +69,38 @@ __global__ void __launch_bounds__(EVK_BLOCK) k_ts_finalise(const float *__restri
     }
 }
 
+// np.searchsorted(a, v) (side 'left') for a sorted float32 / float64 device column and float64 keys, one thread per key: the
+// comparison in float64, as numpy promotes a float32 array against python floats (voxel_grid.py:104-105); a NaN key sorts
+// behind every number, as in numpy
+template <typename T>
+__global__ void __launch_bounds__(EVK_BLOCK) k_searchsorted_left(const T *__restrict__ a, int64_t n, const double *__restrict__ v, int64_t m,
+                                                                int64_t *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double key = v[j];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const double av = (double)a[mid];
+        if (av < key || (key != key && av == av)) lo = mid + 1;
+        else hi = mid;
+    }
+    out[j] = lo;
+}
+
 }  // namespace evk
 
 using namespace evk;
+
+extern "C" int evk_searchsorted_left(const void *a, int elem_bytes, int64_t n, const double *keys, int64_t m, int64_t *out,
+                                     void *stream) {
+    if (n < 0 || m < 0 || (elem_bytes != 4 && elem_bytes != 8) || (n > 0 && !a) || (m > 0 && (!keys || !out))) return EVK_EINVAL;
+    if (m == 0) return EVK_OK;
+    const int blocks = (int)((m + EVK_BLOCK - 1) / EVK_BLOCK);
+    if (elem_bytes == 4) k_searchsorted_left<float><<<blocks, EVK_BLOCK, 0, (hipStream_t)stream>>>((const float *)a, n, keys, m, out);
+    else k_searchsorted_left<double><<<blocks, EVK_BLOCK, 0, (hipStream_t)stream>>>((const double *)a, n, keys, m, out);
+    return launch_status();
+}
 
 extern "C" int evk_timestamp_planes_init_f32(float *out4, int64_t plane_elems, void *stream) {
     if (plane_elems <= 0 || !out4) return EVK_EINVAL;

@@ -267,16 +267,34 @@ def voxel_grids_fixed_n_torch(xs, ys, ts, ps, B, n, sensor_size=(180, 240), temp
     return _voxel_windows(xs, ys, ts, ps, B, starts + [starts[-1] + n], sensor_size)
 
 
+def _device_searchable(ts):
+    return isinstance(ts, torch.Tensor) and ts.is_cuda and ts.dim() == 1 and ts.dtype in (torch.float32, torch.float64)
+
+
+def _searchsorted_device(ts, keys):
+    """np.searchsorted(ts.cpu().numpy(), keys) for a device time column without copying it to the host (voxel_grid.py:104-105:
+    upstream copies the whole column, 40 MB per 10 M events, for two indices): evk_searchsorted_left, float64 comparisons as
+    numpy's.  -> int64 numpy array."""
+    ts = ts if ts.is_contiguous() else ts.contiguous()
+    kd = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.float64)).to(ts.device)
+    out = torch.empty(kd.shape[0], dtype=torch.int64, device=ts.device)
+    _lib.call("evk_searchsorted_left", D.ptr(ts), ts.element_size(), ts.shape[0], D.ptr(kd), kd.shape[0], D.ptr(out), D.stream())
+    return out.cpu().numpy()
+
+
 def events_to_voxel_timesync_torch(xs, ys, ts, ps, B, t0, t1, device=None, np_ts=None, sensor_size=(180, 240),
                                    temporal_bilinear=True):
     """Voxel grid of the events with t0 <= t < t1 (reference: voxel_grid.py:82-112)."""
     assert (t1 > t0)
-    if np_ts is None:
-        np_ts = ts.cpu().numpy()
     if device is None:
         device = xs.device
-    start_idx = np.searchsorted(np_ts, t0)
-    end_idx = np.searchsorted(np_ts, t1)
+    if np_ts is None and _device_searchable(ts):
+        start_idx, end_idx = (int(v) for v in _searchsorted_device(ts, [t0, t1]))
+    else:
+        if np_ts is None:
+            np_ts = ts.cpu().numpy()
+        start_idx = np.searchsorted(np_ts, t0)
+        end_idx = np.searchsorted(np_ts, t1)
     assert (start_idx < end_idx)
     return events_to_voxel_torch(xs[start_idx:end_idx], ys[start_idx:end_idx], ts[start_idx:end_idx],
                                  ps[start_idx:end_idx], B, device, sensor_size=sensor_size,
@@ -289,12 +307,17 @@ def voxel_grids_fixed_t_torch(xs, ys, ts, ps, B, t, sensor_size=(180, 240), temp
     consecutive, so all of them are built in one kernel launch."""
     if not temporal_bilinear:
         raise NotImplementedError("temporal_bilinear=False is dead code upstream (voxel_grid.py:144-147)")
-    np_ts = ts.cpu().numpy()
-    t_starts = np.arange(ts[0].item(), ts[-1].item() - t, t)
+    t_first, t_last = D.ends(ts)
+    t_starts = np.arange(t_first, t_last - t, t)
     if len(t_starts) == 0:
         return []
-    lo = np.searchsorted(np_ts, t_starts)
-    hi = np.searchsorted(np_ts, t_starts + t)
+    if _device_searchable(ts):      # the bounds of all windows from the device column: 16 bytes per window come back, not the column
+        idx = _searchsorted_device(ts, np.concatenate([t_starts, t_starts + t]))
+        lo, hi = idx[:len(t_starts)], idx[len(t_starts):]
+    else:
+        np_ts = ts.cpu().numpy()
+        lo = np.searchsorted(np_ts, t_starts)
+        hi = np.searchsorted(np_ts, t_starts + t)
     assert np.all(lo < hi)                                  # voxel_grid.py:108
     if np.array_equal(hi[:-1], lo[1:]):                     # contiguous windows: one launch
         return _voxel_windows(xs, ys, ts, ps, B, list(lo) + [hi[-1]], sensor_size)

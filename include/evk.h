@@ -615,6 +615,10 @@ int evk_abs_max(const void *p, int elem_bytes, int64_t n, void *out8, void *stre
 /* the average-timestamp images around their events (image.py:266-283): evk_timestamp_planes_init_f32 sets the (4, plane_elems)
  * planes [time+, count+, time-, count-] to 0 / 1 / 0 / 1 (the counts START AT ONE upstream); evk_timestamp_finalise_f32 forms
  * pos = time+ / (count+ == 0 ? 1 : count+) and neg likewise (image.py:278-282), float32 divisions */
+/* out[j] = np.searchsorted(a, keys[j]) (side 'left') for a sorted float32 (elem_bytes 4) / float64 (8) device column of n values
+ * and m float64 device keys, compared in float64 as numpy does: the window bounds of events_to_voxel_timesync_torch /
+ * voxel_grids_fixed_t_torch (voxel_grid.py:104-105) without copying the time column to the host */
+int evk_searchsorted_left(const void *a, int elem_bytes, int64_t n, const double *keys, int64_t m, int64_t *out, void *stream);
 int evk_timestamp_planes_init_f32(float *out4, int64_t plane_elems, void *stream);
 int evk_timestamp_finalise_f32(const float *planes4, int64_t plane_elems, float *pos, float *neg, void *stream);
 int evk_abs(const void *in, int elem_bytes, int64_t n, void *out, void *stream);

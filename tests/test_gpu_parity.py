@@ -840,3 +840,32 @@ def test_f17_timestamp_image_and_event_image_classes(golden):
     e1.image = np.zeros((H, W)); e1.add_event(2.9, 3.1, 0.0, 4.0)
     assert e1.image[3, 2] == 4.0 and e1.image.sum() == 4.0
     assert np.all(np.isnan(E.EventImage((4, 5)).get_image()))
+
+
+def test_device_searchsorted_equals_numpy(E):
+    """evk_searchsorted_left (the window bounds of events_to_voxel_timesync_torch / voxel_grids_fixed_t_torch on a device time
+    column, voxel_grid.py:104-105) against np.searchsorted: float32 and float64 columns, repeated values, keys below / above /
+    between / equal, keys that are not float32 values, a NaN key, an empty column."""
+    from event_utils_amd.representations import voxel_grid as V
+    rng = np.random.default_rng(77)
+    for dtype in (np.float32, np.float64):
+        a = np.sort(rng.uniform(10.0, 11.0, 200_001)).astype(dtype)
+        a[5000:5100] = a[5000]                                   # a run of equal values
+        keys = np.concatenate([rng.uniform(9.5, 11.5, 4000), a[rng.integers(0, len(a), 500)].astype(np.float64),
+                               [a[0], a[-1], -np.inf, np.inf, np.nan, float(a[5000])]])
+        got = V._searchsorted_device(torch.from_numpy(a).cuda(), keys)
+        assert got.dtype == np.int64 and np.array_equal(got, np.searchsorted(a, keys))
+    assert np.array_equal(V._searchsorted_device(torch.empty(0, device="cuda"), [0.5, 2.0]), [0, 0])
+    # the two public callers on a device column against their host-column selves
+    n, H, W, B = 300_000, 60, 80, 3
+    x = torch.from_numpy(rng.integers(0, W, n).astype(np.float32)); y = torch.from_numpy(rng.integers(0, H, n).astype(np.float32))
+    t = torch.from_numpy(np.sort(rng.uniform(0, 1, n)).astype(np.float32)); p = torch.from_numpy(rng.choice([-1.0, 1.0], n).astype(np.float32))
+    host = V.events_to_voxel_timesync_torch(x, y, t, p, B, 0.25, 0.7500001, sensor_size=(H, W))
+    devc = V.events_to_voxel_timesync_torch(x.cuda(), y.cuda(), t.cuda(), p.cuda(), B, 0.25, 0.7500001, sensor_size=(H, W))
+    assert devc.is_cuda
+    close(devc.cpu().numpy(), host.numpy())          # (same events; a slice's alignment decides the kernel family, not the values)
+    a = V.voxel_grids_fixed_t_torch(x, y, t, p, B, 0.13, sensor_size=(H, W))
+    b = V.voxel_grids_fixed_t_torch(x.cuda(), y.cuda(), t.cuda(), p.cuda(), B, 0.13, sensor_size=(H, W))
+    assert len(a) == len(b) == 7
+    for u, v in zip(a, b):
+        close(v.cpu().numpy(), u.numpy())
