@@ -768,6 +768,9 @@ def bench_image_10m(E, tiled, dev, impl):
                     "evk_timestamp_images_f32", D.ptr(xd), D.ptr(yd), D.ptr(td_), D.ptr(pud), n, H + 1, W + 1, float(W), float(H), 0, 0.0,
                     0.1, D.ptr(planes), None, D.stream()), 3), 4),
                 "algorithmic_bytes": alg_ts,
+                **({"traffic": pmc_traffic("k_part_sorted", "img_timestamp")[2],
+                    "traffic_source": pmc_traffic("k_part_sorted", "img_timestamp")[1]}
+                   if pmc_traffic("k_part_sorted", "img_timestamp")[2] else {}),
                 "note": "16 B/event + four planes; the tile kernel is bound by its eight LDS atomics per event (four float64, four "
                         "64-bit fixed-point); direct_kernel_ms = evk_timestamp_images_f32, eight global atomics per event"}
         E.check_errors()

@@ -12,7 +12,7 @@ import sys
 
 ALG = {"c2": 16 * 10_000_000 + 5 * 480 * 640 * 4, "c5_share": 16 * 50_000_000 + 5 * 720 * 1280 * 4,
        "img_nearest": 12 * 10_000_000 + 480 * 640 * 4, "img_bilinear": 12 * 10_000_000 + 480 * 640 * 4,
-       "prebucketed": 16 * 10_000_000 + 5 * 480 * 640 * 4}
+       "prebucketed": 16 * 10_000_000 + 5 * 480 * 640 * 4, "img_timestamp": 16 * 10_000_000 + 4 * 481 * 641 * 4}
 
 
 def collect(d, counter):
@@ -36,7 +36,7 @@ def main():
                    "FETCH_SIZE reports half of a wide coalesced streaming read, MI355X_MICROARCH.md HBM section; WRITE_SIZE "
                    "as reported).  whole_call_bytes = sum over the kernels of one call; algorithmic_bytes = 16 B/event + "
                    "the grid, 12 B/event + the image for img_* (SURVEY.md 8(d)).  Summarised by tools/pmc_summary.py."}
-    for tag in ("c2", "c5_share", "img_nearest", "img_bilinear", "prebucketed"):
+    for tag in ("c2", "c5_share", "img_nearest", "img_bilinear", "img_timestamp", "prebucketed"):
         if not os.path.isdir(os.path.join(root, "pmc_fetch_" + tag)):
             continue
         fetch = collect(os.path.join(root, "pmc_fetch_" + tag), "FETCH_SIZE")

@@ -1,8 +1,9 @@
 """The voxel call of one bench workload, alone, for the rocprofv3 PMC passes (tools/profile_round.sh):
     python tools/pmc_workload.py c2        10 M events, 640x480x5   (configs[1], the headline)
     python tools/pmc_workload.py c5_share  50 M events, 1280x720x5  (one rank's share of configs[4])
-    python tools/pmc_workload.py img_nearest | img_bilinear   10 M events, 640x480: events_to_image (int32) /
-                                           events_to_image_torch(bilinear) through the one-pass path (evk_image2.hip)
+    python tools/pmc_workload.py img_nearest | img_bilinear | img_timestamp   10 M events, 640x480: events_to_image (int32) /
+                                           events_to_image_torch(bilinear) / the average-timestamp planes through the one-pass path
+                                           (evk_image2.hip)
 Runs the internal entry point (resident grid, no per-call checks) 8 times so that the counters see exactly the kernels
 of the call: k_part_sorted and k_voxel_tiles2 (evk_voxel2.hip)."""
 import os
@@ -24,6 +25,14 @@ if tag.startswith("img_"):     # the event images of bench.py's image_10m block:
     p = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
     xd, yd, pd = (torch.from_numpy(a).cuda() for a in (x, y, p))
     inf = float("inf")
+    if tag == "img_timestamp":   # bench.py's image_10m.events_to_timestamp_image_torch: the four planes, one-pass path (round 6)
+        td = torch.sort(torch.rand(n, device="cuda") * 0.1).values.contiguous()
+        planes = torch.zeros((4, H + 1, W + 1), dtype=torch.float32, device="cuda")
+        for _ in range(CALLS):
+            assert tiled.timestamp_images2(xd, yd, td, pd, n, H + 1, W + 1, float(W), float(H), 0, 0.0, 0.1, planes, None)
+        torch.cuda.synchronize()
+        print("done", tag)
+        sys.exit(0)
     if tag == "img_nearest":
         cols, kind, img = (xd.int(), yd.int(), pd.int()), "i32", torch.zeros((H, W), dtype=torch.int32, device="cuda")
     else:

@@ -14,7 +14,7 @@ echo "python bench.py (defaults, cpu_baseline included): $((SECONDS - t0)) s wal
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --no-cpu > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${R}_bench_kernel_stats.csv \;
 rm -rf $OUT/stats
-for tag in c2 c5_share img_nearest img_bilinear prebucketed; do
+for tag in c2 c5_share img_nearest img_bilinear img_timestamp prebucketed; do
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_fetch_$tag.log 2>&1
   timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$tag -- python tools/pmc_workload.py $tag > $OUT/pmc_write_$tag.log 2>&1
   # (kernel durations at steady clocks: a few hundred calls -- the first milliseconds of a burst run 15-20 % slower)
