@@ -112,6 +112,7 @@ SIGNATURES = {
                                c_uint32, P],
     "evk_image2_bilinear_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
                                 c_uint32, P],
+    "evk_image2_splat_indexed_f32": [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_timestamp_images2_f32": [P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, c_int,
                                   c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_comm_unique_id": [P],

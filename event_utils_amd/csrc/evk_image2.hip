@@ -195,6 +195,56 @@ struct SrcTsF32 {
     }
 };
 
+// pxs, pys int64, dxs, dys, w float32: interpolate_to_image on caller-computed pixels and fractions (image.py:102-115;
+// V2_FMT_IMGX).  The bilinear record holds {x - tile x0, y - tile y0} with x = px + dx: it can carry the event when that sum IS
+// a float32 value with floor(x) == px and x - px == dx -- always the case when the caller took px, dx from a float32 coordinate,
+// as every upstream caller does (image.py:79-82, 199-202, 253-256) -- and the pixel and its right / lower neighbour are inside
+// the image.  Anything else (a sum that rounds, fractions outside [0, 1), NaN, pixels that wrap or raise in index_put_) is
+// re-read by its index and takes the direct kernel's code (rare_at).
+struct SrcIdxF32 {
+    static constexpr int G = 4, XYW = 24, TPW = 4;
+    const long long *px, *py;
+    const float *dx, *dy, *w;
+    float *img;
+    int h, wd;
+    template <bool NT = false>
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a0 = reinterpret_cast<const uint4 *>(px + ev0)[2 * gl], a1 = reinterpret_cast<const uint4 *>(px + ev0)[2 * gl + 1];
+        const uint4 b0 = reinterpret_cast<const uint4 *>(py + ev0)[2 * gl], b1 = reinterpret_cast<const uint4 *>(py + ev0)[2 * gl + 1];
+        const uint4 c = load_col16<NT>(dx, ev0, gl), d = load_col16<NT>(dy, ev0, gl);
+        r[0] = a0.x, r[1] = a0.y, r[2] = a0.z, r[3] = a0.w, r[4] = a1.x, r[5] = a1.y, r[6] = a1.z, r[7] = a1.w;
+        r[8] = b0.x, r[9] = b0.y, r[10] = b0.z, r[11] = b0.w, r[12] = b1.x, r[13] = b1.y, r[14] = b1.z, r[15] = b1.w;
+        r[16] = c.x, r[17] = c.y, r[18] = c.z, r[19] = c.w, r[20] = d.x, r[21] = d.y, r[22] = d.z, r[23] = d.w;
+    }
+    template <bool NT = false>
+    __device__ __forceinline__ void load_tp(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const uint4 a = load_col16<NT>(w, ev0, gl);
+        r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w;
+    }
+    __device__ __forceinline__ int key_rel(const uint32_t *r, int e, const TileGridG &g, float &xr, float &yr) const {
+        // (a pixel inside the image has a zero high word; its low word is compared as unsigned, so a negative one fails too)
+        const uint32_t pxl = r[2 * e], pxh = r[2 * e + 1], pyl = r[8 + 2 * e], pyh = r[8 + 2 * e + 1];
+        const float fdx = __uint_as_float(r[16 + e]), fdy = __uint_as_float(r[20 + e]);
+        const bool inwin = ((pxh | pyh) == 0u) & (pxl <= (uint32_t)(g.dom_w - 2)) & (pyl <= (uint32_t)(g.dom_h - 2));
+        const int ipx = inwin ? (int)pxl : 0, ipy = inwin ? (int)pyl : 0;
+        const float fpx = (float)ipx, fpy = (float)ipy;
+        const float xf = fpx + fdx, yf = fpy + fdy;
+        const float flx = floorf(xf), fly = floorf(yf);
+        const bool ok = inwin & (flx == fpx) & (xf - fpx == fdx) & (fly == fpy) & (yf - fpy == fdy);
+        const int tx = tile_of(ipx, g.ix), ty = tile_of(ipy, g.iy);
+        xr = ok ? xf - (float)__mul24(tx, g.tw) : 0.0f;
+        yr = ok ? yf - (float)__mul24(ty, g.th) : 0.0f;
+        return ok ? __mul24(ty, g.tiles_x) + tx : -3;
+    }
+    __device__ __forceinline__ uint32_t w_bits(const uint32_t *r, int e) const { return r[e]; }
+    // the direct kernel's per-event code (evk_scatter.hip, k_splat_indexed_f32); false = IndexError
+    __device__ __forceinline__ bool rare_at(int64_t i) const {
+        Splat s;
+        s.px = px[i], s.py = py[i], s.dx = dx[i], s.dy = dy[i];
+        return splat_iwe(img, h, wd, s, w[i]);
+    }
+};
+
 #ifndef IMG_WG
 #define IMG_WG 512    // threads of a tile workgroup (768 and up: the chunk lists no longer fit the 64 KB of static LDS)
 #endif
@@ -837,5 +887,30 @@ extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const f
             (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
             ic.q, flags, out4, (float *)(sb + ic.L.staging));
     }
+    return launch_status();
+}
+
+/* interpolate_to_image (image.py:102-115) on caller-computed pixels and fractions, on the one-pass design: evk_splat_indexed_f32's
+ * arguments and semantics (negative pixels wrap once, anything else outside raises: *oob), the rest as evk_image2_bilinear_f32 */
+extern "C" int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy, const float *w,
+                                            int64_t n, int h, int wd, int tile_w, int tile_h, int flags, float *img,
+                                            uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                            uint32_t *host_report, uint32_t seq, void *stream) {
+    if (n > 0 && (!px || !py || !dx || !dy || !w)) return EVK_EINVAL;
+    if (!(aligned16(px) && aligned16(py) && aligned16(dx) && aligned16(dy) && aligned16(w))) return EVK_EALIGN;
+    if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;
+    ImgCall ic;
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
+    if (rc != EVK_OK) return rc;
+    if (h < 2 || wd < 2) return EVK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY))
+        img_partition<V2_FMT_IMGX>(SrcIdxF32{(const long long *)px, (const long long *)py, dx, dy, w, img, h, wd}, n, ic, index, scratch,
+                                   oob, host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY))
+        k_image_tiles_b<IMG_WG><<<v2_max_items(n, ic.ntiles), IMG_WG, 0, s>>>(
+            (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, img, (float *)(sb + ic.L.staging));
     return launch_status();
 }

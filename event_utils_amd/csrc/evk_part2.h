@@ -175,6 +175,10 @@ struct Part2 {
 //   2 = neither (NaN: contributes nothing) -- and the side run, always written, the event's normalised time stamp (the
 //   column source's w_bits).  16 B/event read, 12 written.  Rare events go to the column source's rare_ts().
 #define V2_FMT_IMGT 13
+// REC = V2_FMT_IMGX (round 6: interpolate_to_image on caller-computed pixels and fractions, image.py:102-115): the IMGB record
+//   and side run; the only difference is the rare path -- an event the record cannot carry (its pixel + fraction is not a
+//   float32 value, or a pixel that wraps / raises) is re-read by its INDEX in the stream (the column source's rare_at()).
+#define V2_FMT_IMGX 14
 // REC = V2_FMT_VOX8W: the 8-byte voxel records, with the EXACT polarities of a sub-chunk staged in LDS (4 more bytes per
 // event) and written as a second dense run when one of them is wide -- instead of a scattered 4-byte store per wide
 // polarity (arbitrary float32 weights: partition 78 -> ~50 us at 10 M events).  The geometry with 8 K-event sub-chunks
@@ -184,7 +188,7 @@ struct Part2 {
 #define V2_DELTA_LIMIT (1u << 20)
 #define V2_CODE_SHIFT 10
 // bytes of LDS per event of the sorted buffer
-__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : ((rec == V2_FMT_VOX8W || rec == V2_FMT_IMGT) ? 12 : rec); }
+__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : ((rec == V2_FMT_VOX8W || rec == V2_FMT_IMGT || rec == V2_FMT_IMGX) ? 12 : rec); }
 // LIVE (round 5; evk_voxel_live.hip): the runs are consumed WHILE the partition is still sorting, by a second kernel on a
 // second stream (k_voxel_live: two tiles per workgroup, one workgroup per CU beside this kernel's).  What that needs here:
 // the table row of a sub-chunk leaves with its run, as write-through 16-byte stores out of an LDS copy (plain 4-byte stores
@@ -202,9 +206,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                                                             uint32_t seq, uint32_t *live_progress = nullptr,
                                                             uint32_t live_epoch = 0) {
     static_assert(!LIVE || (REC == 8 && V2_STORE_SC1), "the live consumer reads 8-byte records written through");
-    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_VOX8W, "record format");
+    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX || REC == V2_FMT_VOX8W, "record format");
     constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
-    constexpr bool IMGBT = REC == V2_FMT_IMGB || REC == V2_FMT_IMGT;   // bilinear formats: {x, y} relative to the tile + a side run
+    constexpr bool IMGBT = REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX;   // bilinear formats: {x, y} relative to the tile + a side run
     constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || IMGBT;   // exact weights staged in LDS, dense side run on demand
     constexpr bool VOX = R8 || REC == 4;                      // voxel formats: a time column, t_norm in the record
     constexpr int LB = v2_fmt_lds_bytes(REC);
@@ -569,7 +573,7 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                 }
             }
             if (any_wide) tmp[65] = 1u;   // (every writer stores the same value)
-        } else if constexpr (REC == V2_FMT_IMGB) {
+        } else if constexpr (REC == V2_FMT_IMGB || REC == V2_FMT_IMGX) {
             bool any_b = false;
 #pragma unroll
             for (int s2 = 0; s2 < EPT; ++s2) {
@@ -590,8 +594,12 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
             if (__any(rare != 0u)) {   // rare: pixels that wrap or raise in index_put_ -- the direct kernel's global atomics
 #pragma unroll
                 for (int s2 = 0; s2 < EPT; ++s2)
-                    if (rare >> s2 & 1u)
-                        dropped += c.rare(xr[s2], yr[s2], __uint_as_float(c.w_bits(tpr + C::TPW * (s2 / G), s2 % G))) ? 0u : 1u;
+                    if (rare >> s2 & 1u) {
+                        if constexpr (REC == V2_FMT_IMGX)   // by its index in the stream (group s2 / G of this thread, event s2 % G)
+                            dropped += c.rare_at(row_base(sc, s2 / G) + (int64_t)G * tl_ + (s2 % G)) ? 0u : 1u;
+                        else
+                            dropped += c.rare(xr[s2], yr[s2], __uint_as_float(c.w_bits(tpr + C::TPW * (s2 / G), s2 % G))) ? 0u : 1u;
+                    }
             }
             rare = 0;
         } else if constexpr (REC == V2_FMT_IMGT) {

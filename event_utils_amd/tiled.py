@@ -449,6 +449,9 @@ TILED_MIN_EVENTS_IMAGE_BILINEAR = 1
 # stream synchronisation (ts[0] / ts[-1] read by the kernel, the IndexError check on the partition kernel's report), the direct one
 # has both: 0.054 against 0.090 ms per public call at 50 k events (profiles/r06_timestamp_images.txt): any count
 TILED_MIN_EVENTS_TIMESTAMP = 1
+# interpolate_to_image on caller-computed pixels / fractions (round 6): four global atomics per event at ~21 G/s against the two
+# launches' ~18 us; the call synchronises either way (it raises before it returns)
+TILED_MIN_EVENTS_SPLAT_INDEXED = 100_000
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
@@ -486,6 +489,39 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     else:
         _rezero_on_failure(index, lambda: _lib.call("evk_image2_%s_f32" % ("bilinear" if kind == "bilinear" else "nearest"),
                                                     D.ptr(xd), D.ptr(yd), D.ptr(wd_), n, H, W, clipx, clipy, *tail))
+    return True
+
+
+def splat_indexed2(pxs, pys, dxs, dys, ws, n, H, W, img, oob, stage=0):
+    """evk_image2_splat_indexed_f32: interpolate_to_image (image.py:102-115) of caller-computed pixels / fractions ADDED to `img`
+    (H, W) on the one-pass path.  Returns False when it has no tiling for this image (the caller then uses the direct kernel)."""
+    L = _lib.lib()
+    shape = voxel2_shape(H, W, 1)
+    if shape is None or H < 2 or W < 2:
+        return False
+    tw, th = shape
+    if (tw + 2) * (th + 1) > 2048:
+        return False
+    dev = img.device
+    ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
+    key = ("image2", ntiles, n, tw, th)
+    sizes = _staging_bytes.get(key)
+    if sizes is None:
+        sizes = (int(L.evk_voxel2_index_len(ntiles, n)), int(L.evk_image2_scratch_bytes(ntiles, n, tw, th)))
+        if sizes[0] <= 0:
+            return False
+        _staging_bytes[key] = sizes
+    index = _zbuf("image2_index", sizes[0], dev)
+    scratch = _buf("voxel2_scratch", sizes[1], dev)
+    flags = stage
+    if not FORCE["image_fixed"]:
+        flags |= _lib.EVK_IMAGE2_NO_FIXED
+    if not FORCE["xcd_order"]:
+        flags |= 64
+    report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
+    _rezero_on_failure(index, lambda: _lib.call(
+        "evk_image2_splat_indexed_f32", D.ptr(pxs), D.ptr(pys), D.ptr(dxs), D.ptr(dys), D.ptr(ws), n, H, W, tw, th, flags, D.ptr(img),
+        D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None, report, seq, D.stream()))
     return True
 
 

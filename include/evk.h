@@ -441,6 +441,14 @@ int evk_image2_nearest_f32(const float *x, const float *y, const float *w, int64
 int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int64_t n, int h, int wd, float clipx,
                             float clipy, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
                             int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+/* evk_splat_indexed_f32 (above; interpolate_to_image on caller-computed pixels and fractions, image.py:102-115) on the same design
+ * (round 6): an event whose px + dx, py + dy are float32 values with floor() == px, py -- every event whose pixel and fraction
+ * were taken from a float32 coordinate, as upstream's callers do -- travels as a bilinear record; any other (a sum that rounds,
+ * fractions outside [0, 1), NaN, pixels that wrap or raise) is re-read by its index and takes the direct kernel's code inside
+ * the partition kernel.  Same arguments and *oob as evk_splat_indexed_f32, the rest as evk_image2_bilinear_f32 (always adds). */
+int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy, const float *w, int64_t n,
+                                 int h, int wd, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
+                                 int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
 /* evk_timestamp_images_f32 (above; events_to_timestamp_image[_torch], image.py:219-353: eight global atomics per event) on
  * the same design (round 6): one partition -- 16 B/event read, a 12-byte record {x, y relative to the tile; the event's
  * class in their sign bits; its normalised time stamp} moved once -- and a tile kernel with four LDS windows per tile

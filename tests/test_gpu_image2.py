@@ -344,3 +344,68 @@ def test_timestamp_images_one_pass_errors_small_images_and_unsorted_time(E):
     assert msgs[0] == msgs[1]
     a, b = E.events_to_timestamp_image_torch(*cols, sensor_size=(H, W))           # the stream works on after the error
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
+# ---- interpolate_to_image on caller-computed pixels / fractions, one-pass path (round 6: evk_image2_splat_indexed_f32) ---------
+def test_interpolate_to_image_one_pass_against_direct_kernel_and_oracle(E):
+    """image.py:102-115 through the public function on device tensors: events whose px + dx is a float32 coordinate travel as
+    bilinear records, the others -- fractions that are not the fraction of any float32 coordinate at that pixel, fractions
+    outside [0, 1), NaN, pixels at -1 (wrap) -- take the direct kernel's code inside the partition kernel; the image is
+    accumulated IN PLACE on top of what it held; out-of-range pixels raise IndexError on both kernel families."""
+    import os
+    from event_utils_amd import _lib
+    from event_utils_amd.representations import image as I
+    rng = np.random.default_rng(41)
+    n, H, W = 1_500_000, 300, 400
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    hot = rng.random(n) < 0.4                                   # a blob: cut tiles
+    x[hot] = rng.uniform(100, 130, hot.sum()).astype(np.float32); y[hot] = rng.uniform(50, 70, hot.sum()).astype(np.float32)
+    px, py = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+    dx, dy = (x - np.floor(x)).astype(np.float32), (y - np.floor(y)).astype(np.float32)
+    k = n // 10
+    dx[:k] = rng.uniform(0, 1, k).astype(np.float32)            # 24 random mantissa bits: px + dx rounds -> rare path
+    dy[k:2 * k] = rng.uniform(0, 1, k).astype(np.float32)
+    dx[2 * k:2 * k + 500] = 1.5; dy[2 * k + 500:2 * k + 1000] = -0.25
+    px[2 * k + 1000:2 * k + 2000] = -1; py[2 * k + 2000:2 * k + 3000] = -1          # wrap to the last column / row
+    for weights in ("unit", "float"):
+        w = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32) if weights == "unit" else rng.normal(size=n).astype(np.float32)
+        base = rng.normal(size=(H, W)).astype(np.float32)
+        ref = R.interpolate_to_image(px, py, dx, dy, w, base.copy(), "f64")
+        mag = R.interpolate_to_image(px, py, np.abs(dx), np.abs(dy), np.abs(w), np.abs(base), "f64")
+        cols = [torch.from_numpy(a).cuda() for a in (px, py, dx, dy, w)]
+        calls = []
+        orig = _lib.call
+        _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+        try:
+            got = {}
+            for impl in ("tiled", "direct"):
+                os.environ["EVK_IMPL"] = impl
+                img = torch.from_numpy(base.copy()).cuda()
+                out = I.interpolate_to_image(*cols, img)
+                assert out is img
+                got[impl] = img.cpu().numpy().astype(np.float64)
+                assert calls[-1] == ("evk_image2_splat_indexed_f32" if impl == "tiled" else "evk_splat_indexed_f32")
+        finally:
+            _lib.call = orig
+            os.environ["EVK_IMPL"] = "tiled"
+        for impl in got:
+            assert np.max(np.abs(got[impl] - ref)) <= 1e-5 * np.max(np.abs(ref)) + 4e-7 * np.max(mag), impl
+    # a NaN fraction poisons exactly the pixels the reference poisons; a CPU image is round-tripped and still edited in place
+    dxn = dx.copy(); dxn[123_456] = np.nan
+    w = np.ones(n, np.float32)
+    ref = R.interpolate_to_image(px, py, dxn, dy, w, np.zeros((H, W), np.float32), "f64")
+    img = torch.zeros(H, W)
+    I.interpolate_to_image(*[torch.from_numpy(a) for a in (px, py, dxn, dy, w)], img)
+    assert np.array_equal(np.isnan(img.numpy()), np.isnan(ref)) and np.isnan(ref).sum() == 4
+    # pixels whose right neighbour is outside raise, with the same message on both kernel families
+    pxb = px.copy(); pxb[77] = W - 1
+    msgs = []
+    for impl in ("tiled", "direct"):
+        os.environ["EVK_IMPL"] = impl
+        try:
+            with pytest.raises(IndexError) as ei:
+                I.interpolate_to_image(*[torch.from_numpy(a).cuda() for a in (pxb, py, dx, dy, w)], torch.zeros(H, W, device="cuda"))
+            msgs.append(str(ei.value))
+        finally:
+            os.environ["EVK_IMPL"] = "tiled"
+    assert msgs[0] == msgs[1]

@@ -392,7 +392,18 @@ def case_prims(rng):
             if which == "splat":
                 px = rng.integers(0, W - 1, n); py = rng.integers(0, H - 1, n)
                 dx = rng.random(n).astype(np.float32); dy = rng.random(n).astype(np.float32)
-                w = rng.normal(size=n).astype(np.float32)
+                kind = str(rng.choice(["random", "coords", "mixed"]))
+                if kind != "random":      # pixels and fractions taken from float32 coordinates (what upstream's callers pass): records
+                    xc, yc = coords(rng, n, H, W, True, str(rng.choice(["uniform", "blob", "pixel", "edge"])))
+                    take = np.ones(n, bool) if kind == "coords" else rng.random(n) < 0.7
+                    px = np.where(take, np.floor(xc).astype(np.int64), px); py = np.where(take, np.floor(yc).astype(np.int64), py)
+                    dx = np.where(take, xc - np.floor(xc), dx).astype(np.float32); dy = np.where(take, yc - np.floor(yc), dy).astype(np.float32)
+                    px = np.minimum(px, W - 2); py = np.minimum(py, H - 2)
+                if n > 64 and rng.random() < 0.5:
+                    px[:16] = -1; py[16:32] = -1                  # wrap once, as index_put_ does
+                w = rng.normal(size=n).astype(np.float32) if rng.random() < 0.5 else weights(rng, n, str(rng.choice(["pm1", "pm1z", "ints"])))
+                os.environ["EVK_IMPL"] = str(rng.choice(["auto", "tiled", "direct"]))
+                desc += " %s impl=%s" % (kind, os.environ["EVK_IMPL"])
                 w1 = rng.normal(size=(2, n)).astype(np.float32); w2 = rng.normal(size=(2, n)).astype(np.float32)
                 ref = R.interpolate_to_image(px, py, dx, dy, w, np.zeros((H, W), np.float32), accum="f64")
                 img = torch.zeros(H, W, device="cuda")
@@ -426,6 +437,8 @@ def case_prims(rng):
             return desc + " sigma=%g" % sigma, None if np.array_equal(got, ref) else "blur not bit-identical (max %.3e)" % np.max(np.abs(got - ref))
     except Exception as e:  # noqa: BLE001
         return desc, "raised %s: %s" % (type(e).__name__, e)
+    finally:
+        os.environ.pop("EVK_IMPL", None)
 
 
 def case_search(rng):
