@@ -138,7 +138,12 @@ class DeviceEvents:
             if precision == "auto":
                 precision = "f64" if any(a.dtype == torch.float64 for a in (xs, ys, ts, ps)) else "f32"
             dt = torch.float32 if precision == "f32" else torch.float64
-            return cls(*(D.to_device(a, dt, device) for a in (xs, ys, ts, ps)))
+            cols = [D.to_device(a, dt, device) for a in (xs, ys, ts, ps)]
+            # device SLICES (xs[a:b]) start off a 16-byte boundary three times out of four, and the bucketing kernels read 16 bytes
+            # at a time: an event set is evaluated again and again, so misaligned columns are copied once (tiled.realign)
+            if all(c.dim() == 1 for c in cols) and cols[0].shape[0] >= 1024:
+                cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]
+            return cls(*cols)
         cols = [np.asarray(a).reshape(-1) for a in (xs, ys, ts, ps)]
         n = len(cols[2])
         t_offset, dev_cols = 0.0, None

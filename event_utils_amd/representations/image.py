@@ -116,6 +116,8 @@ def events_to_image_torch(xs, ys, ps, device=None, sensor_size=(180, 240), clip_
     # Above the crossover: one-pass partition + LDS tiles (evk_image2.hip); below it, or for columns it cannot take
     # (unaligned views), one global atomic per contribution (evk_scatter.hip).  Same semantics either way.
     img = None
+    if xd.shape == pd.shape:
+        xd, yd, pd = tiled.realign((xd, yd, pd), tiled.default_impl(), 4 if bilinear else 1)    # (device slices: tiled.realign)
     if tiled.can_tile_image((xd, yd, pd), tiled.default_impl(), bilinear) and xd.shape == pd.shape:
         fresh = (not bilinear) and float(default) == 0.0
         if fresh:           # every pixel is written: no memset
@@ -149,6 +151,8 @@ def interpolate_to_image(pxs, pys, dxs, dys, weights, img):
     n = pxs.shape[0]
     from .. import tiled
     impl = tiled.default_impl()
+    if all(c.dim() == 1 and c.shape[0] == n for c in a) and impl != "direct" and n * 4 >= tiled.REALIGN_ATOMICS:
+        a = [c if (c.is_contiguous() and c.data_ptr() % 16 == 0) else c.clone() for c in a]       # (device slices: tiled.realign)
     # (round 6) the one-pass partition + LDS windows for events whose pixel + fraction is a float32 coordinate -- what every
     # upstream caller passes --, the direct kernel's four global atomics for the others, decided per event by the partition kernel
     fast = (work.dtype == torch.float32 and work.dim() == 2 and impl in ("tiled", "auto")
@@ -251,6 +255,8 @@ def _timestamp_images_device(xd, yd, td, pd, img_size, clip_out_of_range, interp
     # one-pass path cannot take (unaligned views), eight global atomics per event (evk_scatter.hip).  Same semantics either way.
     impl = tiled.default_impl()
     from_events = ta is None
+    if xd.shape == yd.shape == td.shape == pd.shape:
+        xd, yd, td, pd = tiled.realign((xd, yd, td, pd), impl, 8)                                 # (device slices: tiled.realign)
     fast = (tiled.can_tile_image((xd, yd, td, pd), impl, True) and xd.shape == yd.shape == td.shape == pd.shape
             and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_TIMESTAMP)
             and tiled.timestamp_images2(xd, yd, td, pd, n, img_size[0], img_size[1], clipx, clipy, mode, 0.0 if from_events else ta,

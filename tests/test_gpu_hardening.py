@@ -648,3 +648,68 @@ def test_uploads_convert_on_the_device_like_numpy_on_the_host():
         xy = rng.integers(0, 640, (500, 2))
         assert np.array_equal(D.to_device(xy[:, 1], torch.int32).cpu().numpy(), xy[:, 1].astype(np.int32))
         assert D.to_device(np.zeros(0), torch.float32).shape == (0,)
+
+
+def test_device_slices_take_the_one_pass_paths():
+    """A device SLICE (xs[a:b]) starts wherever the slice does -- off a 16-byte boundary three times out of four.  Such columns
+    used to fall to the direct kernels (2-8 global atomics per event); from a few hundred thousand events on they are copied to
+    aligned buffers and take the one-pass paths: same results as the aligned stream, the one-pass entry points called; small
+    slices and EVK_IMPL=direct keep the direct kernels; resident event sets built from slices are bucketed."""
+    import numpy as np
+    import torch
+    import event_utils_amd as E
+    from event_utils_amd import _lib, tiled
+    from event_utils_amd.representations import image as I, voxel_grid as V
+    from oracle import reference_np as R
+    rng = np.random.default_rng(51)
+    n, H, W, B = 1_200_003, 180, 240, 5
+    x = rng.uniform(0, W - 1, n).astype(np.float32); y = rng.uniform(0, H - 1, n).astype(np.float32)
+    t = np.sort(rng.uniform(0, 0.1, n)).astype(np.float32); p = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    xd, yd, td, pd = (torch.from_numpy(a).cuda() for a in (x, y, t, p))
+    calls = []
+    orig = _lib.call
+    _lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+
+    def close(a, ref, tol=1e-5):
+        a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+        assert np.max(np.abs(a - ref)) <= tol * max(np.max(np.abs(ref)), 1e-30)
+    try:
+        for off in (1, 2, 3):
+            sl = slice(off, n - 1)
+            cx, cy, ct, cp = (c[sl] for c in (xd, yd, td, pd))
+            assert cx.data_ptr() % 16 != 0
+            del calls[:]
+            g = V.events_to_voxel_torch(cx.floor(), cy.floor(), ct, cp, B, sensor_size=(H, W))        # floor(): fresh, aligned
+            g2 = V.events_to_voxel_torch(torch.floor(xd)[sl], torch.floor(yd)[sl], ct, cp, B, sensor_size=(H, W))
+            assert calls.count("evk_voxel2_f32") == 2 and "evk_voxel_from_events_f32" not in calls
+            ref = R.events_to_voxel_torch(np.floor(x[sl]), np.floor(y[sl]), t[sl], p[sl], B, sensor_size=(H, W), accum="f64")
+            close(g.cpu().numpy(), ref); close(g2.cpu().numpy(), ref)
+            del calls[:]
+            img = I.events_to_image_torch(cx, cy, cp, sensor_size=(H, W), interpolation='bilinear')
+            assert "evk_image2_bilinear_f32" in calls and "evk_image_bilinear_f32" not in calls
+            close(img.cpu().numpy(), R.events_to_image_torch(x[sl], y[sl], p[sl], sensor_size=(H, W), interpolation='bilinear', accum="f64"))
+            del calls[:]
+            a, b = I.events_to_timestamp_image_torch(cx, cy, ct, cp, sensor_size=(H, W))
+            assert "evk_timestamp_images2_f32" in calls and "evk_timestamp_images_f32" not in calls
+            ra, rb = R.events_to_timestamp_image_torch(x[sl], y[sl], t[sl], p[sl], sensor_size=(H, W), accum="f64")
+            close(a.cpu().numpy(), ra); close(b.cpu().numpy(), rb)
+            pos, neg = V.events_to_neg_pos_voxel_torch(torch.floor(xd)[sl], torch.floor(yd)[sl], ct, cp, B, sensor_size=(H, W))
+            close((pos - neg).cpu().numpy(), R.events_to_voxel_torch(np.floor(x[sl]), np.floor(y[sl]), t[sl], np.where(p[sl] > 0, 1, -1).astype(np.float32),
+                                                                        B, sensor_size=(H, W), accum="f64"))
+        # a small slice keeps the direct kernel (the copy would cost more than it saves), and so does EVK_IMPL=direct
+        del calls[:]
+        V.events_to_voxel_torch(torch.floor(xd)[1:50_001], torch.floor(yd)[1:50_001], td[1:50_001], pd[1:50_001], B, sensor_size=(H, W))
+        assert "evk_voxel_from_events_f32" in calls and "evk_voxel2_f32" not in calls
+        # resident events built from slices: bucketed (the objective's fused path), same value as from the aligned copy
+        ev_s = E.DeviceEvents.from_arrays(xd[1:], yd[1:], td[1:], pd[1:])
+        ev_a = E.DeviceEvents.from_arrays(xd[1:].clone(), yd[1:].clone(), td[1:].clone(), pd[1:].clone())
+        assert all(c.data_ptr() % 16 == 0 for c in (ev_s.x, ev_s.y, ev_s.t, ev_s.p))
+        o = E.variance_objective(); o.sensor_size = (H, W)
+        w = E.linvel_warp()
+        q = np.array([30.0, -20.0])
+        fs = o.evaluate_function(q, ev_s, None, None, None, w, (H, W), 1.0)
+        fa = o.evaluate_function(q, ev_a, None, None, None, w, (H, W), 1.0)
+        assert fs == fa and tiled.iwe_plan(ev_s, float(t[-1]), 30.0, -20.0, float(W), float(H), H + 1, W + 1, 0) is not None
+    finally:
+        _lib.call = orig
+    E.check_errors()
