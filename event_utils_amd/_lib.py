@@ -33,6 +33,7 @@ EVK_VOXEL_DETERMINISTIC = 256
 EVK_IMAGE2_NO_FIXED = 512
 EVK_VOXEL2_REC4, EVK_VOXEL2_REC8, EVK_VOXEL2_NO_COUNT, EVK_VOXEL2_WG512 = 1024, 2048, 4096, 8192
 EVK_VOXEL2_LIVE = 16384
+EVK_COLUMNS_UNALIGNED = 65536
 EVK_VOXEL2_NO_COUNT2 = 32768
 EVK_STAGE_STATS, EVK_STAGE_COMPACT, EVK_STAGE_LEGACY_SCATTER = 16, 32, 64
 

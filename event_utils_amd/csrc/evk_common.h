@@ -77,6 +77,11 @@ __device__ __forceinline__ Vec4<T> load4(const T *p, int64_t i4) {
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// columns of the one-pass entry points: 16-byte aligned, or -- with EVK_COLUMNS_UNALIGNED (evk.h) in `flags` -- aligned to their
+// element (4 bytes; 8 for int64 pixels): the kernels' 16-byte loads are dword-aligned loads (evk_part.h, load_col16)
+inline bool column_ok(const void *p, int flags, unsigned elem = 4) {
+    return (reinterpret_cast<uintptr_t>(p) & ((flags & EVK_COLUMNS_UNALIGNED) ? elem - 1u : 15u)) == 0;
+}
 
 // Streaming launch shape: enough 256-thread blocks to fill 256 CUs x 8 blocks, grid-stride beyond that.
 inline int stream_grid(int64_t work_items, int per_thread = 1) {

@@ -209,8 +209,10 @@ struct SrcIdxF32 {
     int h, wd;
     template <bool NT = false>
     __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
-        const uint4 a0 = reinterpret_cast<const uint4 *>(px + ev0)[2 * gl], a1 = reinterpret_cast<const uint4 *>(px + ev0)[2 * gl + 1];
-        const uint4 b0 = reinterpret_cast<const uint4 *>(py + ev0)[2 * gl], b1 = reinterpret_cast<const uint4 *>(py + ev0)[2 * gl + 1];
+        // (16-byte loads at dword alignment, as load_col16: 2 gl and 2 gl + 1 are the two halves of this lane's four int64)
+        const float *fx = reinterpret_cast<const float *>(px + ev0), *fy = reinterpret_cast<const float *>(py + ev0);
+        const uint4 a0 = load_col16<NT>(fx, 0, 2 * gl), a1 = load_col16<NT>(fx, 0, 2 * gl + 1);
+        const uint4 b0 = load_col16<NT>(fy, 0, 2 * gl), b1 = load_col16<NT>(fy, 0, 2 * gl + 1);
         const uint4 c = load_col16<NT>(dx, ev0, gl), d = load_col16<NT>(dy, ev0, gl);
         r[0] = a0.x, r[1] = a0.y, r[2] = a0.z, r[3] = a0.w, r[4] = a1.x, r[5] = a1.y, r[6] = a1.z, r[7] = a1.w;
         r[8] = b0.x, r[9] = b0.y, r[10] = b0.z, r[11] = b0.w, r[12] = b1.x, r[13] = b1.y, r[14] = b1.z, r[15] = b1.w;
@@ -813,7 +815,8 @@ extern "C" int evk_image2_nearest_f32(const float *x, const float *y, const floa
                                       void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                                       uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !w)) return EVK_EINVAL;
-    if (!(aligned16(x) && aligned16(y) && aligned16(w))) return EVK_EALIGN;
+    if (!(column_ok(x, flags) && column_ok(y, flags) && column_ok(w, flags))) return EVK_EALIGN;
+    flags &= ~EVK_COLUMNS_UNALIGNED;
     ImgCall ic;
     const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
     if (rc != EVK_OK) return rc;
@@ -833,7 +836,8 @@ extern "C" int evk_image2_bilinear_f32(const float *x, const float *y, const flo
                                        void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                                        uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !w)) return EVK_EINVAL;
-    if (!(aligned16(x) && aligned16(y) && aligned16(w))) return EVK_EALIGN;
+    if (!(column_ok(x, flags) && column_ok(y, flags) && column_ok(w, flags))) return EVK_EALIGN;
+    flags &= ~EVK_COLUMNS_UNALIGNED;
     if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;   // the ring of a window is ADDED to the image: always accumulates
     ImgCall ic;
     const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
@@ -863,7 +867,8 @@ extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const f
     if (mode < 0 || mode > 2 || (flags & EVK_VOXEL_OVERWRITE)) return EVK_EINVAL;   // (the windows are ADDED to the images)
     const int from_events = (flags & EVK_VOXEL_T_FROM_EVENTS) ? 1 : 0;
     flags &= ~EVK_VOXEL_T_FROM_EVENTS;
-    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    if (!(column_ok(x, flags) && column_ok(y, flags) && column_ok(t, flags) && column_ok(p, flags))) return EVK_EALIGN;
+    flags &= ~EVK_COLUMNS_UNALIGNED;
     ImgCall ic;
     const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, out4, index, scratch, scratch_bytes, host_report, IMG_TS_PLANES);
     if (rc != EVK_OK) return rc;
@@ -897,7 +902,9 @@ extern "C" int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py
                                             uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
                                             uint32_t *host_report, uint32_t seq, void *stream) {
     if (n > 0 && (!px || !py || !dx || !dy || !w)) return EVK_EINVAL;
-    if (!(aligned16(px) && aligned16(py) && aligned16(dx) && aligned16(dy) && aligned16(w))) return EVK_EALIGN;
+    if (!(column_ok(px, flags, 8) && column_ok(py, flags, 8) && column_ok(dx, flags) && column_ok(dy, flags) && column_ok(w, flags)))
+        return EVK_EALIGN;
+    flags &= ~EVK_COLUMNS_UNALIGNED;
     if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;
     ImgCall ic;
     const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);

@@ -90,15 +90,24 @@ __device__ __forceinline__ float time_norm(float t, const TimeNorm &k) { return 
 // records the partition writes (and the tile kernel reads back) in L2 / MALL: 10 M events from HBM 0.0730 -> 0.0711 ms, 50 M events
 // 0.340 -> 0.335 ms (tools/ab.sh, ROTATE=1).  Only a loop that re-reads ONE cache-sized stream call after call -- rounds 1-3's
 // bench -- is slower with it (0.0686 -> 0.0715 ms: the columns no longer survive in the Infinity Cache from call to call).
+// (round 6) The 16 bytes are declared DWORD-aligned: gfx950 takes a global_load_dwordx4 at any dword boundary, and the instruction
+// is the same one (checked in the ISA: no kernel changed) -- so a column may start anywhere, e.g. a device slice xs[a:b]
+// (EVK_COLUMNS_UNALIGNED: the caller then guarantees that the 12 bytes behind the column's last event are readable, because a
+// group that is only partly inside the stream is loaded whole).
 typedef uint32_t evk_u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) evk_quad4 {
+    evk_u32x4 v;
+};
 template <bool NT>
 __device__ __forceinline__ uint4 load_col16(const float *col, int64_t ev0, uint32_t gl) {
-    if constexpr (NT) {
-        const evk_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const evk_u32x4 *>(col + ev0) + gl);
-        return make_uint4(v.x, v.y, v.z, v.w);
-    } else {
-        return reinterpret_cast<const uint4 *>(col + ev0)[gl];
-    }
+    const evk_quad4 *q = reinterpret_cast<const evk_quad4 *>(col + ev0) + gl;
+    evk_u32x4 v;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Waddress-of-packed-member"
+    if constexpr (NT) v = __builtin_nontemporal_load(&q->v);
+    else v = q->v;
+#pragma clang diagnostic pop
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 struct SrcF32 {  // four float32 SoA columns, 16 B / event
     static constexpr int G = 4, XYW = 8, TPW = 8;

@@ -1102,10 +1102,10 @@ extern "C" int evk_voxel2_f32(const float *x, const float *y, const float *t, co
                               uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
                               uint32_t seq, void *stream) {
     if (n > 0 && (!x || !y || !t || !p)) return EVK_EINVAL;
-    if (!(aligned16(x) && aligned16(y) && aligned16(t) && aligned16(p))) return EVK_EALIGN;
+    if (!(column_ok(x, flags) && column_ok(y, flags) && column_ok(t, flags) && column_ok(p, flags))) return EVK_EALIGN;
     const SrcF32 c{x, y, t, p};
-    return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags, vox, index, scratch, scratch_bytes, oob, host_report,
-                  seq, stream);
+    return voxel2(c, n, h, wd, tile_w, tile_h, t_first, t_last, B, flags & ~EVK_COLUMNS_UNALIGNED, vox, index, scratch, scratch_bytes,
+                  oob, host_report, seq, stream);
 }
 
 extern "C" int evk_voxel2_band_f32(int64_t n, int h, int wd, int tile_w, int tile_h, int B, int flags, int tile_row_lo,

@@ -151,13 +151,13 @@ def interpolate_to_image(pxs, pys, dxs, dys, weights, img):
     n = pxs.shape[0]
     from .. import tiled
     impl = tiled.default_impl()
-    if all(c.dim() == 1 and c.shape[0] == n for c in a) and impl != "direct" and n * 4 >= tiled.REALIGN_ATOMICS:
-        a = [c if (c.is_contiguous() and c.data_ptr() % 16 == 0) else c.clone() for c in a]       # (device slices: tiled.realign)
+    if all(c.dim() == 1 and c.shape[0] == n for c in a):
+        a = list(tiled.realign(tuple(a), impl, 4))                                                 # (device slices: tiled.realign)
     # (round 6) the one-pass partition + LDS windows for events whose pixel + fraction is a float32 coordinate -- what every
     # upstream caller passes --, the direct kernel's four global atomics for the others, decided per event by the partition kernel
     fast = (work.dtype == torch.float32 and work.dim() == 2 and impl in ("tiled", "auto")
             and 0 < n <= 4_000_000_000 and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_SPLAT_INDEXED)
-            and all(c.dim() == 1 and c.shape[0] == n and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in a)
+            and all(c.dim() == 1 and c.shape[0] == n and tiled.column_ok(c) for c in a)
             and tiled.splat_indexed2(*a, n, work.shape[0], work.shape[1], work, oob))
     if not fast:
         _lib.call("evk_splat_indexed_f32", D.ptr(a[0]), D.ptr(a[1]), D.ptr(a[2]), D.ptr(a[3]), D.ptr(a[4]), n, work.shape[0],

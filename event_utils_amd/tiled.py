@@ -228,24 +228,42 @@ def want_compact(key_mode, n, tw_log2, th_log2):
 
 
 # A device SLICE (xs[a:b]: a window of a resident stream, voxel_grid.py:109-111, the data loaders' index ranges) starts wherever
-# the slice does -- off a 16-byte boundary three times out of four -- and the one-pass kernels read their columns 16 bytes at a
-# time.  Such columns (and strided views) used to fall to the direct kernels: 0.96 ms instead of 0.072 ms for a 10 M-event voxel
-# grid.  From REALIGN_ATOMICS / (global atomics per event of the direct kernel) events on they are copied to aligned buffers first
-# (16 B/event read and written: ~half of a one-pass call); below, the direct kernel is the cheaper of the two.
+# the slice does -- off a 16-byte boundary three times out of four.  Such columns used to fall to the direct kernels: 0.98 ms
+# instead of 0.072 ms for a 10 M-event voxel grid.  The one-pass kernels' 16-byte loads are dword-aligned loads (gfx950 takes them
+# at any dword boundary; evk_part.h, load_col16), so a misaligned column is read WHERE IT LIES (EVK_COLUMNS_UNALIGNED) -- provided
+# the 12 bytes behind its last event belong to the same storage (a group of four events that is only partly inside the stream is
+# loaded whole): true for every slice that stops short of its parent's end.  A column without that slack, or a strided view, is
+# copied to an aligned buffer from REALIGN_ATOMICS / (global atomics per event of the direct kernel) events on; below, the direct
+# kernel is the cheaper of the two.
 REALIGN_ATOMICS = 800_000
 
 
+def column_ok(c):
+    """Can the one-pass kernels read this device column in place?  Contiguous, and 16-byte aligned or followed by three more
+    elements' worth of readable storage."""
+    if not c.is_contiguous():
+        return False
+    if c.data_ptr() % 16 == 0:
+        return True
+    es = c.element_size()
+    return c.data_ptr() % es == 0 and c.untyped_storage().nbytes() - (c.storage_offset() + c.shape[0]) * es >= 3 * es
+
+
+def unaligned_flag(cols):
+    """EVK_COLUMNS_UNALIGNED when one of the columns (column_ok) does not start on a 16-byte boundary."""
+    return _lib.EVK_COLUMNS_UNALIGNED if any(c is not None and c.data_ptr() % 16 for c in cols) else 0
+
+
 def realign(cols, impl, atomics_per_event):
-    """`cols` (4-byte device columns of one length, or None entries) as the one-pass paths need them: unchanged when they already
-    are contiguous and 16-byte aligned, the call is small, or EVK_IMPL=direct; else aligned copies."""
+    """`cols` (device columns of one length, or None entries) as the one-pass paths can take them: unchanged when they can be read
+    in place (column_ok), the call is small, or EVK_IMPL=direct; else aligned copies of the ones that cannot."""
     import torch
     live = [c for c in cols if c is not None]
     if impl == "direct" or not live or live[0].shape[0] * atomics_per_event < REALIGN_ATOMICS:
         return cols
-    ok = lambda c: c.is_contiguous() and c.data_ptr() % 16 == 0     # noqa: E731
-    if all(ok(c) for c in live) or not all(c.element_size() == 4 and c.is_cuda and c.dim() == 1 for c in live):
+    if not all(c.is_cuda and c.dim() == 1 for c in live) or all(column_ok(c) for c in live):
         return cols
-    return tuple(c if (c is None or ok(c)) else c.clone(memory_format=torch.contiguous_format) for c in cols)
+    return tuple(c if (c is None or column_ok(c)) else c.clone(memory_format=torch.contiguous_format) for c in cols)
 
 
 def can_tile(cols, impl, min_events=None):
@@ -255,7 +273,7 @@ def can_tile(cols, impl, min_events=None):
     n = cols[0].shape[0]
     if impl not in ("tiled", "auto") or n == 0 or n > 4_000_000_000:
         return False
-    if not all(c.dtype == torch.float32 and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in cols):
+    if not all(c.dtype == torch.float32 and column_ok(c) for c in cols):
         return False
     return impl == "tiled" or n >= (TILED_MIN_EVENTS if min_events is None else min_events)
 
@@ -450,6 +468,8 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
             oob.ptr if oob is not None else None, report, seq, D.stream())
     if native is None:
+        if any(c is not None and c.data_ptr() % 16 for c in cols):      # a device slice, read where it lies (can_tile checked the slack behind it)
+            tail = tail[:7] + (flags | _lib.EVK_COLUMNS_UNALIGNED,) + tail[8:]
         _rezero_on_failure(index, lambda: _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail))
     else:
         _rezero_on_failure(index, lambda: _lib.call("evk_%s_native_f32" % ver, *native.head(), *tail))
@@ -498,6 +518,11 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     index = _zbuf("image2_index", sizes[0], dev)          # (its own: the header words [0], [1] mean something else here)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
     flags = stage | (_lib.EVK_VOXEL_OVERWRITE if (fresh and kind != "bilinear") else 0)
+    if kind == "i32":
+        if any(c is not None and c.data_ptr() % 16 for c in (xd, yd, wd_)):
+            return False                  # (the integer entry point reads aligned columns only; its callers upload them)
+    else:
+        flags |= unaligned_flag((xd, yd, wd_))
     if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
     if not FORCE["xcd_order"]:
@@ -534,7 +559,7 @@ def splat_indexed2(pxs, pys, dxs, dys, ws, n, H, W, img, oob, stage=0):
         _staging_bytes[key] = sizes
     index = _zbuf("image2_index", sizes[0], dev)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
-    flags = stage
+    flags = stage | unaligned_flag((pxs, pys, dxs, dys, ws))
     if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
     if not FORCE["xcd_order"]:
@@ -569,7 +594,7 @@ def timestamp_images2(xd, yd, td, pd, n, H, W, clipx, clipy, mode, ta, tdiv, out
         _staging_bytes[key] = sizes
     index = _zbuf("image2_index", sizes[0], dev)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
-    flags = stage | (_lib.EVK_VOXEL_T_FROM_EVENTS if from_events else 0)
+    flags = stage | (_lib.EVK_VOXEL_T_FROM_EVENTS if from_events else 0) | unaligned_flag((xd, yd, td, pd))
     if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
     if not FORCE["xcd_order"]:
@@ -588,7 +613,7 @@ def can_tile_image(cols, impl, bilinear=False):
     n = cols[0].shape[0]
     if impl not in ("tiled", "auto") or n == 0 or n > 4_000_000_000:
         return False
-    if not all(c is None or (c.element_size() == 4 and c.is_contiguous() and c.data_ptr() % 16 == 0) for c in cols):
+    if not all(c is None or (c.element_size() == 4 and column_ok(c)) for c in cols):
         return False
     return impl == "tiled" or n >= (TILED_MIN_EVENTS_IMAGE_BILINEAR if bilinear else TILED_MIN_EVENTS_IMAGE)
 

@@ -652,9 +652,11 @@ def test_uploads_convert_on_the_device_like_numpy_on_the_host():
 
 def test_device_slices_take_the_one_pass_paths():
     """A device SLICE (xs[a:b]) starts wherever the slice does -- off a 16-byte boundary three times out of four.  Such columns
-    used to fall to the direct kernels (2-8 global atomics per event); from a few hundred thousand events on they are copied to
-    aligned buffers and take the one-pass paths: same results as the aligned stream, the one-pass entry points called; small
-    slices and EVK_IMPL=direct keep the direct kernels; resident event sets built from slices are bucketed."""
+    used to fall to the direct kernels (2-8 global atomics per event); now the one-pass kernels read them where they lie
+    (EVK_COLUMNS_UNALIGNED: their 16-byte loads are dword-aligned loads) when the 12 bytes behind the last event belong to the
+    same storage, and aligned copies otherwise (from a few hundred thousand events on): same results as the aligned stream, the
+    one-pass entry points called; small slices without slack and EVK_IMPL=direct keep the direct kernels; resident event sets
+    built from slices are bucketed."""
     import numpy as np
     import torch
     import event_utils_amd as E
@@ -674,10 +676,12 @@ def test_device_slices_take_the_one_pass_paths():
         a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
         assert np.max(np.abs(a - ref)) <= tol * max(np.max(np.abs(ref)), 1e-30)
     try:
-        for off in (1, 2, 3):
-            sl = slice(off, n - 1)
+        for off, end in ((1, n - 7), (2, n - 3), (3, n), (1, n - 1)):
+            # (a slice that stops >= 3 events short of its parent's end is read where it lies, EVK_COLUMNS_UNALIGNED; one that
+            # reaches the end has no readable slack behind its last event and is copied)
+            sl = slice(off, end)
             cx, cy, ct, cp = (c[sl] for c in (xd, yd, td, pd))
-            assert cx.data_ptr() % 16 != 0
+            assert cx.data_ptr() % 16 != 0 and tiled.column_ok(ct) == (end <= n - 3)
             del calls[:]
             g = V.events_to_voxel_torch(cx.floor(), cy.floor(), ct, cp, B, sensor_size=(H, W))        # floor(): fresh, aligned
             g2 = V.events_to_voxel_torch(torch.floor(xd)[sl], torch.floor(yd)[sl], ct, cp, B, sensor_size=(H, W))
@@ -696,10 +700,21 @@ def test_device_slices_take_the_one_pass_paths():
             pos, neg = V.events_to_neg_pos_voxel_torch(torch.floor(xd)[sl], torch.floor(yd)[sl], ct, cp, B, sensor_size=(H, W))
             close((pos - neg).cpu().numpy(), R.events_to_voxel_torch(np.floor(x[sl]), np.floor(y[sl]), t[sl], np.where(p[sl] > 0, 1, -1).astype(np.float32),
                                                                         B, sensor_size=(H, W), accum="f64"))
-        # a small slice keeps the direct kernel (the copy would cost more than it saves), and so does EVK_IMPL=direct
+        # a small slice WITH slack is read in place too; without slack it keeps the direct kernel (the copy would cost more than
+        # it saves)
         del calls[:]
         V.events_to_voxel_torch(torch.floor(xd)[1:50_001], torch.floor(yd)[1:50_001], td[1:50_001], pd[1:50_001], B, sensor_size=(H, W))
+        assert "evk_voxel2_f32" in calls and "evk_voxel_from_events_f32" not in calls
+        del calls[:]
+        m = 50_000
+        sx, sy, st, sp = (c[:m + 1].clone()[1:] for c in (torch.floor(xd), torch.floor(yd), td, pd))     # ends with its storage
+        g = V.events_to_voxel_torch(sx, sy, st, sp, B, sensor_size=(H, W))
         assert "evk_voxel_from_events_f32" in calls and "evk_voxel2_f32" not in calls
+        close(g.cpu().numpy(), R.events_to_voxel_torch(np.floor(x[1:m + 1]), np.floor(y[1:m + 1]), t[1:m + 1], p[1:m + 1], B, sensor_size=(H, W), accum="f64"))
+        # the library refuses a misaligned column without the flag, as before
+        from event_utils_amd import _device as D
+        assert _lib.lib().evk_voxel2_f32(D.ptr(sx), D.ptr(sy), D.ptr(st), D.ptr(sp), m, H, W, 40, 15, 0.0, 1.0, B, 0, None, None, None, 0,
+                                         None, None, 0, None) == -3        # EVK_EALIGN (include/evk.h)
         # resident events built from slices: bucketed (the objective's fused path), same value as from the aligned copy
         ev_s = E.DeviceEvents.from_arrays(xd[1:], yd[1:], td[1:], pd[1:])
         ev_a = E.DeviceEvents.from_arrays(xd[1:].clone(), yd[1:].clone(), td[1:].clone(), pd[1:].clone())
