@@ -226,7 +226,9 @@ def _voxel_windows(xs, ys, ts, ps, B, bounds, sensor_size):
         oob = D.OobCounter(dev)
         for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
             cols = [c[a:b] for c in (xd, yd, td, pd)]
-            cols = [c if c.data_ptr() % 16 == 0 else c.clone() for c in cols]     # (a window may start at any event)
+            # (a window may start at any event: read where it lies, tiled.column_ok; the last window of a stream that ends with
+            # its storage has no readable slack behind it and is copied)
+            cols = [c if tiled.column_ok(c) else c.clone() for c in cols]
             out = torch.empty((B, H, W), dtype=torch.float32, device=dev)
             tiled.voxel_f32(*cols, None, None, B, H, W, out, oob, fresh=True)
             grids.append(out.to(device))
