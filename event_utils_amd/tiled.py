@@ -259,8 +259,8 @@ def realign(cols, impl, atomics_per_event):
     in place (column_ok), the call is small, or EVK_IMPL=direct; else aligned copies of the ones that cannot."""
     import torch
     live = [c for c in cols if c is not None]
-    if impl == "direct" or not live or live[0].shape[0] * atomics_per_event < REALIGN_ATOMICS:
-        return cols
+    if impl == "direct" or not live or (impl != "tiled" and live[0].shape[0] * atomics_per_event < REALIGN_ATOMICS):
+        return cols          # (EVK_IMPL=tiled asks for the one-pass path at any count)
     if not all(c.is_cuda and c.dim() == 1 for c in live) or all(column_ok(c) for c in live):
         return cols
     return tuple(c if (c is None or column_ok(c)) else c.clone(memory_format=torch.contiguous_format) for c in cols)
