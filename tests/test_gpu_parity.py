@@ -200,6 +200,15 @@ def test_f4_image_torch(E, golden, impl, monkeypatch):
         out = E.events_to_image_torch(xs, ys, ps, sensor_size=ss, **kw)
         assert out.dtype == torch.float32
         close(out.numpy(), g[key])
+    # interpolate_to_image (image.py:102-115) on the pixels, fractions and masked weights events_to_image_torch hands it upstream
+    # (image.py:79-86): the reference's own padded bilinear image, through either kernel family (round 6: the one-pass path too)
+    clipx, clipy = ss[1], ss[0]                                   # padded image (H+1, W+1): thresholds img_size - 1
+    mask = ((xs < clipx) & (ys < clipy)).float()
+    pxs, pys = xs.floor(), ys.floor()
+    dxs, dys = xs - pxs, ys - pys
+    img = torch.zeros(ss[0] + 1, ss[1] + 1)
+    E.interpolate_to_image((pxs * mask).long(), (pys * mask).long(), dxs, dys, ps * mask, img)
+    close(img.numpy(), g["bil_pad"])
     close(E.events_to_image(f64(g["xs"]), f64(g["ys"]), f64(g["ps"]), sensor_size=ss, interpolation='bilinear', padding=False), g["np_bil"])
     close(E.events_to_image(f64(g["xs"]), f64(g["ys"]), f64(g["ps"]), sensor_size=ss, interpolation='bilinear', padding=True), g["np_bil_pad"])
     with pytest.raises(IndexError):
