@@ -114,6 +114,10 @@ SIGNATURES = {
     "evk_image2_bilinear_f32": [P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, c_int64, P, P,
                                 c_uint32, P],
     "evk_image2_splat_indexed_f32": [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P, c_uint32, P],
+    "evk_image2_splat_drv_indexed_f32": [P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P, P, c_uint32,
+                                         P],
+    "evk_image2_drv_f64": [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_int, c_int, P, P, P, P, c_int64, P, P,
+                           c_uint32, P],
     "evk_timestamp_images2_f32": [P, P, P, P, c_int64, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_int, c_int,
                                   c_int, P, P, P, c_int64, P, P, c_uint32, P],
     "evk_comm_unique_id": [P],
@@ -146,6 +150,7 @@ _SPECIAL = {
     "evk_num_cu": ([], c_int),
     "evk_image2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
     "evk_timestamp_images2_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
+    "evk_image2_indexed_scratch_bytes": ([c_int, c_int64, c_int, c_int], c_int64),
     "evk_dense_rank_scratch_bytes": ([c_int64], c_int64),
     "evk_spectral_scratch_bytes": ([c_int, c_int], c_int64),
     "evk_minmax_scratch_bytes": ([], c_int64),

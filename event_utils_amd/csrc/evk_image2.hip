@@ -247,6 +247,130 @@ struct SrcIdxF32 {
     }
 };
 
+// ---- the derivative splats (V2_FMT_IMGD: the side run holds the event's index, the tile kernel fetches its weights) ----------
+// pxs, pys int64, dxs, dys float32; w1, w2 float32 (2, n): interpolate_to_derivative_img (image.py:117-136).  Keys as SrcIdxF32.
+struct SrcIdxDrvF32 {
+    static constexpr int G = 4, XYW = 24, TPW = 1;
+    const long long *px, *py;
+    const float *dx, *dy, *w1, *w2;
+    int64_t n;
+    float *dimg;
+    int h, wd;
+    template <bool NT = false>
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        SrcIdxF32{px, py, dx, dy, nullptr, nullptr, h, wd}.template load_xy<NT>(ev0, gl, r);
+    }
+    template <bool NT = false>
+    __device__ __forceinline__ void load_tp(int64_t, uint32_t, uint32_t *r) const { r[0] = 0u; }
+    __device__ __forceinline__ int key_rel(const uint32_t *r, int e, const TileGridG &g, float &xr, float &yr) const {
+        return SrcIdxF32{px, py, dx, dy, nullptr, nullptr, h, wd}.key_rel(r, e, g, xr, yr);
+    }
+    // the direct kernel's per-event code (evk_scatter.hip, k_splat_drv_indexed_f32, C = 2); false = IndexError
+    __device__ __forceinline__ bool rare_at(int64_t i) const {
+        long long x0 = px[i], x1 = x0 + 1, y0 = py[i], y1 = y0 + 1;
+        if (!(wrap_index(x0, wd) && wrap_index(x1, wd) && wrap_index(y0, h) && wrap_index(y1, h))) return false;
+        const float fx = dx[i], fy = dy[i], ax = 1.0f - fx, ay = 1.0f - fy;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float a = w1[(int64_t)c * n + i], b = w2[(int64_t)c * n + i];
+            float *d = dimg + (int64_t)c * h * wd;
+            atomic_add(d + y0 * wd + x0, a * (-ay) + b * (-ax));
+            atomic_add(d + y0 * wd + x1, a * ay + b * (-fx));
+            atomic_add(d + y1 * wd + x0, a * (-fy) + b * ax);
+            atomic_add(d + y1 * wd + x1, a * fy + b * fx);
+        }
+        return true;
+    }
+};
+// x, y, p float64, jx, jy float64 (2, n) or NULL: events_to_image_drv (image.py:162-217) -- coordinates and weights are cast to
+// float32 BEFORE floor (Q7); the clip mask multiplies indices AND weights (:203-206), so a masked event adds p * 0 at pixel (0, 0).
+struct SrcDrvF64 {
+    static constexpr int G = 4, XYW = 16, TPW = 1;
+    const double *x, *y, *p, *jx, *jy;
+    int64_t n;
+    float clipx, clipy;
+    float *img, *dimg;
+    int h, wd;
+    template <bool NT = false>
+    __device__ __forceinline__ void load_xy(int64_t ev0, uint32_t gl, uint32_t *r) const {
+        const float *fx = reinterpret_cast<const float *>(x + ev0), *fy = reinterpret_cast<const float *>(y + ev0);
+        const uint4 a0 = load_col16<NT>(fx, 0, 2 * gl), a1 = load_col16<NT>(fx, 0, 2 * gl + 1);
+        const uint4 b0 = load_col16<NT>(fy, 0, 2 * gl), b1 = load_col16<NT>(fy, 0, 2 * gl + 1);
+        r[0] = a0.x, r[1] = a0.y, r[2] = a0.z, r[3] = a0.w, r[4] = a1.x, r[5] = a1.y, r[6] = a1.z, r[7] = a1.w;
+        r[8] = b0.x, r[9] = b0.y, r[10] = b0.z, r[11] = b0.w, r[12] = b1.x, r[13] = b1.y, r[14] = b1.z, r[15] = b1.w;
+    }
+    template <bool NT = false>
+    __device__ __forceinline__ void load_tp(int64_t, uint32_t, uint32_t *r) const { r[0] = 0u; }
+    __device__ __forceinline__ int key_rel(const uint32_t *r, int e, const TileGridG &g, float &xr, float &yr) const {
+        const float xf = (float)__hiloint2double((int)r[2 * e + 1], (int)r[2 * e]);
+        const float yf = (float)__hiloint2double((int)r[8 + 2 * e + 1], (int)r[8 + 2 * e]);
+        const float fx = floorf(xf), fy = floorf(yf);
+        const bool ok = !(xf >= clipx) & !(yf >= clipy) & (fx >= 0.0f) & (fx <= (float)(g.dom_w - 2)) & (fy >= 0.0f) &
+                        (fy <= (float)(g.dom_h - 2));
+        const int px = ok ? (int)fx : 0, py = ok ? (int)fy : 0;
+        const int tx = tile_of(px, g.ix), ty = tile_of(py, g.iy);
+        xr = ok ? xf - (float)__mul24(tx, g.tw) : 0.0f;
+        yr = ok ? yf - (float)__mul24(ty, g.th) : 0.0f;
+        return ok ? __mul24(ty, g.tiles_x) + tx : -3;
+    }
+    // the direct kernel's per-event code (evk_scatter.hip, k_image_drv_f64); false = IndexError
+    __device__ __forceinline__ bool rare_at(int64_t i) const {
+        const float xf = (float)x[i], yf = (float)y[i], pf = (float)p[i];
+        const float mask = (!(xf >= clipx) && !(yf >= clipy)) ? 1.0f : 0.0f;
+        // a masked event adds p * 0 * (...) to the pixels (0..1, 0..1): nothing, unless a factor is not finite
+        if (mask == 0.0f && fabsf(pf) <= 3.0e38f && fabsf(xf) <= 3.0e38f && fabsf(yf) <= 3.0e38f &&
+            (!jx || (fabs(jx[i]) <= 3.0e38 && fabs(jx[n + i]) <= 3.0e38 && fabs(jy[i]) <= 3.0e38 && fabs(jy[n + i]) <= 3.0e38)))
+            return wd >= 2 && h >= 2;
+        const float fx = floorf(xf), fy = floorf(yf);
+        Splat s;
+        s.dx = xf - fx;
+        s.dy = yf - fy;
+        s.px = (long long)(fx * mask);
+        s.py = (long long)(fy * mask);
+        const float mp = pf * mask;
+        if (!splat_iwe(img, h, wd, s, mp)) return false;
+        if (jx) {
+            long long x0 = s.px, x1 = s.px + 1, y0 = s.py, y1 = s.py + 1;
+            wrap_index(x0, wd), wrap_index(x1, wd), wrap_index(y0, h), wrap_index(y1, h);
+            const float ax = 1.0f - s.dx, ay = 1.0f - s.dy;
+            const float w1[2] = {(float)jx[i] * mp, (float)jx[n + i] * mp};
+            const float w2[2] = {(float)jy[i] * mp, (float)jy[n + i] * mp};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float *d = dimg + (int64_t)c * h * wd;
+                atomic_add(d + y0 * wd + x0, w1[c] * (-ay) + w2[c] * (-ax));
+                atomic_add(d + y0 * wd + x1, w1[c] * ay + w2[c] * (-s.dx));
+                atomic_add(d + y1 * wd + x0, w1[c] * (-s.dy) + w2[c] * ax);
+                atomic_add(d + y1 * wd + x1, w1[c] * s.dy + w2[c] * s.dx);
+            }
+        }
+        return true;
+    }
+};
+// the weights of an event by its index: mp (the image's weight), a = w1[0..1], b = w2[0..1]
+struct WgtIdxDrvF32 {
+    static constexpr bool IWE = false;
+    const float *w1, *w2;
+    int64_t n;
+    __device__ __forceinline__ void get(uint32_t i, bool grad, float &mp, float (&a)[2], float (&b)[2]) const {
+        mp = 0.0f;
+        a[0] = w1[i], a[1] = w1[n + i], b[0] = w2[i], b[1] = w2[n + i];
+    }
+};
+struct WgtDrvF64 {
+    static constexpr bool IWE = true;
+    const double *p, *jx, *jy;
+    int64_t n;
+    __device__ __forceinline__ void get(uint32_t i, bool grad, float &mp, float (&a)[2], float (&b)[2]) const {
+        mp = (float)p[i];
+        a[0] = a[1] = b[0] = b[1] = 0.0f;
+        if (grad) {
+            a[0] = (float)jx[i] * mp, a[1] = (float)jx[n + i] * mp;
+            b[0] = (float)jy[i] * mp, b[1] = (float)jy[n + i] * mp;
+        }
+    }
+};
+
 #ifndef IMG_WG
 #define IMG_WG 512    // threads of a tile workgroup (768 and up: the chunk lists no longer fit the 64 KB of static LDS)
 #endif
@@ -733,6 +857,105 @@ __global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__
     });
 }
 
+// ---- derivative splats: the image of warped events and / or its two derivative planes (round 6) ------------------------------
+// Per record the event's weights come from the caller's columns by the index the side run holds (dependent loads: the record's
+// four or five weights do not fit a sub-chunk's LDS); float64 LDS atomics; the products and sums of every corner in float32
+// exactly as the direct kernels write them (image.py:111-114, 131-135).
+template <int WG, typename WF>
+__global__ void __launch_bounds__(WG) k_image_tiles_drv(const uint2 *__restrict__ rec, const uint32_t *__restrict__ side,
+                                                        const uint32_t *__restrict__ table, uint32_t *__restrict__ index,
+                                                        TileGridG g, Part2 q, int flags, const WF wf, int grad,
+                                                        float *__restrict__ img, float *__restrict__ dimg, float *__restrict__ staging) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char drv_smem[];
+    acc_t *const win = reinterpret_cast<acc_t *>(drv_smem);   // [planes][wcells]: (image |) derivative 0 | derivative 1
+    __shared__ uint2 cseg[WG / 64][IMG_CAP + 1];
+    const int ntiles = g.tiles_x * g.tiles_y;
+    ImgItem it;
+    if (!img_item(index, ntiles, q, flags, it)) return;
+    constexpr int P0 = WF::IWE ? 1 : 0;
+    const int planes = P0 + (grad ? 2 : 0);
+    const int tw = g.tw, th = g.th;
+    const int ww = tw + 1, wh = th + 1, wpitch = ww | 1, wcells = wpitch * wh;
+    for (int i = threadIdx.x; i < planes * wcells; i += WG) win[i] = 0.0;
+    auto one = [&](uint32_t xb, uint32_t yb, uint32_t idx) {
+        const float xr = __uint_as_float(xb), yr = __uint_as_float(yb);
+        const float fx = floorf(xr), fy = floorf(yr);
+        const float dx = xr - fx, dy = yr - fy;
+        const float ax = 1.0f - dx, ay = 1.0f - dy;
+        const int c0 = __mul24((int)fy, wpitch) + (int)fx;
+        float mp, a[2], b[2];
+        wf.get(idx, grad != 0, mp, a, b);
+        if constexpr (WF::IWE) {
+            const float wa = mp * ax, wd = mp * dx;
+            lds_add(win + c0, wa * ay), lds_add(win + c0 + 1, wd * ay), lds_add(win + c0 + wpitch, wa * dy),
+                lds_add(win + c0 + wpitch + 1, wd * dy);
+        }
+        if (grad) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc_t *const d = win + __mul24(P0 + c, wcells) + c0;
+                lds_add(d, a[c] * (-ay) + b[c] * (-ax)), lds_add(d + 1, a[c] * ay + b[c] * (-dx)),
+                    lds_add(d + wpitch, a[c] * (-dy) + b[c] * ax), lds_add(d + wpitch + 1, a[c] * dy + b[c] * dx);
+            }
+        }
+    };
+    img_records<WG, IMG_U, RecB>(
+        table, q, it, cseg,
+        [&](uint32_t pos) -> RecB {
+            RecB v;
+            v.r = load_u4(rec + pos);
+            v.w = load_u2(side + pos);
+            return v;
+        },
+        [&](const RecB &v, uint32_t pos, uint32_t end) {
+            one(v.r.x, v.r.y, v.w.x);
+            if (pos + 1 < end) one(v.r.z, v.r.w, v.w.y);
+        });
+    __syncthreads();
+    const int tx0 = (it.tile % g.tiles_x) * tw, ty0 = (it.tile / g.tiles_x) * th;
+    const int dcells = ww * wh;
+    const uint32_t mw = magic_div((uint32_t)ww);
+    const int64_t plane = (int64_t)g.dom_h * g.dom_w;
+    auto lds_cell = [&](int pl, int c) -> float {
+        const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww;
+        return (float)win[pl * wcells + row * wpitch + col];
+    };
+    auto flush = [&](auto value_of) {
+        for (int i = threadIdx.x; i < planes * dcells; i += WG) {
+            const int pl = i / dcells, c = i - pl * dcells;
+            const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww;
+            const int X = tx0 + col, Y = ty0 + row;
+            if (X < g.dom_w && Y < g.dom_h) {
+                float *o = ((WF::IWE && pl == 0) ? img : dimg + (pl - P0) * plane) + (int64_t)Y * g.dom_w + X;
+                const float v = value_of(pl, c);
+                if (row == 0 || row == th || col == 0 || col == tw) {
+                    if (v != 0.0f || v != v) atomic_add(o, v);
+                } else {
+                    *o += v;
+                }
+            }
+        }
+    };
+    if (it.nparts == 1) {
+        flush(lds_cell);
+        return;
+    }
+    const int64_t stride = v2_staging_stride(3 * dcells);
+    float *mine = staging + (int64_t)it.item * stride;
+    for (int i = threadIdx.x; i < planes * dcells; i += WG) {
+        const int pl = i / dcells;
+        __hip_atomic_store(mine + i, lds_cell(pl, i - pl * dcells), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!img_last_part(index, ntiles, it)) return;
+    const float *parts = staging + (int64_t)it.first_item * stride;
+    flush([&](int pl, int c) {
+        float sum = 0.0f;
+        for (uint32_t pp = 0; pp < it.nparts; ++pp)
+            sum += __hip_atomic_load(parts + (int64_t)pp * stride + pl * dcells + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return sum;
+    });
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 // One geometry for the images: 1024 threads x 8 events, sub-chunks of 8 K events (68 KB of LDS with 4-byte records,
 // 100 KB with the 12 bytes of the bilinear format).
@@ -748,10 +971,11 @@ struct ImgCall {
     Part2 q;
     V2Layout L;
     int ntiles;
+    bool small;   // 8 K-event sub-chunks (1024 x 8)
 };
 #define IMG_TS_PLANES 6   // staging of a cut tile's piece, in tw x th floats x 2: four (tw + 1) x (th + 1) float windows fit
 static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile_h, int flags, const void *out, uint32_t *index,
-                     void *scratch, int64_t scratch_bytes, uint32_t *host_report, int planes = 2) {
+                     void *scratch, int64_t scratch_bytes, uint32_t *host_report, int planes = 2, bool small_only = false) {
     const int known = EVK_VOXEL_OVERWRITE | EVK_VOXEL2_PARTITION_ONLY | EVK_VOXEL2_TILES_ONLY | EVK_VOXEL2_NO_XCD_ORDER |
                       EVK_IMAGE2_NO_FIXED;
     if (make_grid_g(ic.g, h, wd, tile_w, tile_h) != EVK_OK || !out || !index || !scratch || n <= 0 ||
@@ -762,7 +986,9 @@ static int img_setup(ImgCall &ic, int64_t n, int h, int wd, int tile_w, int tile
     if (ic.ntiles > evk_voxel2_max_tiles() || !evk_voxel2_num_tiles(h, wd, tile_w, tile_h) ||
         (tile_w + 2) * (tile_h + 1) > IMG_WIN_MAX)
         return EVK_EINVAL;
-    const bool small = img_small(ic.ntiles);
+    // (small_only: the column sources that load 24 words per four events -- int64 pixels -- spill in the 12-event geometry)
+    const bool small = small_only || img_small(ic.ntiles);
+    ic.small = small;
     ic.L = v2_layout(ic.ntiles, n, planes, tile_w, tile_h, small);   // (2 planes of tw x th floats hold a (tw + 1) x (th + 1) window)
     if (scratch_bytes < ic.L.total) return EVK_ESCRATCH;
     if (!aligned16(scratch)) return EVK_EALIGN;
@@ -774,12 +1000,16 @@ template <int FMT, typename C>
 static void img_partition(const C &c, int64_t n, const ImgCall &ic, uint32_t *index, void *scratch, uint32_t *oob,
                           uint32_t *host_report, uint32_t seq, hipStream_t s, int t_from_events = 0) {
     char *sb = (char *)scratch;
-    if (img_small(ic.ntiles))
+    if constexpr (FMT == V2_FMT_IMGX || FMT == V2_FMT_IMGD) {   // (small_only callers: no 12-event instantiation of these)
         launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, t_from_events, sb + ic.L.rec, sb + ic.L.pw,
                                   (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
-    else
+    } else if (ic.small) {
+        launch_part<1024, 8, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, t_from_events, sb + ic.L.rec, sb + ic.L.pw,
+                                  (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
+    } else {
         launch_part<1024, 12, FMT>(c, n, ic.g, ic.ntiles, ic.q, 0.0f, 0.0f, 0.0f, t_from_events, sb + ic.L.rec, sb + ic.L.pw,
                                    (uint32_t *)(sb + ic.L.bases), (uint32_t *)(sb + ic.L.table), index, oob, host_report, seq, s);
+    }
 }
 
 }  // namespace evk
@@ -854,6 +1084,13 @@ extern "C" int evk_image2_bilinear_f32(const float *x, const float *y, const flo
     return launch_status();
 }
 
+/* scratch of evk_image2_splat_indexed_f32, evk_image2_splat_drv_indexed_f32 and evk_image2_drv_f64 (8 K-event sub-chunks whatever
+ * the tile count) */
+extern "C" int64_t evk_image2_indexed_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h) {
+    if (ntiles <= 0 || n < 0 || tile_w <= 0 || tile_h <= 0) return 0;
+    return v2_layout(ntiles, n, IMG_TS_PLANES, tile_w, tile_h, true).total;
+}
+
 extern "C" int64_t evk_timestamp_images2_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h) {
     if (ntiles <= 0 || n < 0 || tile_w <= 0 || tile_h <= 0) return 0;
     return v2_layout(ntiles, n, IMG_TS_PLANES, tile_w, tile_h, img_small(ntiles)).total;
@@ -907,7 +1144,7 @@ extern "C" int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py
     flags &= ~EVK_COLUMNS_UNALIGNED;
     if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;
     ImgCall ic;
-    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report);
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, img, index, scratch, scratch_bytes, host_report, IMG_TS_PLANES, true);
     if (rc != EVK_OK) return rc;
     if (h < 2 || wd < 2) return EVK_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -920,4 +1157,63 @@ extern "C" int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py
             (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
             ic.q, flags, img, (float *)(sb + ic.L.staging));
     return launch_status();
+}
+
+template <typename C, typename WF>
+static int drv_call(const C &c, const WF &wf, int grad, int64_t n, int h, int wd, int tile_w, int tile_h, int flags, float *img,
+                    float *dimg, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                    uint32_t seq, void *stream) {
+    if (flags & EVK_VOXEL_OVERWRITE) return EVK_EINVAL;   // (the windows are ADDED to the images)
+    ImgCall ic;
+    const int rc = img_setup(ic, n, h, wd, tile_w, tile_h, flags, WF::IWE ? img : dimg, index, scratch, scratch_bytes, host_report,
+                             IMG_TS_PLANES, true);
+    if (rc != EVK_OK) return rc;
+    if (h < 2 || wd < 2) return EVK_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    if (!(flags & EVK_VOXEL2_TILES_ONLY)) img_partition<V2_FMT_IMGD>(c, n, ic, index, scratch, oob, host_report, seq, s);
+    if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
+        const int wcells = ((tile_w + 1) | 1) * (tile_h + 1);
+        const size_t lds = (size_t)((WF::IWE ? 1 : 0) + (grad ? 2 : 0)) * wcells * sizeof(acc_t);
+        static std::once_flag once[64];   // per device and instantiation
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 63], [] {
+            (void)hipFuncSetAttribute((const void *)k_image_tiles_drv<IMG_WG, WF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      3 * IMG_WIN_MAX * (int)sizeof(acc_t));
+        });
+        k_image_tiles_drv<IMG_WG, WF><<<v2_max_items(n, ic.ntiles), IMG_WG, lds, s>>>(
+            (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
+            ic.q, flags, wf, grad, img, dimg, (float *)(sb + ic.L.staging));
+    }
+    return launch_status();
+}
+
+/* interpolate_to_derivative_img (image.py:117-136), two channels, on the one-pass design: evk_splat_drv_indexed_f32's arguments
+ * (C = 2) and semantics, the rest as evk_image2_splat_indexed_f32; scratch: evk_timestamp_images2_scratch_bytes */
+extern "C" int evk_image2_splat_drv_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy,
+                                                const float *w1, const float *w2, int64_t n, int h, int wd, int tile_w, int tile_h,
+                                                int flags, float *d_img, uint32_t *index, void *scratch, int64_t scratch_bytes,
+                                                uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream) {
+    if (n > 0 && (!px || !py || !dx || !dy || !w1 || !w2)) return EVK_EINVAL;
+    if (n > (int64_t)4000000000LL || !d_img) return EVK_EINVAL;
+    if (!(column_ok(px, flags, 8) && column_ok(py, flags, 8) && column_ok(dx, flags) && column_ok(dy, flags))) return EVK_EALIGN;
+    flags &= ~EVK_COLUMNS_UNALIGNED;
+    const SrcIdxDrvF32 c{(const long long *)px, (const long long *)py, dx, dy, w1, w2, n, d_img, h, wd};
+    return drv_call(c, WgtIdxDrvF32{w1, w2, n}, 1, n, h, wd, tile_w, tile_h, flags, nullptr, d_img, index, scratch, scratch_bytes, oob,
+                    host_report, seq, stream);
+}
+
+/* events_to_image_drv (image.py:162-217) on the one-pass design: evk_image_drv_f64's arguments and semantics (jx, jy NULL: the
+ * image alone), the rest as evk_image2_bilinear_f32; columns 16-byte aligned; scratch: evk_timestamp_images2_scratch_bytes */
+extern "C" int evk_image2_drv_f64(const double *x, const double *y, const double *p, const double *jx, const double *jy, int64_t n,
+                                  int h, int wd, float clipx, float clipy, int tile_w, int tile_h, int flags, float *img,
+                                  float *d_img, uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob,
+                                  uint32_t *host_report, uint32_t seq, void *stream) {
+    if (n > 0 && (!x || !y || !p)) return EVK_EINVAL;
+    if ((jx == nullptr) != (jy == nullptr) || (jx && !d_img) || !img || n > (int64_t)4000000000LL) return EVK_EINVAL;
+    if (!(aligned16(x) && aligned16(y))) return EVK_EALIGN;
+    const SrcDrvF64 c{x, y, p, jx, jy, n, clipx, clipy, img, d_img, h, wd};
+    return drv_call(c, WgtDrvF64{p, jx, jy, n}, jx ? 1 : 0, n, h, wd, tile_w, tile_h, flags, img, d_img, index, scratch,
+                    scratch_bytes, oob, host_report, seq, stream);
 }

@@ -179,6 +179,11 @@ struct Part2 {
 //   and side run; the only difference is the rare path -- an event the record cannot carry (its pixel + fraction is not a
 //   float32 value, or a pixel that wraps / raises) is re-read by its INDEX in the stream (the column source's rare_at()).
 #define V2_FMT_IMGX 14
+// REC = V2_FMT_IMGD (round 6: the derivative splats -- interpolate_to_derivative_img, image.py:117-136, and events_to_image_drv,
+//   image.py:162-217): the bilinear record {x - tile x0, y - tile y0}, and as side run the event's INDEX in the stream: the tile
+//   kernel fetches the event's weights (four or five values: more than a sub-chunk's LDS could stage) from the caller's columns by
+//   that index.  Rare events are re-read by their index (rare_at), as IMGX's.  n < 2^32.
+#define V2_FMT_IMGD 15
 // REC = V2_FMT_VOX8W: the 8-byte voxel records, with the EXACT polarities of a sub-chunk staged in LDS (4 more bytes per
 // event) and written as a second dense run when one of them is wide -- instead of a scattered 4-byte store per wide
 // polarity (arbitrary float32 weights: partition 78 -> ~50 us at 10 M events).  The geometry with 8 K-event sub-chunks
@@ -188,7 +193,7 @@ struct Part2 {
 #define V2_DELTA_LIMIT (1u << 20)
 #define V2_CODE_SHIFT 10
 // bytes of LDS per event of the sorted buffer
-__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : ((rec == V2_FMT_VOX8W || rec == V2_FMT_IMGT || rec == V2_FMT_IMGX) ? 12 : rec); }
+__host__ __device__ constexpr int v2_fmt_lds_bytes(int rec) { return rec == V2_FMT_IMGN ? 8 : ((rec == V2_FMT_VOX8W || rec == V2_FMT_IMGT || rec == V2_FMT_IMGX || rec == V2_FMT_IMGD) ? 12 : rec); }
 // LIVE (round 5; evk_voxel_live.hip): the runs are consumed WHILE the partition is still sorting, by a second kernel on a
 // second stream (k_voxel_live: two tiles per workgroup, one workgroup per CU beside this kernel's).  What that needs here:
 // the table row of a sub-chunk leaves with its run, as write-through 16-byte stores out of an LDS copy (plain 4-byte stores
@@ -206,9 +211,9 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                                                             uint32_t seq, uint32_t *live_progress = nullptr,
                                                             uint32_t live_epoch = 0) {
     static_assert(!LIVE || (REC == 8 && V2_STORE_SC1), "the live consumer reads 8-byte records written through");
-    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX || REC == V2_FMT_VOX8W, "record format");
+    static_assert(REC == 8 || REC == 4 || REC == V2_FMT_IMGN || REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX || REC == V2_FMT_IMGD || REC == V2_FMT_VOX8W, "record format");
     constexpr bool R8 = REC == 8 || REC == V2_FMT_VOX8W;      // 8-byte voxel records
-    constexpr bool IMGBT = REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX;   // bilinear formats: {x, y} relative to the tile + a side run
+    constexpr bool IMGBT = REC == V2_FMT_IMGB || REC == V2_FMT_IMGT || REC == V2_FMT_IMGX || REC == V2_FMT_IMGD;   // bilinear formats: {x, y} relative to the tile + a side run
     constexpr bool STAGE_W = REC == V2_FMT_VOX8W || REC == V2_FMT_IMGN || IMGBT;   // exact weights staged in LDS, dense side run on demand
     constexpr bool VOX = R8 || REC == 4;                      // voxel formats: a time column, t_norm in the record
     constexpr int LB = v2_fmt_lds_bytes(REC);
@@ -600,6 +605,24 @@ __global__ void __launch_bounds__(THREADS, 4) k_part_sorted(const C c, int64_t n
                         else
                             dropped += c.rare(xr[s2], yr[s2], __uint_as_float(c.w_bits(tpr + C::TPW * (s2 / G), s2 % G))) ? 0u : 1u;
                     }
+            }
+            rare = 0;
+        } else if constexpr (REC == V2_FMT_IMGD) {
+            bool any_d = false;
+#pragma unroll
+            for (int s2 = 0; s2 < EPT; ++s2) {
+                if (kl[s2] != 0xFFFFFFFFu) {
+                    const uint32_t pos = slot_of(s2);
+                    sorted[pos] = make_uint2(__float_as_uint(xr[s2]), __float_as_uint(yr[s2]));
+                    sortedp[pos] = (uint32_t)(row_base(sc, s2 / G) + (int64_t)G * tl_ + (s2 % G));   // the event's index in the stream
+                    any_d = true;
+                }
+            }
+            if (any_d) tmp[65] = 1u;   // the side run of this sub-chunk is always written
+            if (__any(rare != 0u)) {
+#pragma unroll
+                for (int s2 = 0; s2 < EPT; ++s2)
+                    if (rare >> s2 & 1u) dropped += c.rare_at(row_base(sc, s2 / G) + (int64_t)G * tl_ + (s2 % G)) ? 0u : 1u;
             }
             rare = 0;
         } else if constexpr (REC == V2_FMT_IMGT) {

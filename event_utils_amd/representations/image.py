@@ -176,9 +176,20 @@ def interpolate_to_derivative_img(pxs, pys, dxs, dys, d_img, w1, w2):
     oob = D.OobCounter(dev)
     a = [D.to_device(pxs, torch.int64), D.to_device(pys, torch.int64), D.to_device(dxs, torch.float32),
          D.to_device(dys, torch.float32), D.to_device(w1, torch.float32), D.to_device(w2, torch.float32)]
-    _lib.call("evk_splat_drv_indexed_f32", D.ptr(a[0]), D.ptr(a[1]), D.ptr(a[2]), D.ptr(a[3]), D.ptr(a[4]), D.ptr(a[5]),
-              work.shape[0],
-              pxs.shape[0], work.shape[1], work.shape[2], D.ptr(work), oob.ptr, D.stream())
+    n = pxs.shape[0]
+    from .. import tiled
+    impl = tiled.default_impl()
+    # (round 6) two channels, float32 image: the one-pass partition + LDS windows, the tile kernel fetching every event's four
+    # weights by its index; events whose pixel + fraction is not a float32 coordinate take the direct kernel's code there
+    fast = False
+    if (work.dtype == torch.float32 and work.dim() == 3 and work.shape[0] == 2 and impl in ("tiled", "auto")
+            and 0 < n <= 4_000_000_000 and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_SPLAT_DRV)
+            and all(c.dim() == 1 and c.shape[0] == n for c in a[:4]) and all(tuple(c.shape) == (2, n) and c.is_contiguous() for c in a[4:])):
+        a[:4] = tiled.realign(tuple(a[:4]), impl, 8)
+        fast = all(tiled.column_ok(c) for c in a[:4]) and tiled.splat_drv_indexed2(*a, n, work.shape[1], work.shape[2], work, oob)
+    if not fast:
+        _lib.call("evk_splat_drv_indexed_f32", D.ptr(a[0]), D.ptr(a[1]), D.ptr(a[2]), D.ptr(a[3]), D.ptr(a[4]), D.ptr(a[5]),
+                  work.shape[0], n, work.shape[1], work.shape[2], D.ptr(work), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (tuple(d_img.shape),))
     if work is not d_img:
         d_img.copy_(work)
@@ -197,8 +208,17 @@ def _events_to_image_drv_device(xn, yn, pn, jacobian_xn, jacobian_yn, sensor_siz
     jy = D.to_device(jacobian_yn, torch.float64) if compute_gradient else None
     oob = D.OobCounter(dev)
     xd, yd, pd = D.to_device(xn, torch.float64), D.to_device(yn, torch.float64), D.to_device(pn, torch.float64)
-    _lib.call("evk_image_drv_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), D.ptr(jx), D.ptr(jy), n, img_size[0], img_size[1], clipx, clipy,
-              D.ptr(img), D.ptr(d_img), oob.ptr, D.stream())
+    from .. import tiled
+    impl = tiled.default_impl()
+    # (round 6) the one-pass partition + LDS windows (the image and its two derivative planes), the tile kernel fetching p and
+    # the Jacobians by the event's index; masked / wrapping / out-of-range events take the direct kernel's code there
+    fast = (impl in ("tiled", "auto") and 0 < n <= 4_000_000_000 and (impl == "tiled" or n >= tiled.TILED_MIN_EVENTS_SPLAT_DRV)
+            and all(c.dim() == 1 and c.shape[0] == n and c.is_contiguous() and c.data_ptr() % 16 == 0 for c in (xd, yd, pd))
+            and (jx is None or all(tuple(c.shape) == (2, n) and c.is_contiguous() for c in (jx, jy)))
+            and tiled.image_drv2(xd, yd, pd, jx, jy, n, img_size[0], img_size[1], clipx, clipy, img, d_img, oob))
+    if not fast:
+        _lib.call("evk_image_drv_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), D.ptr(jx), D.ptr(jy), n, img_size[0], img_size[1], clipx,
+                  clipy, D.ptr(img), D.ptr(d_img), oob.ptr, D.stream())
     oob.raise_if_set(IndexError, "index out of range for image of size %s" % (img_size,))
     return img, d_img
 

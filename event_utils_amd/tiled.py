@@ -493,6 +493,9 @@ TILED_MIN_EVENTS_TIMESTAMP = 1
 # interpolate_to_image on caller-computed pixels / fractions (round 6): four global atomics per event at ~21 G/s against the two
 # launches' ~18 us; the call synchronises either way (it raises before it returns)
 TILED_MIN_EVENTS_SPLAT_INDEXED = 100_000
+# the derivative splats (interpolate_to_derivative_img: 8 atomics per event; events_to_image_drv: 4 or 12): the one-pass tile kernel
+# fetches every event's weights by index (dependent loads), so its crossover lies higher than the plain splat's
+TILED_MIN_EVENTS_SPLAT_DRV = 100_000
 
 
 def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stage=0):
@@ -538,36 +541,71 @@ def image2(kind, xd, yd, wd_, n, H, W, clipx, clipy, out, oob, fresh=False, stag
     return True
 
 
-def splat_indexed2(pxs, pys, dxs, dys, ws, n, H, W, img, oob, stage=0):
-    """evk_image2_splat_indexed_f32: interpolate_to_image (image.py:102-115) of caller-computed pixels / fractions ADDED to `img`
-    (H, W) on the one-pass path.  Returns False when it has no tiling for this image (the caller then uses the direct kernel)."""
+def _indexed_env(dev, n, H, W, cols, oob, stage):
+    """Tiling, index, scratch, flags and report slot shared by the one-pass calls on indexed / float64 columns, or None."""
     L = _lib.lib()
     shape = voxel2_shape(H, W, 1)
     if shape is None or H < 2 or W < 2:
-        return False
+        return None
     tw, th = shape
     if (tw + 2) * (th + 1) > 2048:
-        return False
-    dev = img.device
+        return None
     ntiles = L.evk_voxel2_num_tiles(H, W, tw, th)
-    key = ("image2", ntiles, n, tw, th)
+    key = ("indexed2", ntiles, n, tw, th)
     sizes = _staging_bytes.get(key)
     if sizes is None:
-        sizes = (int(L.evk_voxel2_index_len(ntiles, n)), int(L.evk_image2_scratch_bytes(ntiles, n, tw, th)))
+        sizes = (int(L.evk_voxel2_index_len(ntiles, n)), int(L.evk_image2_indexed_scratch_bytes(ntiles, n, tw, th)))
         if sizes[0] <= 0:
-            return False
+            return None
         _staging_bytes[key] = sizes
     index = _zbuf("image2_index", sizes[0], dev)
     scratch = _buf("voxel2_scratch", sizes[1], dev)
-    flags = stage | unaligned_flag((pxs, pys, dxs, dys, ws))
+    flags = stage | unaligned_flag(cols)
     if not FORCE["image_fixed"]:
         flags |= _lib.EVK_IMAGE2_NO_FIXED
     if not FORCE["xcd_order"]:
         flags |= 64
     report, seq = oob.report_args() if (oob is not None and not (stage & _lib.EVK_VOXEL2_TILES_ONLY)) else (None, 0)
+    return tw, th, flags, index, scratch, report, seq
+
+
+def splat_indexed2(pxs, pys, dxs, dys, ws, n, H, W, img, oob, stage=0):
+    """evk_image2_splat_indexed_f32: interpolate_to_image (image.py:102-115) of caller-computed pixels / fractions ADDED to `img`
+    (H, W) on the one-pass path.  Returns False when it has no tiling for this image (the caller then uses the direct kernel)."""
+    env = _indexed_env(img.device, n, H, W, (pxs, pys, dxs, dys, ws), oob, stage)
+    if env is None:
+        return False
+    tw, th, flags, index, scratch, report, seq = env
     _rezero_on_failure(index, lambda: _lib.call(
         "evk_image2_splat_indexed_f32", D.ptr(pxs), D.ptr(pys), D.ptr(dxs), D.ptr(dys), D.ptr(ws), n, H, W, tw, th, flags, D.ptr(img),
         D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None, report, seq, D.stream()))
+    return True
+
+
+def splat_drv_indexed2(pxs, pys, dxs, dys, w1, w2, n, H, W, d_img, oob, stage=0):
+    """evk_image2_splat_drv_indexed_f32: interpolate_to_derivative_img (image.py:117-136; two channels) ADDED to `d_img` (2, H, W).
+    w1, w2: contiguous (2, n) float32.  Returns False when the one-pass path has no tiling for this image."""
+    env = _indexed_env(d_img.device, n, H, W, (pxs, pys, dxs, dys), oob, stage)
+    if env is None:
+        return False
+    tw, th, flags, index, scratch, report, seq = env
+    _rezero_on_failure(index, lambda: _lib.call(
+        "evk_image2_splat_drv_indexed_f32", D.ptr(pxs), D.ptr(pys), D.ptr(dxs), D.ptr(dys), D.ptr(w1), D.ptr(w2), n, H, W, tw, th,
+        flags, D.ptr(d_img), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None, report, seq,
+        D.stream()))
+    return True
+
+
+def image_drv2(xd, yd, pd, jx, jy, n, H, W, clipx, clipy, img, d_img, oob, stage=0):
+    """evk_image2_drv_f64: events_to_image_drv (image.py:162-217) on float64 device columns, image (and, with jx / jy (2, n), its
+    two derivative planes) ADDED to img / d_img.  Returns False when the one-pass path has no tiling for this image."""
+    env = _indexed_env(img.device, n, H, W, (), oob, stage)
+    if env is None:
+        return False
+    tw, th, flags, index, scratch, report, seq = env
+    _rezero_on_failure(index, lambda: _lib.call(
+        "evk_image2_drv_f64", D.ptr(xd), D.ptr(yd), D.ptr(pd), D.ptr(jx), D.ptr(jy), n, H, W, clipx, clipy, tw, th, flags, D.ptr(img),
+        D.ptr(d_img), D.ptr(index), D.ptr(scratch), scratch.numel(), oob.ptr if oob is not None else None, report, seq, D.stream()))
     return True
 
 

@@ -456,6 +456,22 @@ int evk_image2_bilinear_f32(const float *x, const float *y, const float *w, int6
 int evk_image2_splat_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy, const float *w, int64_t n,
                                  int h, int wd, int tile_w, int tile_h, int flags, float *img, uint32_t *index, void *scratch,
                                  int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq, void *stream);
+/* The derivative splats on the same design (round 6): evk_splat_drv_indexed_f32 (interpolate_to_derivative_img, image.py:117-136;
+ * two channels) and evk_image_drv_f64 (events_to_image_drv, image.py:162-217).  An event's record carries its coordinates
+ * relative to the tile and its INDEX in the stream; the tile kernel fetches the event's four or five weights from the caller's
+ * columns by that index (they do not fit the partition's LDS) and accumulates the image and / or its two derivative planes in LDS
+ * windows.  Arguments and *oob as the direct entry points', the rest as evk_image2_bilinear_f32 (always add; n < 2^32);
+ * evk_image2_drv_f64: x, y 16-byte aligned, jx == jy == NULL for the image alone.  `scratch` of these two and of
+ * evk_image2_splat_indexed_f32: evk_image2_indexed_scratch_bytes (8 K-event sub-chunks whatever the tile count). */
+int64_t evk_image2_indexed_scratch_bytes(int ntiles, int64_t n, int tile_w, int tile_h);
+int evk_image2_splat_drv_indexed_f32(const int64_t *px, const int64_t *py, const float *dx, const float *dy, const float *w1,
+                                     const float *w2, int64_t n, int h, int wd, int tile_w, int tile_h, int flags, float *d_img,
+                                     uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report,
+                                     uint32_t seq, void *stream);
+int evk_image2_drv_f64(const double *x, const double *y, const double *p, const double *jx, const double *jy, int64_t n, int h,
+                       int wd, float clipx, float clipy, int tile_w, int tile_h, int flags, float *img, float *d_img,
+                       uint32_t *index, void *scratch, int64_t scratch_bytes, uint32_t *oob, uint32_t *host_report, uint32_t seq,
+                       void *stream);
 /* evk_timestamp_images_f32 (above; events_to_timestamp_image[_torch], image.py:219-353: eight global atomics per event) on
  * the same design (round 6): one partition -- 16 B/event read, a 12-byte record {x, y relative to the tile; the event's
  * class in their sign bits; its normalised time stamp} moved once -- and a tile kernel with four LDS windows per tile
