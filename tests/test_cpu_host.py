@@ -494,3 +494,28 @@ def test_bench_extras_guard_prints_the_line_it_has_and_leaves():
     assert line["value"] == 1.5 and line["extras_timed_out"]["leg"] == "breakdown"
     r = subprocess.run([sys.executable, "-c", code, "20", "0.1"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "finished", (r.stdout, r.stderr)
+
+
+def test_image_kernels_compile_without_register_spills(tmp_path):
+    """The same for evk_image2.hip: every k_part_sorted instantiation of the event-image / timestamp / indexed / derivative column
+    sources and their tile kernels.  (The sources that load 24 words per four events -- int64 pixels -- have no 12-event
+    instantiation: it spilled 60-81 registers.)"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.isfile(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    from event_utils_amd.csrc import build as B
+    src = os.path.join(B.HERE, "evk_image2.hip")
+    subprocess.run([hipcc] + list(B.CFLAGS) + ["-c", src, "-o", str(tmp_path / "i2.o"), "-save-temps=obj"], check=True, cwd=B.HERE,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert asm, os.listdir(tmp_path)
+    text = open(tmp_path / asm[0]).read()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    seen = {n: (int(v), int(sp)) for n, v, sp in kernels if "k_part_sorted" in n or "k_image_tiles" in n}
+    assert len(seen) >= 17, sorted(seen)
+    assert not {n: vs for n, vs in seen.items() if vs[1]}
+    assert all(v <= 128 for v, _ in seen.values())
+    assert not any(("SrcIdx" in n or "SrcDrv" in n) and "ELi12E" in n for n in seen)
