@@ -385,7 +385,7 @@ int evk_voxel_tiled_f32(const float *records, uint32_t *bucket_index, int64_t n,
  * is being captured into a graph) run as without it.  evk_voxel2_f32 only. */
 #define EVK_VOXEL2_LIVE 16384
 /* EVK_COLUMNS_UNALIGNED (round 6; evk_voxel2_f32, evk_image2_nearest_f32 / _bilinear_f32, evk_image2_splat_indexed_f32,
- * evk_timestamp_images2_f32): the event columns need only the alignment of their elements (4 bytes; 8 for int64 pixels) instead
+ * evk_image2_splat_drv_indexed_f32 (pixels and fractions), evk_timestamp_images2_f32): the event columns need only the alignment of their elements (4 bytes; 8 for int64 pixels) instead
  * of 16 bytes -- a device SLICE xs[a:b] of a resident stream is read where it lies.  The kernels load 16 bytes at a time and a
  * group of four events that is only partly inside the stream is loaded whole: the caller guarantees that the 12 bytes (24 for
  * int64) behind every column's last event are readable (inside the same allocation).  Without the flag a column that is not
