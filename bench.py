@@ -771,8 +771,9 @@ def bench_image_10m(E, tiled, dev, impl):
                 **({"traffic": pmc_traffic("k_part_sorted", "img_timestamp")[2],
                     "traffic_source": pmc_traffic("k_part_sorted", "img_timestamp")[1]}
                    if pmc_traffic("k_part_sorted", "img_timestamp")[2] else {}),
-                "note": "16 B/event + four planes; the tile kernel is bound by its eight LDS atomics per event (four float64, four "
-                        "64-bit fixed-point); direct_kernel_ms = evk_timestamp_images_f32, eight global atomics per event"}
+                "note": "16 B/event + four planes; the tile kernel is bound by its eight 64-bit fixed-point LDS atomics per event (events "
+                        "whose normalised time lies outside [-1, 1] add float64 values to a window of their own); direct_kernel_ms = "
+                        "evk_timestamp_images_f32, eight global atomics per event"}
         E.check_errors()
     except Exception as e:  # noqa: BLE001
         res["events_to_timestamp_image_torch"] = {"error": repr(e)}

@@ -756,7 +756,8 @@ __global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__
                                                        TileGridG g, Part2 q, int flags, float *__restrict__ out4,
                                                        float *__restrict__ staging) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ts_smem[];
-    acc_t *const win = reinterpret_cast<acc_t *>(ts_smem);   // [4][wcells]: time+ | count+ | time- | count-
+    // [4][wcells]: time+ | count+ | time- | count-; fixed-point mode: [4] and [5] take the time of events with |nts| > 1 (float64)
+    acc_t *const win = reinterpret_cast<acc_t *>(ts_smem);
     __shared__ uint2 cseg[WG / 64][IMG_CAP + 1];
     const int ntiles = g.tiles_x * g.tiles_y;
     ImgItem it;
@@ -764,7 +765,7 @@ __global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__
     const bool fixed = !(flags & EVK_IMAGE2_NO_FIXED);
     const int tw = g.tw, th = g.th;
     const int ww = tw + 1, wh = th + 1, wpitch = ww | 1, wcells = wpitch * wh;
-    for (int i = threadIdx.x; i < 4 * wcells; i += WG) win[i] = 0.0;
+    for (int i = threadIdx.x; i < (fixed ? 6 : 4) * wcells; i += WG) win[i] = 0.0;
     unsigned long long *const winq = reinterpret_cast<unsigned long long *>(win);
     auto one = [&](auto fixed_tag, uint32_t xb, uint32_t yb, uint32_t wside) {
         constexpr bool FIXED = decltype(fixed_tag)::value;
@@ -777,18 +778,32 @@ __global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__
         const int c0 = __mul24((int)fy, wpitch) + (int)fx;
         acc_t *const val = win + __mul24((int)(2u * k), wcells);
         const float nts = __uint_as_float(wside);
-        const float ta_ = nts * ax, td_ = nts * dx;
-        lds_add(val + c0, ta_ * ay), lds_add(val + c0 + 1, td_ * ay), lds_add(val + c0 + wpitch, ta_ * dy),
-            lds_add(val + c0 + wpitch + 1, td_ * dy);
         if constexpr (FIXED) {
-            unsigned long long *const cnt = winq + __mul24((int)(2u * k + 1u), wcells);
-            const float wa = IMG_FIX_ONE * ax, wd = IMG_FIX_ONE * dx;   // the weight is 1.0: 1.0f * ax == ax
-            auto addq = [&](int c, float v) {
-                __hip_atomic_fetch_add(cnt + c, (unsigned long long)(long long)__float2int_rn(v), __ATOMIC_RELAXED,
+            // 64-bit integer LDS atomics run at 4.1 lane-operations per clock and CU, float64 ones at 2.9: the
+            // normalised time of a SORTED stream lies in [0, 1], so its four products go in as 2^-30 steps like the count's (a
+            // power of two commutes with every rounding); an event beyond that -- unsorted time stamps, mode 2 with large t, NaN
+            // -- adds float64 values to a window of its own (wave-divergent only there)
+            auto addq = [&](unsigned long long *base, int c, float v) {
+                __hip_atomic_fetch_add(base + c, (unsigned long long)(long long)__float2int_rn(v), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             };
-            addq(c0, wa * ay), addq(c0 + 1, wd * ay), addq(c0 + wpitch, wa * dy), addq(c0 + wpitch + 1, wd * dy);
+            if (fabsf(nts) <= 1.0f) {
+                unsigned long long *const tq = winq + __mul24((int)(2u * k), wcells);
+                const float ns = nts * IMG_FIX_ONE, ta_ = ns * ax, td_ = ns * dx;
+                addq(tq, c0, ta_ * ay), addq(tq, c0 + 1, td_ * ay), addq(tq, c0 + wpitch, ta_ * dy), addq(tq, c0 + wpitch + 1, td_ * dy);
+            } else {
+                acc_t *const esc = win + __mul24((int)(4u + k), wcells);
+                const float ta_ = nts * ax, td_ = nts * dx;
+                lds_add(esc + c0, ta_ * ay), lds_add(esc + c0 + 1, td_ * ay), lds_add(esc + c0 + wpitch, ta_ * dy),
+                    lds_add(esc + c0 + wpitch + 1, td_ * dy);
+            }
+            unsigned long long *const cnt = winq + __mul24((int)(2u * k + 1u), wcells);
+            const float wa = IMG_FIX_ONE * ax, wd = IMG_FIX_ONE * dx;   // the weight is 1.0: 1.0f * ax == ax
+            addq(cnt, c0, wa * ay), addq(cnt, c0 + 1, wd * ay), addq(cnt, c0 + wpitch, wa * dy), addq(cnt, c0 + wpitch + 1, wd * dy);
         } else {
+            const float ta_ = nts * ax, td_ = nts * dx;
+            lds_add(val + c0, ta_ * ay), lds_add(val + c0 + 1, td_ * ay), lds_add(val + c0 + wpitch, ta_ * dy),
+                lds_add(val + c0 + wpitch + 1, td_ * dy);
             acc_t *const cnt = val + wcells;
             lds_add(cnt + c0, ax * ay), lds_add(cnt + c0 + 1, dx * ay), lds_add(cnt + c0 + wpitch, ax * dy),
                 lds_add(cnt + c0 + wpitch + 1, dx * dy);
@@ -817,7 +832,10 @@ __global__ void __launch_bounds__(WG) k_image_tiles_ts(const uint2 *__restrict__
     const int64_t plane = (int64_t)g.dom_h * g.dom_w;
     auto lds_cell = [&](int pl, int c) -> float {
         const int row = (int)div_magic((uint32_t)c, mw), col = c - row * ww, l = pl * wcells + row * wpitch + col;
-        if (fixed && (pl & 1)) return (float)((double)(long long)winq[l] * (1.0 / (double)IMG_FIX_ONE));
+        if (fixed) {   // count: integer steps; time: integer steps + the float64 window of the events beyond [-1, 1]
+            const double q30 = (double)(long long)winq[l] * (1.0 / (double)IMG_FIX_ONE);
+            return (float)((pl & 1) ? q30 : q30 + win[l + (4 - pl / 2) * wcells]);     // time plane 0 -> window 4, 2 -> 5
+        }
         return (float)win[l];
     };
     // interior pixels belong to this window alone (plain read-modify-write), the ring is shared with the neighbours' windows
@@ -1117,13 +1135,13 @@ extern "C" int evk_timestamp_images2_f32(const float *x, const float *y, const f
                                    host_report, seq, s, from_events);
     if (!(flags & EVK_VOXEL2_PARTITION_ONLY)) {
         const int wcells = ((tile_w + 1) | 1) * (tile_h + 1);
-        const size_t lds = (size_t)4 * wcells * sizeof(acc_t);
+        const size_t lds = (size_t)((flags & EVK_IMAGE2_NO_FIXED) ? 4 : 6) * wcells * sizeof(acc_t);
         static std::once_flag once[64];   // per device: the attribute belongs to the loaded code object
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::call_once(once[dev & 63], [] {
             (void)hipFuncSetAttribute((const void *)k_image_tiles_ts<IMG_WG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      4 * IMG_WIN_MAX * (int)sizeof(acc_t));
+                                      6 * IMG_WIN_MAX * (int)sizeof(acc_t));
         });
         k_image_tiles_ts<IMG_WG><<<v2_max_items(n, ic.ntiles), IMG_WG, lds, s>>>(
             (const uint2 *)(sb + ic.L.rec), (const uint32_t *)(sb + ic.L.pw), (const uint32_t *)(sb + ic.L.table), index, ic.g,
