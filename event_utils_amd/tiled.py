@@ -453,7 +453,7 @@ def voxel2_bands(cols, n, t_first, t_last, B, H, W, nbands, oob=None):
     return gen()
 
 
-def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0):
+def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, split_polarity=False, stage=0, aligned=False):
     """evk_voxel2_f32 / evk_voxel2_native_f32: partition + tile kernel from ONE library call.  t_first None = ts[0] and
     ts[-1] are read on the device (no transfer before the launch)."""
     index, scratch, nbytes, flags = _voxel2_env(out.device, n, B, H, W, tw, th, split_polarity)
@@ -468,7 +468,8 @@ def voxel2(cols, native, n, t_first, t_last, B, H, W, tw, th, out, oob, fresh, s
     tail = (H, W, tw, th, t_first, t_last, B, flags, D.ptr(out), D.ptr(index), D.ptr(scratch), sizes[1],
             oob.ptr if oob is not None else None, report, seq, D.stream())
     if native is None:
-        if any(c is not None and c.data_ptr() % 16 for c in cols):      # a device slice, read where it lies (can_tile checked the slack behind it)
+        # a device slice is read where it lies (can_tile checked the slack behind it); aligned=True: the caller has looked already
+        if not aligned and any(c is not None and c.data_ptr() % 16 for c in cols):
             tail = tail[:7] + (flags | _lib.EVK_COLUMNS_UNALIGNED,) + tail[8:]
         _rezero_on_failure(index, lambda: _lib.call("evk_%s_f32" % ver, *(D.ptr(c) for c in cols), n, *tail))
     else:
@@ -697,13 +698,16 @@ def voxel_f32(xd, yd, td, pd, t_first, t_last, B, H, W, out, oob=None, impl=None
     if native is not None:
         tileable = impl != "direct" and native.aligned() and (impl == "tiled" or native.n >= TILED_MIN_EVENTS_NATIVE)
     else:
-        xd, yd, td, pd = realign((xd, yd, td, pd), impl, 2)
+        # (the common case -- freshly allocated columns -- costs four pointer reads here and skips the slice handling)
+        aligned16 = not ((xd.data_ptr() | yd.data_ptr() | td.data_ptr() | pd.data_ptr()) & 15)
+        if not aligned16:
+            xd, yd, td, pd = realign((xd, yd, td, pd), impl, 2)
         tileable = can_tile((xd, yd, td, pd), impl)
     if tileable:
         shape2 = voxel2_shape(H, W, B)
         if shape2 is not None:
             voxel2((xd, yd, td, pd), native, xd.shape[0] if native is None else native.n, t_first, t_last, B, H, W, *shape2,
-                   out, oob, fresh)
+                   out, oob, fresh, aligned=native is None and aligned16)
             return out
     if det and (xd.shape[0] if native is None else native.n):
         raise ValueError("EVK_VOXEL_DETERMINISTIC=1: the one-pass path cannot take this call (%d bins of %dx%d: no tiling "
